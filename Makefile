@@ -1,0 +1,65 @@
+# Build of the eMI355X backend (no cmake/ninja needed; hipcc + g++ + make).
+#
+#   make            -> etol_amd/lib/libemi355x.so      (HIP kernels + C ABI, gfx950)
+#                      etol_amd/lib/libetol_mi355x.so  (C++ host: TrajectoryOptimizer + eMI355X)
+#                      etol_amd/lib/etol_mi355x_example1, tests/harness/libetol_harness.so
+#   make oracle     -> oracle/liboracle.so, oracle/libepsopt_style.so  (test infrastructure)
+#
+# Built artefacts are git-ignored but travel to the GPU box with the snapshot.
+ROCM      ?= /opt/rocm
+HIPCC     ?= $(ROCM)/bin/hipcc
+CXX       ?= g++
+CC        ?= gcc
+ARCH      ?= gfx950
+LIBDIR    := etol_amd/lib
+CSRC      := etol_amd/csrc
+HOST      := etol_amd/host
+
+HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+CXXFLAGS  := -O2 -std=c++17 -fPIC -Iinclude -Wall
+XML2_INC  := -I/usr/include/libxml2
+XML2_LIB  := -lxml2
+
+.PHONY: all lib host oracle clean
+ifneq ($(wildcard etol_amd/host/eMI355X.cpp),)
+all: lib host oracle
+else
+all: lib oracle
+endif
+
+lib: $(LIBDIR)/libemi355x.so
+host: $(LIBDIR)/libetol_mi355x.so $(LIBDIR)/etol_mi355x_example1 tests/harness/libetol_harness.so
+
+$(LIBDIR):
+	mkdir -p $(LIBDIR)
+
+$(LIBDIR)/emi_kernels.o: $(CSRC)/emi_kernels.hip $(CSRC)/emi_kernels.hpp $(CSRC)/emi_models.hpp include/emi355x.h | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(LIBDIR)/emi_api.o: $(CSRC)/emi_api.hip $(CSRC)/emi_kernels.hpp $(CSRC)/emi_models.hpp include/emi355x.h | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(LIBDIR)/emi_host.o: $(CSRC)/emi_host.cpp include/emi355x.h | $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -c $< -o $@
+
+$(LIBDIR)/libemi355x.so: $(LIBDIR)/emi_kernels.o $(LIBDIR)/emi_api.o $(LIBDIR)/emi_host.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+HOST_SRC := $(HOST)/TrajectoryOptimizer.cpp $(HOST)/eMI355X.cpp $(HOST)/emi_nlp.cpp
+HOST_HDR := $(wildcard include/ETOL/*.hpp) $(wildcard $(HOST)/*.hpp) include/emi355x.h
+
+$(LIBDIR)/libetol_mi355x.so: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libemi355x.so
+	$(CXX) $(CXXFLAGS) $(XML2_INC) -I$(HOST) -shared -o $@ $(HOST_SRC) -L$(LIBDIR) -lemi355x $(XML2_LIB) \
+		-Wl,-rpath,'$$ORIGIN'
+
+$(LIBDIR)/etol_mi355x_example1: etol_amd/examples/etol_mi355x_example1.cpp $(LIBDIR)/libetol_mi355x.so
+	$(CXX) $(CXXFLAGS) -I$(HOST) -o $@ $< -L$(LIBDIR) -letol_mi355x -lemi355x -Wl,-rpath,'$$ORIGIN'
+
+tests/harness/libetol_harness.so: tests/harness/etol_harness.cpp $(LIBDIR)/libetol_mi355x.so
+	$(CXX) $(CXXFLAGS) -I$(HOST) -shared -o $@ $< -L$(LIBDIR) -letol_mi355x -lemi355x \
+		-Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -rf $(LIBDIR) tests/harness/*.so
+	$(MAKE) -C oracle clean

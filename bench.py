@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- collocation-node constraint+Jacobian evaluations per second on MI355X.
+
+A "step" is ONE full evaluation pass of the hot path over the rank's batch of synthetic
+problem instances (BASELINE.json config 3: 6-state quadrotor VGP, N=1024 LGL nodes, 20 static
+keep-outs), producing for every node F, C, L, the defect row, dF, dC, dL with the Jacobian
+values landed in the NLP value array and the cost reduced.
+Inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Instances shard across ranks with no data-path collective (weak scaling: B per GPU); the
+only collective of the path, the gather of the trajectories, runs once after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES = {"c3": 1040, "c2": 560, "c5": 944}       # SURVEY.md section 8d, per node-eval
+HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6                               # MI355X fp64 matrix
+
+
+def cpu_baseline(M, n_obs, budget_s=10.0):
+    """ePSOPT-style CPU port (oracle/epsopt_style.cpp) on a bounded sample of the same workload,
+    all host cores via OpenMP over instances.  Checker/baseline only, never the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+    from etol_amd import workloads as W
+    from etol_amd import lgl
+    cores = O.eps().eps_max_threads()
+    Bs = max(cores, 8)
+    X, U, recs = W.quadrotor_batch(2, Bs, M, n_obs)
+    mesh = lgl(M)
+    O.evaluate(1, W.QUAD_PARAMS, M, mesh, 0.0, W.TF, X, U, recs, style="epsopt", nthreads=cores)  # warm
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        O.evaluate(1, W.QUAD_PARAMS, M, mesh, 0.0, W.TF, X, U, recs, style="epsopt", nthreads=cores)
+        passes += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or passes >= 200:
+            break
+    return {"value": Bs * M * passes / el, "unit": "node-evals/s", "cores": int(cores), "kind": "port",
+            "sample": f"{passes} passes over {Bs} instances x {M} nodes (ePSOPT-style std::any/dual-number port, "
+                      f"OpenMP over instances), {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1024, help="problem instances per GPU")
+    ap.add_argument("--nodes", type=int, default=1024)
+    ap.add_argument("--obstacles", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=10.0)
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import etol_amd as E
+    from etol_amd import workloads as W
+
+    M, B, n_obs = a.nodes, a.batch, a.obstacles
+    ev = E.Evaluator(local)
+    ev.set_mesh(M, 0.0, W.TF)
+    ev.set_model(E.MODEL_QUADROTOR2D, W.QUAD_PARAMS)
+    ev.set_batch(B)
+    X, U, recs = W.quadrotor_batch(3, B, M, n_obs, first_instance=rank * B)   # scenario s -> rank s // B
+    if n_obs:
+        ev.set_path(recs, 0, 1)
+    dev = torch.device("cuda", local)
+    dX = torch.from_numpy(X).to(dev)
+    dU = torch.from_numpy(U).to(dev)
+    RES, VALS, COST = ev.alloc_outputs()
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(a.warmup):
+        ev.eval_dev(dX, dU, RES, VALS, COST)
+    torch.cuda.synchronize()
+    ev.profile(True)          # HIP-event brackets around each kernel, on the launch stream
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ev.eval_dev(dX, dU, RES, VALS, COST)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    prof = ev.profile_read()
+    ev.profile(False)
+
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    ms_per_step = 1e3 * el / a.steps
+    value = world * B * M * a.steps / el
+
+    # the path's one collective: gather the trajectories to rank 0 (once per batch, untimed)
+    gather_ms = None
+    if world > 1:
+        traj = torch.cat([dX.reshape(B, -1), dU.reshape(B, -1)], dim=1).contiguous()
+        out = [torch.empty_like(traj) for _ in range(world)] if rank == 0 else None
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        dist.gather(traj, out, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = 1e3 * (time.perf_counter() - tg)
+
+    if rank == 0:
+        node_ms = prof["node_ms"] / max(prof["node_launches"], 1)
+        def_ms = prof["defect_ms"] / max(prof["defect_launches"], 1)
+        key = "c3" if n_obs == 20 else "c2"
+        alg_bytes = (ALG_BYTES[key] if n_obs in (0, 20) else 560 + 24 * n_obs) * B * M
+        flops = 2.0 * M * 6 * B * M
+        if node_ms >= def_ms:
+            ach = alg_bytes / (node_ms * 1e-3) / 1e9
+            roof = {"kernel": "emi_nodes_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": node_ms}
+        else:
+            ach = flops / (def_ms * 1e-3) / 1e12
+            roof = {"kernel": "emi_defect_f64_kernel", "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": None, "avg_ms": def_ms}
+        roof["other_kernel_ms"] = {"emi_nodes_kernel": node_ms, "emi_defect_f64_kernel": def_ms}
+        line = {
+            "metric": "collocation-node constraint+Jacobian evals/sec, 6-state VGP N=1024",
+            "value": value, "unit": "node-evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"config[2]: 6-state quadrotor VGP, N={M} LGL nodes + {n_obs} static keep-outs, "
+                                   f"{B} instances per GPU", "nodes": M, "instances_per_gpu": B,
+                       "path_rows": n_obs, "parallelism": f"instances sharded x{world}", "gather_ms": gather_ms},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(M, n_obs, a.cpu_budget)
+        print(json.dumps(line), flush=True)
+    ev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

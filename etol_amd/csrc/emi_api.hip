@@ -1,0 +1,594 @@
+// emi_api.hip -- device side of the C ABI declared in include/emi355x.h.
+//
+// A context owns: the HIP stream, the mesh constants on the device (w, node
+// times, diag(D), D), the path/track tables, and scratch for the cost
+// partials.  Trajectory and result arrays belong to the caller (device
+// pointers), except in the *_host forms which stage through context-owned
+// buffers.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "emi355x.h"
+#include "emi_kernels.hpp"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ProfEvents {
+    hipEvent_t e[3];
+    bool has_node, has_defect;
+};
+
+}  // namespace
+
+struct emi_ctx_s {
+    int device = 0;
+    bool f32 = false;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // mesh
+    int M = 0;
+    double t0 = 0, tf = 0;
+    DevBuf d_w, d_t, d_Ddiag, d_D;
+    std::vector<double> h_tau, h_w;
+    // model
+    int model = -1, ns = 0, nc = 0, maximize = 0;
+    double params[EMI_MAX_PARAMS] = {0};
+    // batch / path
+    int B = 0;
+    int np = 0, path_sets = 0, px = 0, py = 1;
+    DevBuf d_path;
+    int ntracks = 0, track_sets = 0;
+    DevBuf d_trkx, d_trky;
+    DevBuf d_cost_part;
+    // host-form staging
+    DevBuf s_X, s_U, s_RES, s_VALS, s_COST, s_LF, s_LC, s_H;
+    // measurement
+    hipEvent_t t_start = nullptr, t_stop = nullptr;
+    bool profile = false;
+    std::vector<ProfEvents> prof;
+    size_t prof_used = 0;
+    bool attr_set = false;
+};
+
+namespace {
+
+int fail(emi_ctx_t c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                              \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess)                                                         \
+            return fail((c), EMI_ERR_HIP, "%s failed: %s (%s:%d)", #call,             \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                   \
+    } while (0)
+
+int ensure(emi_ctx_t c, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return EMI_OK;
+    if (b.p) { HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    if (bytes == 0) return EMI_OK;
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return EMI_OK;
+}
+
+// upload a host double array in the context's real type
+int upload_real(emi_ctx_t c, DevBuf& b, const double* src, size_t n) {
+    const size_t rb = c->f32 ? 4 : 8;
+    int st = ensure(c, b, n * rb);
+    if (st) return st;
+    if (n == 0) return EMI_OK;
+    if (c->f32) {
+        std::vector<float> tmp(n);
+        for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
+        HIP_TRY(c, hipMemcpyAsync(b.p, tmp.data(), n * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(b.p, src, n * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return EMI_OK;
+}
+
+int download_real(emi_ctx_t c, double* dst, const void* dsrc, size_t n) {
+    if (!dst || n == 0) return EMI_OK;
+    if (c->f32) {
+        std::vector<float> tmp(n);
+        HIP_TRY(c, hipMemcpyAsync(tmp.data(), dsrc, n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (size_t i = 0; i < n; ++i) dst[i] = tmp[i];
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(dst, dsrc, n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return EMI_OK;
+}
+
+int nvals_of(emi_ctx_t c) { return c->ns * (c->ns + c->nc) + 2 * c->np + (c->ns + c->nc); }
+int nres_of(emi_ctx_t c) { return c->ns + c->np; }
+int nhess_of(emi_ctx_t c) { const int nv = c->ns + c->nc; return nv * (nv + 1) / 2; }
+
+int ready(emi_ctx_t c) {
+    if (!c) return EMI_ERR_ARG;
+    if (c->M <= 0) return fail(c, EMI_ERR_STATE, "emi_set_mesh has not been called");
+    if (c->model < 0) return fail(c, EMI_ERR_STATE, "emi_set_model has not been called");
+    if (c->B <= 0) return fail(c, EMI_ERR_STATE, "emi_set_batch has not been called");
+    if (c->np > 0 && c->path_sets != 1 && c->path_sets != c->B)
+        return fail(c, EMI_ERR_STATE, "path table has %d sets, batch is %d", c->path_sets, c->B);
+    if (c->ntracks > 0 && c->track_sets != 1 && c->track_sets != c->B)
+        return fail(c, EMI_ERR_STATE, "track table has %d sets, batch is %d", c->track_sets, c->B);
+    return EMI_OK;
+}
+
+template <typename T>
+void fill_node_args(emi_ctx_t c, emi::NodeArgs<T>& a, const void* dX, const void* dU, void* dRES,
+                    void* dVALS, void* dCOST) {
+    a.X = (const T*)dX;
+    a.U = (const T*)dU;
+    a.RES = (T*)dRES;
+    a.VALS = (T*)dVALS;
+    a.cost_part = (T*)c->d_cost_part.p;
+    a.cost = (T*)dCOST;
+    a.w = (const T*)c->d_w.p;
+    a.node_t = (const T*)c->d_t.p;
+    a.Ddiag = (const T*)c->d_Ddiag.p;
+    a.path = (const T*)c->d_path.p;
+    a.track_x = (const T*)c->d_trkx.p;
+    a.track_y = (const T*)c->d_trky.p;
+    a.M = c->M;
+    a.B = c->B;
+    a.np = c->np;
+    a.nres = nres_of(c);
+    a.nvals = nvals_of(c);
+    a.path_sets = c->path_sets;
+    a.track_sets = c->track_sets;
+    a.ntracks = c->ntracks;
+    a.px = c->px;
+    a.py = c->py;
+    a.h = (T)((c->tf - c->t0) / 2.0);
+    a.sgn = c->maximize ? T(-1) : T(1);
+    for (int i = 0; i < EMI_MAX_PARAMS; ++i) a.P.p[i] = (T)c->params[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int emi_device_count(int* count) {
+    if (!count) return EMI_ERR_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return EMI_OK;
+}
+
+static int create_impl(int device_id, bool f32, emi_ctx_t* out) {
+    if (!out) return EMI_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return EMI_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= n) return EMI_ERR_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return EMI_ERR_HIP;
+    // gfx950 only: the code object holds no other ISA
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return EMI_ERR_NO_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return EMI_ERR_HIP;
+    emi_ctx_t c = new emi_ctx_s();
+    c->device = device_id;
+    c->f32 = f32;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return EMI_ERR_HIP;
+    }
+    c->own_stream = true;
+    if (hipEventCreate(&c->t_start) != hipSuccess || hipEventCreate(&c->t_stop) != hipSuccess) {
+        delete c;
+        return EMI_ERR_HIP;
+    }
+    *out = c;
+    return EMI_OK;
+}
+
+int emi_create(int device_id, emi_ctx_t* out) { return create_impl(device_id, false, out); }
+int emi_create_f32(int device_id, emi_ctx_t* out) { return create_impl(device_id, true, out); }
+
+int emi_destroy(emi_ctx_t c) {
+    if (!c) return EMI_ERR_ARG;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->d_w, &c->d_t, &c->d_Ddiag, &c->d_D, &c->d_path, &c->d_trkx, &c->d_trky,
+                      &c->d_cost_part, &c->s_X, &c->s_U, &c->s_RES, &c->s_VALS, &c->s_COST,
+                      &c->s_LF, &c->s_LC, &c->s_H};
+    for (DevBuf* b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto& pe : c->prof)
+        for (int i = 0; i < 3; ++i) (void)hipEventDestroy(pe.e[i]);
+    if (c->t_start) (void)hipEventDestroy(c->t_start);
+    if (c->t_stop) (void)hipEventDestroy(c->t_stop);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return EMI_OK;
+}
+
+const char* emi_last_error(emi_ctx_t c) { return c ? c->err.c_str() : "null context"; }
+
+int emi_set_stream(emi_ctx_t c, void* s) {
+    if (!c) return EMI_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (s == nullptr) {
+        if (!c->own_stream) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            c->own_stream = true;
+        }
+        return EMI_OK;
+    }
+    if (c->own_stream) { HIP_TRY(c, hipStreamDestroy(c->stream)); c->own_stream = false; }
+    c->stream = (hipStream_t)s;
+    return EMI_OK;
+}
+
+int emi_get_stream(emi_ctx_t c, void** s) {
+    if (!c || !s) return EMI_ERR_ARG;
+    *s = (void*)c->stream;
+    return EMI_OK;
+}
+
+int emi_synchronize(emi_ctx_t c) {
+    if (!c) return EMI_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EMI_OK;
+}
+
+int emi_set_mesh(emi_ctx_t c, int M, const double* tau, const double* w, const double* D, double t0,
+                 double tf) {
+    if (!c || M < 2 || !tau || !w || !D) return fail(c, EMI_ERR_ARG, "emi_set_mesh: bad argument");
+    if (!(tf > t0)) return fail(c, EMI_ERR_ARG, "emi_set_mesh: tf must exceed t0");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const double h = (tf - t0) / 2.0;
+    std::vector<double> nt(M), dd(M);
+    for (int k = 0; k < M; ++k) {
+        nt[k] = t0 + h * (tau[k] + 1.0);
+        dd[k] = D[(size_t)k * M + k];
+    }
+    int st;
+    if ((st = upload_real(c, c->d_w, w, M))) return st;
+    if ((st = upload_real(c, c->d_t, nt.data(), M))) return st;
+    if ((st = upload_real(c, c->d_Ddiag, dd.data(), M))) return st;
+    if ((st = upload_real(c, c->d_D, D, (size_t)M * M))) return st;
+    c->h_tau.assign(tau, tau + M);
+    c->h_w.assign(w, w + M);
+    c->M = M;
+    c->t0 = t0;
+    c->tf = tf;
+    // tables sized by M are stale now
+    c->ntracks = 0;
+    c->track_sets = 0;
+    return EMI_OK;
+}
+
+int emi_set_model(emi_ctx_t c, int model, const double* params, int nparams, int maximize) {
+    if (!c) return EMI_ERR_ARG;
+    int ns, nc, np_expected;
+    if (emi_model_dims(model, &ns, &nc, &np_expected)) return fail(c, EMI_ERR_ARG, "unknown model %d", model);
+    if (nparams != np_expected || (nparams > 0 && !params))
+        return fail(c, EMI_ERR_ARG, "model %d takes %d parameters, got %d", model, np_expected, nparams);
+    c->model = model;
+    c->ns = ns;
+    c->nc = nc;
+    c->maximize = maximize ? 1 : 0;
+    memset(c->params, 0, sizeof c->params);
+    for (int i = 0; i < nparams; ++i) c->params[i] = params[i];
+    return EMI_OK;
+}
+
+int emi_set_batch(emi_ctx_t c, int B) {
+    if (!c || B < 1) return fail(c, EMI_ERR_ARG, "emi_set_batch: B must be >= 1");
+    if (c->M <= 0) return fail(c, EMI_ERR_STATE, "emi_set_mesh must precede emi_set_batch");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t rb = c->f32 ? 4 : 8;
+    int st = ensure(c, c->d_cost_part, (size_t)B * emi::node_chunks(c->M) * rb);
+    if (st) return st;
+    c->B = B;
+    return EMI_OK;
+}
+
+int emi_set_path(emi_ctx_t c, int np, int nsets, const double* recs, int px_state, int py_state) {
+    if (!c || np < 0) return fail(c, EMI_ERR_ARG, "emi_set_path: bad argument");
+    if (c->model < 0) return fail(c, EMI_ERR_STATE, "emi_set_model must precede emi_set_path");
+    if (np > 0 && (!recs || nsets < 1)) return fail(c, EMI_ERR_ARG, "emi_set_path: null table");
+    if (px_state < 0 || px_state >= c->ns || py_state < 0 || py_state >= c->ns || px_state == py_state)
+        return fail(c, EMI_ERR_ARG, "emi_set_path: state indices (%d,%d) out of range", px_state, py_state);
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (size_t i = 0; i < (size_t)np * nsets; ++i) {
+        const int kind = (int)recs[i * EMI_PATH_REC];
+        if (kind != EMI_PATH_ELLIPSE && kind != EMI_PATH_DISC && kind != EMI_PATH_TRACK)
+            return fail(c, EMI_ERR_ARG, "emi_set_path: record %zu has unknown kind %d", i, kind);
+    }
+    int st = upload_real(c, c->d_path, recs, (size_t)np * nsets * EMI_PATH_REC);
+    if (st) return st;
+    c->np = np;
+    c->path_sets = np > 0 ? nsets : 0;
+    c->px = px_state;
+    c->py = py_state;
+    return EMI_OK;
+}
+
+int emi_set_tracks(emi_ctx_t c, int ntracks, int nsets, const double* xc, const double* yc) {
+    if (!c || ntracks < 0) return fail(c, EMI_ERR_ARG, "emi_set_tracks: bad argument");
+    if (c->M <= 0) return fail(c, EMI_ERR_STATE, "emi_set_mesh must precede emi_set_tracks");
+    if (ntracks > 0 && (!xc || !yc || nsets < 1)) return fail(c, EMI_ERR_ARG, "emi_set_tracks: null table");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)ntracks * nsets * c->M;
+    int st;
+    if ((st = upload_real(c, c->d_trkx, xc, n))) return st;
+    if ((st = upload_real(c, c->d_trky, yc, n))) return st;
+    c->ntracks = ntracks;
+    c->track_sets = ntracks > 0 ? nsets : 0;
+    return EMI_OK;
+}
+
+int emi_get_layout(emi_ctx_t c, emi_layout_t* o) {
+    if (!c || !o) return EMI_ERR_ARG;
+    o->model = c->model;
+    o->ns = c->ns;
+    o->nc = c->nc;
+    o->np = c->np;
+    o->M = c->M;
+    o->B = c->B;
+    o->nres = nres_of(c);
+    o->nvals = nvals_of(c);
+    o->nhess = nhess_of(c);
+    o->real_bytes = c->f32 ? 4 : 8;
+    o->px = c->px;
+    o->py = c->py;
+    o->t0 = c->t0;
+    o->tf = c->tf;
+    return EMI_OK;
+}
+
+// Per-instance NLP numbering (DESIGN.md "NLP layout"):
+//   variables   z: state i node k -> i*M + k ; control c node k -> (ns+c)*M + k
+//   constraints g: defect (i,k) -> i*M + k ; events ns*M + e (e < 2 ns) ;
+//                  path (j,k) -> ns*M + 2 ns + j*M + k
+int emi_jac_structure(emi_ctx_t c, int* rows, int* cols) {
+    if (!c || !rows || !cols) return EMI_ERR_ARG;
+    if (c->M <= 0 || c->model < 0) return fail(c, EMI_ERR_STATE, "mesh and model must be set");
+    const int M = c->M, ns = c->ns, nv = c->ns + c->nc, np = c->np;
+    size_t e = 0;
+    for (int i = 0; i < ns; ++i)
+        for (int v = 0; v < nv; ++v)
+            for (int k = 0; k < M; ++k, ++e) { rows[e] = i * M + k; cols[e] = v * M + k; }
+    for (int j = 0; j < np; ++j)
+        for (int s = 0; s < 2; ++s)
+            for (int k = 0; k < M; ++k, ++e) {
+                rows[e] = ns * M + 2 * ns + j * M + k;
+                cols[e] = (s == 0 ? c->px : c->py) * M + k;
+            }
+    for (int v = 0; v < nv; ++v)
+        for (int k = 0; k < M; ++k, ++e) { rows[e] = -1; cols[e] = v * M + k; }
+    return EMI_OK;
+}
+
+int emi_dev_alloc(emi_ctx_t c, size_t bytes, void** dptr) {
+    if (!c || !dptr) return EMI_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMalloc(dptr, bytes));
+    return EMI_OK;
+}
+int emi_dev_free(emi_ctx_t c, void* dptr) {
+    if (!c) return EMI_ERR_ARG;
+    HIP_TRY(c, hipFree(dptr));
+    return EMI_OK;
+}
+int emi_h2d(emi_ctx_t c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return EMI_ERR_ARG;
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EMI_OK;
+}
+int emi_d2h(emi_ctx_t c, void* dst, const void* src, size_t bytes) {
+    if (!c || !dst || !src) return EMI_ERR_ARG;
+    HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EMI_OK;
+}
+
+int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* dVALS, void* dCOST,
+                 unsigned flags) {
+    int st = ready(c);
+    if (st) return st;
+    const bool nodes = flags & EMI_EVAL_NODES, defect = flags & EMI_EVAL_DEFECT;
+    const bool jac = !(flags & EMI_EVAL_NOJAC);
+    if (!nodes && !defect) return fail(c, EMI_ERR_ARG, "emi_eval: empty flags");
+    if (!dX || !dRES || (nodes && (!dU || !dCOST || (jac && !dVALS))))
+        return fail(c, EMI_ERR_ARG, "emi_eval: null device pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->attr_set) {
+        HIP_TRY(c, emi::defect_f64_set_attr());
+        c->attr_set = true;
+    }
+    ProfEvents* pe = nullptr;
+    if (c->profile) {
+        if (c->prof_used == c->prof.size()) {
+            ProfEvents n;
+            for (int i = 0; i < 3; ++i) HIP_TRY(c, hipEventCreate(&n.e[i]));
+            c->prof.push_back(n);
+        }
+        pe = &c->prof[c->prof_used++];
+        pe->has_node = nodes;
+        pe->has_defect = defect;
+        HIP_TRY(c, hipEventRecord(pe->e[0], c->stream));
+    }
+    if (nodes) {
+        if (c->f32) {
+            emi::NodeArgs<float> a;
+            fill_node_args(c, a, dX, dU, dRES, dVALS, dCOST);
+            HIP_TRY(c, emi::launch_nodes<float>(c->model, a, jac, c->stream));
+        } else {
+            emi::NodeArgs<double> a;
+            fill_node_args(c, a, dX, dU, dRES, dVALS, dCOST);
+            HIP_TRY(c, emi::launch_nodes<double>(c->model, a, jac, c->stream));
+        }
+    }
+    if (pe) HIP_TRY(c, hipEventRecord(pe->e[1], c->stream));
+    if (defect) {
+        if (c->f32) {
+            emi::DefectArgsF32 a{(const float*)dX, (const float*)c->d_D.p, (float*)dRES, c->B * c->ns,
+                                 c->M, c->ns, nres_of(c)};
+            HIP_TRY(c, emi::launch_defect_f32(a, c->stream));
+        } else {
+            emi::DefectArgs a{(const double*)dX, (const double*)c->d_D.p, (double*)dRES, c->B * c->ns,
+                              c->M, c->ns, nres_of(c)};
+            HIP_TRY(c, emi::launch_defect_f64(a, c->stream));
+        }
+    }
+    if (pe) HIP_TRY(c, hipEventRecord(pe->e[2], c->stream));
+    return EMI_OK;
+}
+
+int emi_eval_host(emi_ctx_t c, const double* X, const double* U, double* RES, double* VALS,
+                  double* COST, unsigned flags) {
+    int st = ready(c);
+    if (st) return st;
+    if (!X || !U) return fail(c, EMI_ERR_ARG, "emi_eval_host: null input");
+    const size_t rb = c->f32 ? 4 : 8;
+    const size_t nX = (size_t)c->B * c->ns * c->M, nU = (size_t)c->B * c->nc * c->M;
+    const size_t nR = (size_t)c->B * nres_of(c) * c->M, nV = (size_t)c->B * nvals_of(c) * c->M;
+    if ((st = upload_real(c, c->s_X, X, nX))) return st;
+    if ((st = upload_real(c, c->s_U, U, nU))) return st;
+    if ((st = ensure(c, c->s_RES, nR * rb))) return st;
+    if ((st = ensure(c, c->s_VALS, nV * rb))) return st;
+    if ((st = ensure(c, c->s_COST, (size_t)c->B * rb))) return st;
+    if (!(flags & EMI_EVAL_NODES)) {
+        // accumulate-only form: the caller's RES is the starting value
+        if (!RES) return fail(c, EMI_ERR_ARG, "emi_eval_host: defect-only needs RES in/out");
+        if ((st = upload_real(c, c->s_RES, RES, nR))) return st;
+    }
+    if ((st = emi_eval_dev(c, c->s_X.p, c->s_U.p, c->s_RES.p, c->s_VALS.p, c->s_COST.p, flags))) return st;
+    if ((st = download_real(c, RES, c->s_RES.p, nR))) return st;
+    if (!(flags & EMI_EVAL_NOJAC) && (flags & EMI_EVAL_NODES))
+        if ((st = download_real(c, VALS, c->s_VALS.p, nV))) return st;
+    if (flags & EMI_EVAL_NODES)
+        if ((st = download_real(c, COST, c->s_COST.p, c->B))) return st;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EMI_OK;
+}
+
+int emi_hess_dev(emi_ctx_t c, const void* dX, const void* dU, const void* dLamF, const void* dLamC,
+                 double sigma, void* dH) {
+    int st = ready(c);
+    if (st) return st;
+    if (c->model == EMI_MODEL_FIXEDWING12)
+        return fail(c, EMI_ERR_UNSUPPORTED, "no second-derivative kernel for the fixed-wing model yet");
+    if (!dX || !dU || !dLamF || !dH || (c->np > 0 && !dLamC))
+        return fail(c, EMI_ERR_ARG, "emi_hess: null device pointer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    auto fill = [&](auto& a) {
+        using T = typename std::remove_reference<decltype(a.h)>::type;
+        a.X = (const T*)dX; a.U = (const T*)dU; a.lamF = (const T*)dLamF; a.lamC = (const T*)dLamC;
+        a.H = (T*)dH; a.w = (const T*)c->d_w.p; a.node_t = (const T*)c->d_t.p;
+        a.path = (const T*)c->d_path.p;
+        a.M = c->M; a.B = c->B; a.np = c->np; a.path_sets = c->path_sets; a.px = c->px; a.py = c->py;
+        a.h = (T)((c->tf - c->t0) / 2.0); a.sgn = c->maximize ? T(-1) : T(1); a.sigma = (T)sigma;
+        for (int i = 0; i < EMI_MAX_PARAMS; ++i) a.P.p[i] = (T)c->params[i];
+    };
+    if (c->f32) {
+        emi::HessArgs<float> a;
+        fill(a);
+        HIP_TRY(c, emi::launch_hess<float>(c->model, a, c->stream));
+    } else {
+        emi::HessArgs<double> a;
+        fill(a);
+        HIP_TRY(c, emi::launch_hess<double>(c->model, a, c->stream));
+    }
+    return EMI_OK;
+}
+
+int emi_hess_host(emi_ctx_t c, const double* X, const double* U, const double* LamF,
+                  const double* LamC, double sigma, double* H) {
+    int st = ready(c);
+    if (st) return st;
+    if (!X || !U || !LamF || !H || (c->np > 0 && !LamC)) return fail(c, EMI_ERR_ARG, "emi_hess_host: null pointer");
+    const size_t rb = c->f32 ? 4 : 8;
+    const size_t nX = (size_t)c->B * c->ns * c->M, nU = (size_t)c->B * c->nc * c->M;
+    const size_t nC = (size_t)c->B * c->np * c->M, nH = (size_t)c->B * nhess_of(c) * c->M;
+    if ((st = upload_real(c, c->s_X, X, nX))) return st;
+    if ((st = upload_real(c, c->s_U, U, nU))) return st;
+    if ((st = upload_real(c, c->s_LF, LamF, nX))) return st;
+    if (nC && (st = upload_real(c, c->s_LC, LamC, nC))) return st;
+    if ((st = ensure(c, c->s_H, nH * rb))) return st;
+    if ((st = emi_hess_dev(c, c->s_X.p, c->s_U.p, c->s_LF.p, c->s_LC.p, sigma, c->s_H.p))) return st;
+    return download_real(c, H, c->s_H.p, nH);
+}
+
+int emi_timer_start(emi_ctx_t c) {
+    if (!c) return EMI_ERR_ARG;
+    HIP_TRY(c, hipEventRecord(c->t_start, c->stream));
+    return EMI_OK;
+}
+
+int emi_timer_stop(emi_ctx_t c, float* ms) {
+    if (!c || !ms) return EMI_ERR_ARG;
+    HIP_TRY(c, hipEventRecord(c->t_stop, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->t_stop));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->t_start, c->t_stop));
+    return EMI_OK;
+}
+
+int emi_profile_enable(emi_ctx_t c, int on) {
+    if (!c) return EMI_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->profile = on != 0;
+    c->prof_used = 0;
+    return EMI_OK;
+}
+
+int emi_profile_read(emi_ctx_t c, float* node_ms, int* node_launches, float* defect_ms,
+                     int* defect_launches) {
+    if (!c) return EMI_ERR_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float nm = 0, dm = 0;
+    int nl = 0, dl = 0;
+    for (size_t i = 0; i < c->prof_used; ++i) {
+        ProfEvents& pe = c->prof[i];
+        float ms = 0;
+        if (pe.has_node) {
+            HIP_TRY(c, hipEventElapsedTime(&ms, pe.e[0], pe.e[1]));
+            nm += ms;
+            ++nl;
+        }
+        if (pe.has_defect) {
+            HIP_TRY(c, hipEventElapsedTime(&ms, pe.e[1], pe.e[2]));
+            dm += ms;
+            ++dl;
+        }
+    }
+    c->prof_used = 0;
+    if (node_ms) *node_ms = nm;
+    if (node_launches) *node_launches = nl;
+    if (defect_ms) *defect_ms = dm;
+    if (defect_launches) *defect_launches = dl;
+    return EMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// emi_kernels.hpp -- argument blocks and launcher prototypes shared by the
+// kernels (emi_kernels.hip) and the C-ABI implementation (emi_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+#include "emi355x.h"
+
+#define EMI_NODE_THREADS 256
+
+// defect GEMM tile (fp64 MFMA path)
+#define DEF_TM 96
+#define DEF_TN 128
+#define DEF_BK 16
+
+#include "emi_models.hpp"
+
+namespace emi {
+
+template <typename T> struct NodeArgs {
+    const T* X;         // [B][ns][M]
+    const T* U;         // [B][nc][M]
+    T* RES;             // [B][nres][M]
+    T* VALS;            // [B][nvals][M]
+    T* cost_part;       // [B][nchunks]
+    T* cost;            // [B]
+    const T* w;         // [M]  LGL weights
+    const T* node_t;    // [M]  node times t0 + h (tau+1)
+    const T* Ddiag;     // [M]  D_kk
+    const T* path;      // [path_sets][np][EMI_PATH_REC]
+    const T* track_x;   // [track_sets][ntracks][M]
+    const T* track_y;
+    int M, B, np, nres, nvals;
+    int path_sets, track_sets, ntracks;
+    int px, py;
+    T h, sgn;
+    ModelParams<T> P;
+};
+
+template <typename T> struct HessArgs {
+    const T* X;
+    const T* U;
+    const T* lamF;      // [B][ns][M]
+    const T* lamC;      // [B][np][M]
+    T* H;               // [B][nhess][M]
+    const T* w;
+    const T* node_t;
+    const T* path;
+    int M, B, np, path_sets, px, py;
+    T h, sgn, sigma;
+    ModelParams<T> P;
+};
+
+struct DefectArgs {
+    const double* X;    // [R][M], R = B*ns
+    const double* D;    // [M][M] row-major
+    double* RES;        // [B][nres][M]; defect rows are accumulated into
+    int R, M, ns, nres;
+};
+struct DefectArgsF32 {
+    const float* X;
+    const float* D;
+    float* RES;
+    int R, M, ns, nres;
+};
+
+int node_chunks(int M);
+template <typename T> hipError_t launch_nodes(int model, const NodeArgs<T>& a, bool jac, hipStream_t s);
+template <typename T> hipError_t launch_hess(int model, const HessArgs<T>& a, hipStream_t s);
+hipError_t launch_defect_f64(const DefectArgs& a, hipStream_t s);
+hipError_t launch_defect_f32(const DefectArgsF32& a, hipStream_t s);
+hipError_t defect_f64_set_attr();
+
+}  // namespace emi

@@ -1,0 +1,191 @@
+/*
+ * emi355x.h -- C ABI of libemi355x, the MI355X (gfx950) collocation evaluator.
+ *
+ * This is the drop-in boundary of the eMI355X eSolver.  It is the only thing
+ * `src/eMI355X/eMI355X.cpp` (our ETOL::TrajectoryOptimizer peer of ePSOPT)
+ * calls to reach the GPU.  Plain pointers and sizes only: no C++ types, no
+ * torch types, no exceptions cross this boundary; every call returns an int
+ * status (EMI_OK == 0) and the text of the last failure is kept per context.
+ *
+ * What each entry point replaces in the reference (paths under the ETOL tree;
+ * "[PSOPT]" marks arithmetic that the reference delegates to PSOPT 5.0.0,
+ * whose sources are not part of the reference tree):
+ *
+ *   emi_lgl            [PSOPT] LGL nodes / weights / differentiation matrix
+ *                      selected by  src/ePSOPT/ePSOPT.cpp:68
+ *                      (collocation_method = "Legendre"), node count :44-45
+ *   emi_set_mesh       the (t0,tf) fixed-horizon mapping, ePSOPT.cpp:151-154
+ *   emi_set_model      the per-node callbacks installed at ePSOPT.cpp:76-80
+ *                      (integrand_cost :186-216, dae :218-276) -- the user's
+ *                      f_t closures cannot run on the device, so a model id
+ *                      + parameter block selects a hand-written kernel
+ *   emi_set_path       the path rows counted at ePSOPT.cpp:58 and produced
+ *                      at :261-270; row formulas follow
+ *                      src/Examples/PSOPT/etol_psopt_example1.cpp:163-182
+ *                      (ellipse per polygon edge) and :243-247 (disc)
+ *   emi_set_tracks     moving-disc centres, etol_psopt_example1.cpp:233-241
+ *   emi_eval_*         one pass of the hot loop of ::psopt (ePSOPT.cpp:84):
+ *                      dae + integrand_cost at every node, the defect
+ *                      D.X - (tf-t0)/2.F, the cost quadrature, and what
+ *                      ADOL-C's sparse_jac/gradient drivers return [PSOPT]
+ *   emi_hess_*         what ADOL-C's sparse_hess returns for hessian="exact"
+ *                      (ePSOPT.cpp:65) [PSOPT]
+ *   emi_jac_structure  the sparsity pattern IPOPT is given [PSOPT]
+ *
+ * Threading: a context must be driven by one caller thread at a time
+ * (the reference is single-threaded throughout).
+ *
+ * Data layout (all arrays dense, real type = double unless the context was
+ * created with emi_create_f32):
+ *   X     [B][ns][M]   state trajectories, node index fastest
+ *   U     [B][nc][M]   control trajectories
+ *   RES   [B][ns+np][M]  rows 0..ns-1  : defect  (D.X)_i,k - h f_i(x_k,u_k,t_k)
+ *                        rows ns..     : path constraint values c_j(x_k,t_k)
+ *   VALS  [B][nvals][M], nvals = ns*(ns+nc) + 2*np + (ns+nc):
+ *           entry i*(ns+nc)+v        : d defect_(i,k) / d z_(v,k)
+ *                                      = -h df_i/dz_v + (v==i ? D_kk : 0)
+ *           entry ns*(ns+nc)+2j+{0,1}: d c_j / d (px, py) at node k
+ *           entry ns*(ns+nc)+2np+v   : d cost / d z_(v,k) = sgn h w_k dL/dz_v
+ *   COST  [B]          sgn h sum_k w_k L(x_k,u_k)   (sgn=-1 when maximising,
+ *                      ePSOPT.cpp:212-213)
+ *   h = (tf - t0)/2,  z_(v,k): v<ns -> state v, else control v-ns.
+ */
+#ifndef EMI355X_H_
+#define EMI355X_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMI_ABI_VERSION 1
+
+typedef struct emi_ctx_s* emi_ctx_t;
+
+/* status codes */
+enum {
+    EMI_OK = 0,
+    EMI_ERR_ARG = 1,          /* bad argument (null pointer, size mismatch) */
+    EMI_ERR_STATE = 2,        /* call made before its prerequisites */
+    EMI_ERR_HIP = 3,          /* a HIP runtime call failed */
+    EMI_ERR_NO_DEVICE = 4,    /* no usable gfx950 device */
+    EMI_ERR_UNSUPPORTED = 5,  /* valid request this build has no kernel for */
+    EMI_ERR_COMM = 6          /* RCCL failure */
+};
+
+/* built-in node models (emi_set_model) */
+enum {
+    EMI_MODEL_POINTMASS2D = 0,  /* ns=2 nc=2: etol_psopt_example1.cpp:101-138 */
+    EMI_MODEL_QUADROTOR2D = 1,  /* ns=6 nc=2: planar quadrotor (build-defined) */
+    EMI_MODEL_FIXEDWING12 = 2   /* ns=12 nc=4: rigid-body fixed wing (build-defined) */
+};
+
+/* path-row kinds; one record = EMI_PATH_REC reals: {kind, c0..c6} */
+enum {
+    EMI_PATH_ELLIPSE = 0, /* c = {xc, yc, cos tt, sin tt, a^2, b^2, -}      */
+    EMI_PATH_DISC = 1,    /* c = {xc, yc, r^2, -, -, -, -}                  */
+    EMI_PATH_TRACK = 2    /* c = {track index, r^2, -, ...}: centre per node */
+};
+#define EMI_PATH_REC 8
+
+/* emi_eval flags */
+enum {
+    EMI_EVAL_NODES = 1u,   /* K1+K2+K3+K5: node functions, Jacobian values   */
+    EMI_EVAL_DEFECT = 2u,  /* K4: accumulate D.X into the defect rows        */
+    EMI_EVAL_ALL = 3u,
+    EMI_EVAL_NOJAC = 4u    /* values only (line-search evaluations)          */
+};
+
+typedef struct {
+    int model, ns, nc, np, M, B;
+    int nres;    /* ns + np                        */
+    int nvals;   /* ns*(ns+nc) + 2*np + (ns+nc)    */
+    int nhess;   /* (ns+nc)*(ns+nc+1)/2            */
+    int real_bytes; /* 8 (f64) or 4 (f32)          */
+    int px, py;  /* state indices the keep-outs act on */
+    double t0, tf;
+} emi_layout_t;
+
+/* ---- library ---------------------------------------------------------- */
+int emi_abi_version(void);
+const char* emi_status_string(int status);
+int emi_device_count(int* count);
+
+/* ---- host-side mesh construction (no device needed) -------------------- */
+/* LGL nodes tau[M] (ascending, -1..1), weights w[M], D[M*M] row-major.     */
+int emi_lgl(int M, double* tau, double* w, double* D);
+int emi_model_dims(int model, int* ns, int* nc, int* nparams);
+/* ellipse record from one polygon edge (a->b); follows the arithmetic of
+ * etol_psopt_example1.cpp:163-182 term by term.                            */
+int emi_edge_ellipse(double xa, double ya, double xb, double yb, double* rec8);
+/* linear interpolation of a waypoint table at the node times; follows
+ * TrajectoryOptimizer.hpp:239-258 (bracket search) term by term.           */
+int emi_track_centres(int nway, const double* t, const double* x, const double* y,
+                      int M, const double* node_t, double* xc, double* yc);
+
+/* ---- context ------------------------------------------------------------ */
+int emi_create(int device_id, emi_ctx_t* out);       /* f64 arithmetic */
+int emi_create_f32(int device_id, emi_ctx_t* out);   /* f32 arithmetic */
+int emi_destroy(emi_ctx_t ctx);
+const char* emi_last_error(emi_ctx_t ctx);
+int emi_set_stream(emi_ctx_t ctx, void* hip_stream); /* NULL = own stream */
+int emi_get_stream(emi_ctx_t ctx, void** hip_stream);
+int emi_synchronize(emi_ctx_t ctx);
+
+/* ---- problem definition ------------------------------------------------- */
+int emi_set_mesh(emi_ctx_t ctx, int M, const double* tau, const double* w,
+                 const double* D, double t0, double tf);
+int emi_set_model(emi_ctx_t ctx, int model, const double* params, int nparams,
+                  int maximize);
+int emi_set_batch(emi_ctx_t ctx, int B);
+/* recs: [nsets][np][EMI_PATH_REC]; nsets is 1 (shared) or B (per instance) */
+int emi_set_path(emi_ctx_t ctx, int np, int nsets, const double* recs,
+                 int px_state, int py_state);
+/* xc, yc: [nsets][ntracks][M] disc centres at the node times               */
+int emi_set_tracks(emi_ctx_t ctx, int ntracks, int nsets, const double* xc,
+                   const double* yc);
+int emi_get_layout(emi_ctx_t ctx, emi_layout_t* out);
+
+/* COO pattern of VALS in per-instance NLP numbering:
+ * rows/cols have nvals*M entries ordered like VALS; cost-gradient entries
+ * carry row = -1.                                                          */
+int emi_jac_structure(emi_ctx_t ctx, int* rows, int* cols);
+
+/* ---- device memory helpers (for callers without their own allocator) ---- */
+int emi_dev_alloc(emi_ctx_t ctx, size_t bytes, void** dptr);
+int emi_dev_free(emi_ctx_t ctx, void* dptr);
+int emi_h2d(emi_ctx_t ctx, void* dst, const void* src, size_t bytes);
+int emi_d2h(emi_ctx_t ctx, void* dst, const void* src, size_t bytes);
+
+/* ---- the hot path -------------------------------------------------------- */
+/* Device-pointer form: every pointer is device memory of the layout above,
+ * in the context's real type.  Asynchronous on the context's stream.        */
+int emi_eval_dev(emi_ctx_t ctx, const void* dX, const void* dU, void* dRES,
+                 void* dVALS, void* dCOST, unsigned flags);
+/* Host-buffer form (double in/out whatever the arithmetic type): copies in,
+ * evaluates, copies out, synchronises.  Output pointers may be NULL.        */
+int emi_eval_host(emi_ctx_t ctx, const double* X, const double* U, double* RES,
+                  double* VALS, double* COST, unsigned flags);
+
+/* Lagrangian Hessian node blocks: H[B][nhess][M], lower triangle row-major
+ * of  sigma*sgn*h*w_k*L_zz - h*sum_i lamF_i,k f_i,zz + sum_j lamC_j,k c_j,zz */
+int emi_hess_dev(emi_ctx_t ctx, const void* dX, const void* dU,
+                 const void* dLamF, const void* dLamC, double sigma, void* dH);
+int emi_hess_host(emi_ctx_t ctx, const double* X, const double* U,
+                  const double* LamF, const double* LamC, double sigma,
+                  double* H);
+
+/* ---- measurement --------------------------------------------------------- */
+/* HIP-event timers on the context's stream.                                 */
+int emi_timer_start(emi_ctx_t ctx);
+int emi_timer_stop(emi_ctx_t ctx, float* elapsed_ms); /* synchronises */
+/* Per-kernel event brackets inside emi_eval_dev (adds two events/launch).   */
+int emi_profile_enable(emi_ctx_t ctx, int on);
+int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
+                     float* defect_ms, int* defect_launches); /* syncs+resets */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMI355X_H_ */

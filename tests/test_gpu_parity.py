@@ -1,0 +1,193 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.  -m gpu"""
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+# fp64 tolerances, relative to the row scale (written here on purpose):
+#   node functions / Jacobian values: a handful of roundings          -> 1e-13
+#   defect rows: an M-term dot product with |D| up to N(N+1)/4; the GPU sums in
+#   a different order than the oracle's long-double sum               -> 5e-13 of sum|D_kj||x_j|
+TOL_NODE = 1e-13
+TOL_DEFECT = 5e-13
+
+
+def run_case(name, maximize=False):
+    import etol_amd as E
+    c = cases.case_inputs(name)
+    ev = E.Evaluator(0)
+    ev.set_mesh(c["M"], c["t0"], c["tf"])
+    ev.set_model(c["model"], c["params"], maximize=maximize)
+    ev.set_batch(c["B"])
+    recs = c.get("recs")
+    tracks = None
+    if c.get("ocp2d"):
+        recs, tx, ty = cases.ocp2d_tables(E.edge_ellipse, E.track_centres, ev.node_t)
+        tracks = (tx, ty)
+        ev.set_tracks(tx, ty)
+    if recs is not None:
+        ev.set_path(recs, 0, 1)
+    mesh = (ev.tau, ev.w, ev.D)
+    got = ev.eval_host(c["X"], c["U"])
+    # the oracle gets its OWN tables for the shipped problem (independent restatement)
+    orecs, otracks = recs, tracks
+    if c.get("ocp2d"):
+        orecs, otx, oty = cases.ocp2d_tables(O.edge_ellipse, O.track_centres, ev.node_t)
+        otracks = (otx, oty)
+    ref = O.evaluate(c["model"], c["params"], c["M"], mesh, c["t0"], c["tf"], c["X"], c["U"], orecs, otracks,
+                     maximize=maximize)
+    return c, ev, got, ref
+
+
+def check(c, ev, got, ref):
+    ns = c["X"].shape[1]
+    RES, VALS, COST = got
+    rRES, rVALS, rCOST = ref
+    # defect rows against sum_j |D_kj||x_j| + h|f|
+    absdx = np.einsum("kj,bij->bik", np.abs(ev.D), np.abs(c["X"]))
+    scale = absdx + np.abs(rRES[:, :ns]) + 1.0
+    err = np.abs(RES[:, :ns] - rRES[:, :ns]) / scale
+    assert err.max() < TOL_DEFECT, f"defect rel err {err.max():.3e}"
+    if RES.shape[1] > ns:
+        s = np.abs(rRES[:, ns:]).max() + 1.0
+        assert np.abs(RES[:, ns:] - rRES[:, ns:]).max() / s < TOL_NODE
+    for e in range(VALS.shape[1]):
+        s = np.abs(rVALS[:, e]).max() + 1.0
+        d = np.abs(VALS[:, e] - rVALS[:, e]).max() / s
+        assert d < TOL_NODE, f"VALS entry {e}: rel err {d:.3e}"
+    assert np.abs(COST - rCOST).max() / (np.abs(rCOST).max() + 1.0) < 1e-13
+
+
+@pytest.mark.parametrize("name", cases.CASES)
+def test_eval_matches_oracle(built, name):
+    check(*run_case(name))
+
+
+def test_maximize_flips_cost_sign(built):
+    c, ev, got, ref = run_case("quad_256", maximize=True)
+    check(c, ev, got, ref)
+    assert (got[2] < 0).all()
+
+
+def test_epsopt_style_port_agrees(built):
+    """third opinion: the std::any / dual-number port of ePSOPT::dae"""
+    c, ev, got, _ = run_case("quad_1024_obs")
+    ref = O.evaluate(c["model"], c["params"], c["M"], (ev.tau, ev.w, ev.D), c["t0"], c["tf"], c["X"], c["U"],
+                     c["recs"], style="epsopt")
+    # the port sums D.X in plain double in yet another order: same tolerance class
+    check(c, ev, got, ref)
+
+
+def test_nojac_and_split_passes(built):
+    import etol_amd as E
+    c, ev, got, ref = run_case("quad_ragged")
+    # values-only pass leaves the same RES / COST
+    RES2, _, COST2 = ev.eval_host(c["X"], c["U"], flags=E.EVAL_ALL | E.EVAL_NOJAC)
+    assert np.array_equal(RES2, got[0]) and np.array_equal(COST2, got[2])
+    # node pass then defect-accumulate pass == fused call
+    RESn, VALSn, COSTn = ev.eval_host(c["X"], c["U"], flags=E.EVAL_NODES)
+    RESd, _, _ = ev.eval_host(c["X"], c["U"], flags=E.EVAL_DEFECT, res_in=RESn)
+    assert np.array_equal(RESd, got[0]) and np.array_equal(VALSn, got[1])
+
+
+def test_linearity_of_defect_operator(built):
+    """size-independent property at the full C3 size: K4 is linear in X."""
+    import etol_amd as E
+    M, B = 1024, 4
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 16.0)
+    ev.set_model(E.MODEL_QUADROTOR2D, [1, 0.01, 9.81, 1, 1])
+    ev.set_batch(B)
+    rng = np.random.default_rng(5)
+    Xa, Xb = rng.standard_normal((2, B, 6, M))
+    U = np.zeros((B, 2, M))
+    z = np.zeros((B, 6, M))
+    Ra, _, _ = ev.eval_host(Xa, U, flags=E.EVAL_DEFECT, res_in=z)
+    Rb, _, _ = ev.eval_host(Xb, U, flags=E.EVAL_DEFECT, res_in=z)
+    Rab, _, _ = ev.eval_host(2.0 * Xa - 3.0 * Xb, U, flags=E.EVAL_DEFECT, res_in=z)
+    scale = np.einsum("kj,bij->bik", np.abs(ev.D), 2 * np.abs(Xa) + 3 * np.abs(Xb))
+    assert (np.abs(Rab - (2.0 * Ra - 3.0 * Rb)) / scale).max() < 1e-14
+    # D annihilates constants and differentiates tau exactly
+    ones = np.ones((B, 6, M))
+    R1, _, _ = ev.eval_host(ones, U, flags=E.EVAL_DEFECT, res_in=z)
+    assert np.abs(R1).max() < 1e-9
+    Rt, _, _ = ev.eval_host(ones * ev.tau, U, flags=E.EVAL_DEFECT, res_in=z)
+    assert np.abs(Rt - 1.0).max() < 1e-9
+
+
+def test_hessian_blocks(built):
+    for name in ("pointmass_xml", "quad_ragged"):
+        c, ev, _, _ = run_case(name)
+        lay = ev.layout
+        rng = np.random.default_rng(11)
+        lamF = rng.standard_normal((c["B"], lay.ns, c["M"]))
+        lamC = rng.standard_normal((c["B"], lay.np, c["M"]))
+        H = ev.hess_host(c["X"], c["U"], lamF, lamC, sigma=0.7)
+        recs, tracks = c.get("recs"), None
+        if c.get("ocp2d"):
+            recs, tx, ty = cases.ocp2d_tables(O.edge_ellipse, O.track_centres, ev.node_t)
+            tracks = (tx, ty)
+        Href = O.hessian(c["model"], c["params"], c["M"], (ev.tau, ev.w, ev.D), c["t0"], c["tf"], c["X"], c["U"],
+                         lamF, lamC, 0.7, recs, tracks)
+        # oracle Hessian = central difference of complex-step gradients: ~1e-9 relative
+        assert np.abs(H - Href).max() / (np.abs(Href).max() + 1.0) < 1e-7
+
+
+def test_jac_structure_matches_dense_jacobian(built):
+    """Assemble the full NLP Jacobian from VALS + structure + (I (x) D) and compare with
+    a finite-difference Jacobian of the oracle's constraint vector (small case)."""
+    import etol_amd as E
+    M, B = 7, 1
+    P = [1, 0.01, 9.81, 1, 1]
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 3.0)
+    ev.set_model(E.MODEL_QUADROTOR2D, P)
+    ev.set_batch(B)
+    recs = np.zeros((2, 8))
+    recs[:, 0] = E.PATH_DISC
+    recs[:, 1:4] = [[1, 2, 0.3], [4, 1, 0.2]]
+    ev.set_path(recs, 0, 1)
+    rng = np.random.default_rng(3)
+    X = rng.uniform(0, 5, (B, 6, M))
+    U = rng.uniform(0, 5, (B, 2, M))
+    RES, VALS, COST = ev.eval_host(X, U)
+    rows, cols = ev.jac_structure()
+    ns, nv, np_ = 6, 8, 2
+    n, m = nv * M, ns * M + 2 * ns + np_ * M
+    J = np.zeros((m, n))
+    g = np.zeros(n)
+    v = VALS[0].reshape(-1)
+    for e in range(len(v)):
+        if rows[e] < 0:
+            g[cols[e]] += v[e]
+        else:
+            J[rows[e], cols[e]] += v[e]
+    for i in range(ns):  # off-diagonal part of I (x) D (the diagonal is already in VALS)
+        J[i * M:(i + 1) * M, i * M:(i + 1) * M] += ev.D - np.diag(np.diag(ev.D))
+    for i in range(ns):  # events (ePSOPT.cpp:281-291): x(t0), x(tf)
+        J[ns * M + i, i * M] = 1.0
+        J[ns * M + ns + i, i * M + M - 1] = 1.0
+
+    def gfun(zv):
+        Xz = zv[:ns * M].reshape(1, ns, M)
+        Uz = zv[ns * M:].reshape(1, 2, M)
+        R, _, C = O.evaluate(1, P, M, (ev.tau, ev.w, ev.D), 0.0, 3.0, Xz, Uz, recs)
+        ev_ = np.concatenate([Xz[0, :, 0], Xz[0, :, -1]])
+        return np.concatenate([R[0, :ns].reshape(-1), ev_, R[0, ns:].reshape(-1)]), C[0]
+
+    z0 = np.concatenate([X.reshape(-1), U.reshape(-1)])
+    Jfd = np.zeros_like(J)
+    gfd = np.zeros(n)
+    for q in range(n):
+        d = 1e-6
+        zp, zm = z0.copy(), z0.copy()
+        zp[q] += d
+        zm[q] -= d
+        (gp, cp), (gm, cm) = gfun(zp), gfun(zm)
+        Jfd[:, q] = (gp - gm) / (2 * d)
+        gfd[q] = (cp - cm) / (2 * d)
+    assert np.abs(J - Jfd).max() < 1e-6 * (np.abs(Jfd).max() + 1)
+    assert np.abs(g - gfd).max() < 1e-6 * (np.abs(gfd).max() + 1)
