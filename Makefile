@@ -53,8 +53,8 @@ $(LIBDIR)/libetol_mi355x.so: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libemi355x.so
 $(LIBDIR)/etol_mi355x_example1: etol_amd/examples/etol_mi355x_example1.cpp $(LIBDIR)/libetol_mi355x.so
 	$(CXX) $(CXXFLAGS) -I$(HOST) -o $@ $< -L$(LIBDIR) -letol_mi355x -lemi355x -Wl,-rpath,'$$ORIGIN'
 
-tests/harness/libetol_harness.so: tests/harness/etol_harness.cpp $(LIBDIR)/libetol_mi355x.so
-	$(CXX) $(CXXFLAGS) -I$(HOST) -shared -o $@ $< -L$(LIBDIR) -letol_mi355x -lemi355x \
+tests/harness/libetol_harness.so: tests/harness/etol_harness.cpp $(LIBDIR)/libetol_mi355x.so $(HOST_HDR)
+	$(CXX) $(CXXFLAGS) -I$(HOST) -shared -o $@ $< -L$(LIBDIR) -letol_mi355x -lemi355x -ldl \
 		-Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)'
 
 oracle:

@@ -26,6 +26,18 @@ HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8.
 FP64_MFMA_PEAK_TF = 78.6                               # MI355X fp64 matrix
 
 
+def usable_cores():
+    """CPU threads this process may really use (affinity mask and cgroup quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(M, n_obs, budget_s=10.0):
     """ePSOPT-style CPU port (oracle/epsopt_style.cpp) on a bounded sample of the same workload,
     all host cores via OpenMP over instances.  Checker/baseline only, never the product path."""
@@ -34,7 +46,7 @@ def cpu_baseline(M, n_obs, budget_s=10.0):
     import oracle_lib as O
     from etol_amd import workloads as W
     from etol_amd import lgl
-    cores = O.eps().eps_max_threads()
+    cores = min(O.eps().eps_max_threads(), usable_cores())
     Bs = max(cores, 8)
     X, U, recs = W.quadrotor_batch(2, Bs, M, n_obs)
     mesh = lgl(M)

@@ -1,0 +1,116 @@
+// etol_mi355x_example1.cpp -- loads an ETOL configuration XML and solves it with eMI355X.
+//
+// The eMI355X twin of the reference's src/Examples/PSOPT/etol_psopt_example1.cpp
+// (same OCP, same call sequence, same outputs):
+//    minimize    integral (u0^2 + u1^2) dt
+//    subject to  dx/dt = u0,  dy/dt = u1
+//                (x,y) outside every exclusion zone (one ellipse per polygon edge)
+//                (x,y) outside every moving exclusion disc
+// Callbacks use the eMI355X datatypes (include/ETOL/eMI355X_Types.hpp): they are
+// called once at setup() and describe the problem to the device evaluator.
+#include <ETOL/eMI355X.hpp>
+
+#include <iostream>
+
+namespace mx = ETOL::mi355x;
+
+void editAlgo(ETOL::TrajectoryOptimizer* t);
+ETOL::scalar_t objFunction(F_ARGS);
+ETOL::scalar_t dxdt(F_ARGS);
+ETOL::scalar_t dydt(F_ARGS);
+ETOL::f_t obsConstraint(ETOL::TrajectoryOptimizer* t);
+ETOL::f_t saaConstraint(ETOL::TrajectoryOptimizer* t);
+std::string paramName(const std::string& name, size_t i, size_t j, size_t k);
+
+int main(int argc, char** argv) {
+    if (argc != 2) {
+        printf("Usage: %s <ETOL configuration xml filepath>\n", argv[0]);
+        exit(EXIT_FAILURE);
+    }
+    ETOL::eMI355X solver;
+    ETOL::TrajectoryOptimizer* t = &solver;
+
+    t->loadConfigs(argv[1]);
+    t->printConfigs();
+
+    t->setMaximize(false);
+    ETOL::f_t obj = &objFunction;
+    t->setObjective(&obj);
+    ETOL::f_t xdot = &dxdt, ydot = &dydt;
+    t->setGradient({&xdot, &ydot});
+
+    ETOL::f_t obs = obsConstraint(t);
+    ETOL::f_t saa = saaConstraint(t);
+    t->setConstraints({&obs, &saa});
+
+    t->setup();
+    editAlgo(t);
+    t->debug();
+    t->solve();
+
+    printf("\n!!!!!!!!!!!!!!!!!Results!!!!!!!!!!!!!!!!!\n");
+    printf("Minimization Score:\t%f\n", t->getScore());
+    printf("State variables saved in %s\n",
+           ETOL::TrajectoryOptimizer::save(t->getXtraj(), "state_mi355x1.csv").c_str());
+    printf("Control variables saved in %s\n",
+           ETOL::TrajectoryOptimizer::save(t->getUtraj(), "control_mi355x1.csv").c_str());
+    t->close();
+    printf("\n!!!!!!!!!!!!!!Graceful Exit!!!!!!!!!!!!!!\n");
+    return EXIT_SUCCESS;
+}
+
+// per-solver knobs through the solver's own handle, like the ePSOPT example
+void editAlgo(ETOL::TrajectoryOptimizer* t) {
+    ETOL::eMI355X* ptr = dynamic_cast<ETOL::eMI355X*>(t);
+    if (!ptr) {
+        std::cout << "EditAlgo only works for eMI355X!" << std::endl;
+        exit(EXIT_FAILURE);
+    }
+    mx::Alg* algo = ptr->getAlgorithm();
+    algo->nlp_tolerance = 1.e-8;
+    algo->max_cpu_time = 100;
+}
+
+ETOL::scalar_t objFunction(F_ARGS) { return mx::objective(EMI_MODEL_POINTMASS2D); }
+ETOL::scalar_t dxdt(F_ARGS) { return mx::derivative(EMI_MODEL_POINTMASS2D, 0); }
+ETOL::scalar_t dydt(F_ARGS) { return mx::derivative(EMI_MODEL_POINTMASS2D, 1); }
+
+ETOL::f_t obsConstraint(ETOL::TrajectoryOptimizer* t) {
+    const double tspan = t->getDt() * t->getNSteps();
+    const std::vector<ETOL::border_t>* zones = t->getObstacles_Raw();
+    size_t i = 0;
+    for (const ETOL::border_t& zone : *zones) {
+        for (size_t j = 0; j < zone.size(); ++j)
+            t->addParams({std::pair<PARAM_PAIR>(paramName("side", i, j, 0),
+                                                {ETOL::var_t::CONTINUOUS, -1000., 0., 0., tspan})});
+        ++i;
+    }
+    return [zones](F_ARGS) -> ETOL::scalar_t {
+        try {
+            return mx::ellipse_rows(*zones, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+        } catch (std::bad_any_cast& e) {
+            std::cout << "Error in obs" << std::endl << e.what() << std::endl;
+            exit(EXIT_FAILURE);
+        }
+    };
+}
+
+ETOL::f_t saaConstraint(ETOL::TrajectoryOptimizer* t) {
+    const double tspan = t->getDt() * t->getNSteps();
+    const std::list<ETOL::track_t>* tracks = t->getTracks();
+    for (size_t i = 0; i < tracks->size(); ++i)
+        t->addParams({std::pair<PARAM_PAIR>(paramName("ball", i, 0, 0),
+                                            {ETOL::var_t::CONTINUOUS, -1000., 0., 0., tspan})});
+    return [tracks](F_ARGS) -> ETOL::scalar_t {
+        try {
+            return mx::track_rows(*tracks, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+        } catch (std::bad_any_cast& e) {
+            std::cout << "Error in saa" << std::endl << e.what() << std::endl;
+            exit(EXIT_FAILURE);
+        }
+    };
+}
+
+std::string paramName(const std::string& name, size_t i, size_t j, size_t k) {
+    return name + "_" + std::to_string(i) + "_" + std::to_string(j) + "_" + std::to_string(k);
+}

@@ -1,0 +1,414 @@
+// eMI355X.cpp -- the MI355X eSolver: ETOL configuration -> LGL transcription on the GPU.
+//
+// Mirrors, member for member, what ePSOPT does on the CPU (reference
+// src/ePSOPT/ePSOPT.cpp): setup() :40-81 (problem mapping, algorithm defaults),
+// addBounds() :125-155, solve() :83-94, getTraj() :157-182, debug() :100-102,
+// close() :107.  The per-node callbacks dae/integrand_cost/events (:186-291) have
+// no host counterpart here: they are the kernels behind include/emi355x.h.
+#include <ETOL/eMI355X.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+
+#include "emi_nlp.hpp"
+#include "emi_transcribe.hpp"
+
+namespace ETOL {
+
+// ---------------------------------------------------------------------------------------------
+// keep-out row builders (eMI355X_Types.hpp)
+// ---------------------------------------------------------------------------------------------
+namespace mi355x {
+
+namespace {
+void check_xy(const Symbol& sx, const Symbol& sy, const char* who) {
+    if (sx.kind != Symbol::STATE || sy.kind != Symbol::STATE || sx.index == sy.index) {
+        fprintf(stderr, "%s: keep-out rows must act on two different states\n", who);
+        exit(EXIT_FAILURE);
+    }
+}
+}  // namespace
+
+PathBlock ellipse_rows(const std::vector<border_t>& zones, const Symbol& sx, const Symbol& sy) {
+    check_xy(sx, sy, "ellipse_rows");
+    PathBlock out;
+    out.px = sx.index;
+    out.py = sy.index;
+    for (const border_t& poly : zones) {
+        for (auto a = poly.begin(); a != poly.end(); ++a) {
+            auto b = std::next(a);
+            if (b == poly.end()) b = poly.begin();
+            std::array<double, EMI_PATH_REC> rec{};
+            emi_edge_ellipse((*a)[0], (*a)[1], (*b)[0], (*b)[1], rec.data());
+            out.rows.push_back(rec);
+        }
+    }
+    return out;
+}
+
+PathBlock disc_rows(const std::vector<std::array<double, 3>>& discs, const Symbol& sx, const Symbol& sy) {
+    check_xy(sx, sy, "disc_rows");
+    PathBlock out;
+    out.px = sx.index;
+    out.py = sy.index;
+    for (const auto& d : discs) {
+        std::array<double, EMI_PATH_REC> rec{};
+        rec[0] = (double)EMI_PATH_DISC;
+        rec[1] = d[0];
+        rec[2] = d[1];
+        rec[3] = d[2] * d[2];
+        out.rows.push_back(rec);
+    }
+    return out;
+}
+
+PathBlock track_rows(const std::list<track_t>& tracks, const Symbol& sx, const Symbol& sy) {
+    check_xy(sx, sy, "track_rows");
+    PathBlock out;
+    out.px = sx.index;
+    out.py = sy.index;
+    for (const track_t& trk : tracks) {
+        TrackTable tb;
+        tb.radius = trk.radius;
+        for (const traj_elem_t& wp : trk.trajectory) {
+            tb.t.push_back(wp.first);
+            tb.x.push_back(wp.second.at(0));
+            tb.y.push_back(wp.second.at(1));
+        }
+        out.tracks.push_back(tb);
+    }
+    return out;
+}
+
+}  // namespace mi355x
+
+// ---------------------------------------------------------------------------------------------
+// device adapter: the only place that touches the C ABI
+// ---------------------------------------------------------------------------------------------
+struct eMI355X::Device : public mi355x::NlpEvaluator {
+    emi_ctx_t ctx = nullptr;
+    ~Device() override {
+        if (ctx) emi_destroy(ctx);
+    }
+    int eval(const double* X, const double* U, double* RES, double* VALS, double* COST, bool jac) override {
+        return emi_eval_host(ctx, X, U, RES, VALS, COST, EMI_EVAL_ALL | (jac ? 0u : (unsigned)EMI_EVAL_NOJAC));
+    }
+    int hess(const double* X, const double* U, const double* lamF, const double* lamC, double sigma,
+             double* H) override {
+        return emi_hess_host(ctx, X, U, lamF, lamC, sigma, H);
+    }
+    std::string last_error() const override { return ctx ? emi_last_error(ctx) : "no device context"; }
+};
+
+namespace {
+[[noreturn]] void die(const std::string& msg) {
+    fprintf(stderr, "eMI355X: %s\n", msg.c_str());
+    exit(EXIT_FAILURE);
+}
+void must(int status, emi_ctx_t ctx, const char* what) {
+    if (status == EMI_OK) return;
+    die(std::string(what) + ": " + emi_status_string(status) + (ctx ? std::string(" - ") + emi_last_error(ctx) : ""));
+}
+}  // namespace
+
+eMI355X::eMI355X() : TrajectoryOptimizer() {}
+eMI355X::~eMI355X() {}
+
+mi355x::Alg* eMI355X::getAlgorithm() { return &_algorithm; }
+mi355x::Sol* eMI355X::getSolution() { return &_solution; }
+mi355x::Prob* eMI355X::getProblem() { return &_problem; }
+
+// One call per callback, with Symbols in the anys; collects the model and the path table.
+void eMI355X::traceCallbacks() {
+    mi355x::Prob& P = _problem;
+    vector_t x, u;
+    for (size_t i = 0; i < getNStates(); ++i) x.push_back(mi355x::Symbol{mi355x::Symbol::STATE, i});
+    for (size_t j = 0; j < getNControls(); ++j) u.push_back(mi355x::Symbol{mi355x::Symbol::CONTROL, j});
+    const std::any tsym = mi355x::Symbol{mi355x::Symbol::TIME, 0};
+    if (_objective == NULL) die("no objective function set");
+    if (_gradient.size() != getNStates()) die("setGradient needs one function per state");
+    try {
+        {
+            vector_t params = {std::string()};
+            std::vector<std::string> pnames = {std::string("")};
+            const mi355x::ModelTerm t =
+                std::any_cast<mi355x::ModelTerm>((*_objective)(x, u, params, pnames, tsym, getDt()));
+            if (t.row != -1) die("the objective callback must return mi355x::objective(...)");
+            P.model = t.model;
+            P.model_params = t.params;
+        }
+        for (size_t i = 0; i < getNStates(); ++i) {
+            vector_t params = {std::string()};
+            std::vector<std::string> pnames = {std::string("")};
+            const mi355x::ModelTerm t =
+                std::any_cast<mi355x::ModelTerm>((*_gradient.at(i))(x, u, params, pnames, tsym, getDt()));
+            if (t.row != (int)i || t.model != P.model || t.params != P.model_params)
+                die("gradient callback " + std::to_string(i) + " does not describe state derivative " +
+                    std::to_string(i) + " of the objective's model");
+        }
+        P.path_records.clear();
+        P.track_x.clear();
+        P.track_y.clear();
+        P.ntracks = 0;
+        std::vector<std::array<double, EMI_PATH_REC>> track_recs_pending;
+        bool have_xy = false;
+        std::vector<double> node_t(P.nodes);
+        for (size_t k = 0; k < P.nodes; ++k) node_t[k] = P.t0 + (P.tf - P.t0) / 2.0 * (P.tau[k] + 1.0);
+        for (size_t c = 0; c < _constraints.size(); ++c) {
+            vector_t params = {std::string()};
+            std::vector<std::string> pnames = {std::string("")};
+            const fout_mi355x_t blk =
+                std::any_cast<fout_mi355x_t>((*_constraints.at(c))(x, u, params, pnames, tsym, getDt()));
+            if (blk.rows.empty() && blk.tracks.empty()) continue;
+            if (have_xy && (blk.px != P.px || blk.py != P.py))
+                die("all keep-out rows must act on the same two states");
+            P.px = blk.px;
+            P.py = blk.py;
+            have_xy = true;
+            for (const auto& r : blk.rows) P.path_records.insert(P.path_records.end(), r.begin(), r.end());
+            for (const mi355x::TrackTable& tb : blk.tracks) {
+                std::vector<double> xc(P.nodes), yc(P.nodes);
+                must(emi_track_centres((int)tb.t.size(), tb.t.data(), tb.x.data(), tb.y.data(), (int)P.nodes,
+                                       node_t.data(), xc.data(), yc.data()), nullptr, "emi_track_centres");
+                P.track_x.insert(P.track_x.end(), xc.begin(), xc.end());
+                P.track_y.insert(P.track_y.end(), yc.begin(), yc.end());
+                std::array<double, EMI_PATH_REC> rec{};
+                rec[0] = (double)EMI_PATH_TRACK;
+                rec[1] = (double)P.ntracks++;
+                rec[2] = tb.radius * tb.radius;
+                P.path_records.insert(P.path_records.end(), rec.begin(), rec.end());
+            }
+        }
+    } catch (std::bad_any_cast& e) {
+        _eAny = &e;
+        std::cout << "Error in eMI355X callback trace" << std::endl;
+        errorHandler();
+    }
+    P.npath = P.path_records.size() / EMI_PATH_REC;
+}
+
+// ETOL bounds -> NLP bounds, as ePSOPT::addBounds (reference :125-155): state/control
+// boxes at every node, hard initial state, boxed terminal state, one [lbnd,ubnd] pair
+// per path row taken from _parameters in map (name-sorted) order, fixed horizon.
+void eMI355X::addBounds() {
+    mi355x::Prob& P = _problem;
+    const size_t ns = getNStates(), nc = getNControls();
+    if (getXlower().size() < ns || getXupper().size() < ns || getX0().size() < ns || getXf().size() < ns ||
+        getXtol().size() < ns || getUlower().size() < nc || getUupper().size() < nc)
+        die("bounds / initial / terminal vectors are shorter than the state or control count");
+    P.state_lower.assign(getXlower().begin(), getXlower().begin() + ns);
+    P.state_upper.assign(getXupper().begin(), getXupper().begin() + ns);
+    P.control_lower.assign(getUlower().begin(), getUlower().begin() + nc);
+    P.control_upper.assign(getUupper().begin(), getUupper().begin() + nc);
+    P.event_lower.assign(2 * ns, 0.0);
+    P.event_upper.assign(2 * ns, 0.0);
+    for (size_t i = 0; i < ns; ++i) {
+        P.event_lower[i] = getX0()[i];
+        P.event_upper[i] = getX0()[i];
+        P.event_lower[i + ns] = getXf()[i] - getXtol()[i];
+        P.event_upper[i + ns] = getXf()[i] + getXtol()[i];
+    }
+    P.path_lower.clear();
+    P.path_upper.clear();
+    for (const auto& kv : _parameters) {
+        P.path_lower.push_back(kv.second.lbnd);
+        P.path_upper.push_back(kv.second.ubnd);
+    }
+}
+
+void eMI355X::setup() {
+    mi355x::Prob& P = _problem;
+    if (getXrhorizon() > 0 || getUrhorizon() > 0)
+        die("delayed states/controls (rhorizon > 0) are not supported by the device models yet");
+    P.nstates = getNStates();
+    P.ncontrols = getNControls();
+    P.nodes = getNSteps() + 1;                       // ePSOPT.cpp:44-45
+    P.t0 = 0.;
+    P.tf = getNSteps() * getDt();                    // fixed horizon, ePSOPT.cpp:151-154
+    if (P.nodes < 2 || !(P.tf > 0)) die("nsteps and dt must be positive");
+    P.tau.resize(P.nodes);
+    P.w.resize(P.nodes);
+    P.D.resize(P.nodes * P.nodes);
+    must(emi_lgl((int)P.nodes, P.tau.data(), P.w.data(), P.D.data()), nullptr, "emi_lgl");
+
+    traceCallbacks();
+    int ns = 0, nc = 0, npar = 0;
+    if (emi_model_dims(P.model, &ns, &nc, &npar) != EMI_OK) die("unknown device model");
+    if ((size_t)ns != P.nstates || (size_t)nc != P.ncontrols)
+        die("the device model has " + std::to_string(ns) + " states / " + std::to_string(nc) +
+            " controls, the configuration has " + std::to_string(P.nstates) + " / " + std::to_string(P.ncontrols));
+    if (P.npath != _parameters.size())   // ePSOPT sizes npath from _parameters (:58)
+        die("constraint callbacks returned " + std::to_string(P.npath) + " rows but " +
+            std::to_string(_parameters.size()) + " were registered with addParams");
+    addBounds();
+
+    _dev.reset(new Device());
+    const int st = emi_create(_algorithm.device, &_dev->ctx);
+    if (st != EMI_OK)
+        die(std::string("cannot open MI355X device ") + std::to_string(_algorithm.device) + ": " +
+            emi_status_string(st) + " (there is no CPU fallback)");
+    emi_ctx_t c = _dev->ctx;
+    must(emi_set_mesh(c, (int)P.nodes, P.tau.data(), P.w.data(), P.D.data(), P.t0, P.tf), c, "emi_set_mesh");
+    must(emi_set_model(c, P.model, P.model_params.data(), (int)P.model_params.size(), isMaximized() ? 1 : 0), c,
+         "emi_set_model");
+    must(emi_set_batch(c, 1), c, "emi_set_batch");
+    if (P.ntracks)
+        must(emi_set_tracks(c, (int)P.ntracks, 1, P.track_x.data(), P.track_y.data()), c, "emi_set_tracks");
+    must(emi_set_path(c, (int)P.npath, 1, P.path_records.data(), (int)P.px, (int)P.py), c, "emi_set_path");
+
+    // algorithm defaults of ePSOPT::setup (:62-72) that have a meaning here
+    _algorithm.nlp_iter_max = 200;
+    _algorithm.nlp_tolerance = 1.e-6;
+    _algorithm.print_level = 0;
+}
+
+namespace mi355x {
+
+NlpProblem make_nlp(const Prob& P, NlpEvaluator* ev) {
+    const size_t ns = P.nstates, nc = P.ncontrols, M = P.nodes, nv = ns + nc;
+    NlpProblem nlp;
+    nlp.ns = (int)ns; nlp.nc = (int)nc; nlp.np = (int)P.npath; nlp.M = (int)M;
+    nlp.px = (int)P.px; nlp.py = (int)P.py;
+    nlp.D = P.D;
+    nlp.ev = ev;
+    nlp.zl.resize(nv * M);
+    nlp.zu.resize(nv * M);
+    for (size_t i = 0; i < ns; ++i)
+        for (size_t k = 0; k < M; ++k) {
+            double l = P.state_lower[i], u = P.state_upper[i];
+            if (k == 0) { l = std::max(l, P.event_lower[i]); u = std::min(u, P.event_upper[i]); }
+            if (k == M - 1) { l = std::max(l, P.event_lower[ns + i]); u = std::min(u, P.event_upper[ns + i]); }
+            nlp.zl[i * M + k] = l;
+            nlp.zu[i * M + k] = u;
+        }
+    for (size_t j = 0; j < nc; ++j)
+        for (size_t k = 0; k < M; ++k) {
+            nlp.zl[(ns + j) * M + k] = P.control_lower[j];
+            nlp.zu[(ns + j) * M + k] = P.control_upper[j];
+        }
+    nlp.cl = P.path_lower;
+    nlp.cu = P.path_upper;
+    // keep-out rows are iterated on normalised: ellipse / (a^2 b^2), disc / r^2
+    nlp.cscale.assign(P.npath, 1.0);
+    for (size_t j = 0; j < P.npath; ++j) {
+        const double* r = &P.path_records[j * EMI_PATH_REC];
+        const int kind = (int)r[0];
+        const double ref = kind == EMI_PATH_ELLIPSE ? r[5] * r[6] : (kind == EMI_PATH_DISC ? r[3] : r[2]);
+        if (ref > 0 && std::isfinite(ref)) nlp.cscale[j] = 1.0 / ref;
+    }
+    return nlp;
+}
+
+std::vector<double> initial_guess(const Prob& P) {
+    const size_t ns = P.nstates, nc = P.ncontrols, M = P.nodes;
+    std::vector<double> z0((ns + nc) * M, 0.0);
+    // ePSOPT cold-starts every state at 0 (reference ePSOPT.cpp:47-56) and lets IPOPT's
+    // restoration phase recover; this iteration has no restoration phase, so the default
+    // state guess is the straight line between the boundary states (it satisfies the event
+    // bounds; the defects are then O(1) instead of O(N^2 |x|)).  Controls start at 0.
+    for (size_t i = 0; i < ns; ++i) {
+        const double a = 0.5 * (P.event_lower[i] + P.event_upper[i]);
+        const double b = 0.5 * (P.event_lower[ns + i] + P.event_upper[ns + i]);
+        for (size_t k = 0; k < M; ++k) z0[i * M + k] = a + (b - a) * 0.5 * (P.tau[k] + 1.0);
+    }
+    // Nodes of the line that fall inside a keep-out are moved radially out of it (ellipse:
+    // offset from the centre scaled until the quadratic form reaches 1+margin).  Inside a
+    // keep-out the row function is concave with a vanishing gradient at the centre, which is
+    // the worst place to start a Newton-type iteration from.
+    if (P.npath > 0 && M > 2) {
+        const double margin = 0.05;
+        double* xs = &z0[P.px * M];
+        double* ys = &z0[P.py * M];
+        for (int sweep = 0; sweep < 50; ++sweep) {
+            bool moved = false;
+            for (size_t k = 1; k + 1 < M; ++k) {
+                for (size_t j = 0; j < P.npath; ++j) {
+                    const double* r = &P.path_records[j * EMI_PATH_REC];
+                    const int kind = (int)r[0];
+                    double xc, yc, ct = 1, st = 0, asq, bsq;
+                    if (kind == EMI_PATH_ELLIPSE) { xc = r[1]; yc = r[2]; ct = r[3]; st = r[4]; asq = r[5]; bsq = r[6]; }
+                    else if (kind == EMI_PATH_DISC) { xc = r[1]; yc = r[2]; asq = bsq = r[3]; }
+                    else { const size_t t = (size_t)r[1]; xc = P.track_x[t * M + k]; yc = P.track_y[t * M + k]; asq = bsq = r[2]; }
+                    if (!(asq > 0) || !(bsq > 0)) continue;
+                    const double dx = xs[k] - xc, dy = ys[k] - yc;
+                    double ex = ct * dx - st * dy, ey = st * dx + ct * dy;
+                    const double q = ex * ex / asq + ey * ey / bsq;
+                    if (q >= 1.0 + 0.5 * margin) continue;
+                    if (q < 1e-12) { ex = 0; ey = std::sqrt(bsq * (1.0 + margin)); }      // dead centre: minor axis
+                    else { const double g = std::sqrt((1.0 + margin) / q); ex *= g; ey *= g; }
+                    xs[k] = xc + ct * ex + st * ey;
+                    ys[k] = yc - st * ex + ct * ey;
+                    moved = true;
+                }
+            }
+            if (!moved) break;
+        }
+    }
+    if (P.guess_states.size() == ns * M) std::copy(P.guess_states.begin(), P.guess_states.end(), z0.begin());
+    if (P.guess_controls.size() == nc * M)
+        std::copy(P.guess_controls.begin(), P.guess_controls.end(), z0.begin() + ns * M);
+    return z0;
+}
+
+}  // namespace mi355x
+
+void eMI355X::solve() {
+    if (!_dev || !_dev->ctx) die("solve() called before setup()");
+    mi355x::Prob& P = _problem;
+    const size_t ns = P.nstates, nc = P.ncontrols, M = P.nodes;
+
+    mi355x::NlpProblem nlp = mi355x::make_nlp(P, _dev.get());
+    const std::vector<double> z0 = mi355x::initial_guess(P);
+
+    mi355x::NlpOptions opt;
+    opt.tol = _algorithm.nlp_tolerance;
+    opt.max_iter = _algorithm.nlp_iter_max;
+    opt.print_level = _algorithm.print_level;
+    opt.max_cpu_time = _algorithm.max_cpu_time;
+    const mi355x::NlpResult r = mi355x::solve_nlp(nlp, opt, z0);
+
+    _solution.error_flag = r.ok ? 0 : 1;
+    _solution.error_msg = r.msg;
+    _solution.nlp_iterations = r.iterations;
+    _solution.evaluations = r.evaluations;
+    _solution.kkt_error = r.kkt_error;
+    _solution.constraint_violation = r.constr_viol;
+    if (_solution.error_flag) {
+        std::cout << "!!!!!Problem failed!!!!!" << std::endl << _solution.error_msg << std::endl;
+        return;
+    }
+    _solution.cost = r.cost;
+    _solution.nstates = ns;
+    _solution.ncontrols = nc;
+    _solution.nodes = M;
+    _solution.states.assign(r.z.begin(), r.z.begin() + ns * M);
+    _solution.controls.assign(r.z.begin() + ns * M, r.z.end());
+    _solution.time.resize(M);
+    for (size_t k = 0; k < M; ++k) _solution.time[k] = P.t0 + (P.tf - P.t0) / 2.0 * (P.tau[k] + 1.0);
+    setScore(isMaximized() ? -_solution.cost : _solution.cost);
+    getTraj();
+}
+
+// one (t_k, values) element per LGL node, states and controls (ePSOPT.cpp:157-182)
+void eMI355X::getTraj() {
+    traj_t* xt = getXtraj();
+    traj_t* ut = getUtraj();
+    xt->clear();
+    ut->clear();
+    const size_t M = _solution.nodes;
+    for (size_t k = 0; k < M; ++k) {
+        state_t xs, us;
+        for (size_t i = 0; i < _solution.nstates; ++i) xs.push_back(_solution.states[i * M + k]);
+        for (size_t j = 0; j < _solution.ncontrols; ++j) us.push_back(_solution.controls[j * M + k]);
+        xt->push_back(traj_elem_t(_solution.time[k], xs));
+        ut->push_back(traj_elem_t(_solution.time[k], us));
+    }
+}
+
+void eMI355X::debug() { _algorithm.print_level = 5; }
+
+void eMI355X::close() { _dev.reset(); }
+
+}  // namespace ETOL

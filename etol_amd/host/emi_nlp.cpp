@@ -1,0 +1,646 @@
+// emi_nlp.cpp -- primal-dual interior-point iteration for the transcribed VGP.
+// See emi_nlp.hpp for what this stands in for in the reference (IPOPT behind
+// PSOPT, src/ePSOPT/ePSOPT.cpp:62-66,84).  Written from the published
+// algorithm (Waechter & Biegler 2006: barrier subproblems, fraction-to-the-
+// boundary rule, inertia correction of the KKT matrix), with an l1 merit
+// function instead of a filter.
+//
+// NLP in per-instance numbering (DESIGN.md "NLP layout"):
+//   variables   z (states then controls, index v*M+k), slacks s for the path rows
+//   equalities  defect_(i,k)(z) = 0,   c_(j,k)(z) - s_(j,k) = 0
+//   bounds      zl <= z <= zu (zl==zu removes the variable), cl_j <= s_(j,k) <= cu_j
+// The boundary conditions of ePSOPT::events (ePSOPT.cpp:137-141, 281-291) act
+// directly on node variables, so they arrive here as variable bounds.
+#include "emi_nlp.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+namespace ETOL {
+namespace mi355x {
+
+// ---------------------------------------------------------------------------------------------
+// Bunch-Kaufman LDL^T, lower triangle, unblocked
+// ---------------------------------------------------------------------------------------------
+bool ldlt_factor(LdltFactor& F) {
+    const int n = F.n;
+    double* A = F.a.data();
+    F.ipiv.assign(n, 0);
+    F.npos = F.nneg = F.nzero = 0;
+    const double alpha = (1.0 + std::sqrt(17.0)) / 8.0;
+    auto at = [&](int i, int j) -> double& { return A[(size_t)i * n + j]; };
+    bool ok = true;
+    int k = 0;
+    while (k < n) {
+        int kstep = 1, kp = k;
+        const double absakk = std::fabs(at(k, k));
+        int imax = k;
+        double colmax = 0.0;
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(at(i, k)) > colmax) { colmax = std::fabs(at(i, k)); imax = i; }
+        if (std::max(absakk, colmax) == 0.0) {
+            ok = false;
+            F.ipiv[k] = k;
+            ++F.nzero;
+            ++k;
+            continue;
+        }
+        if (absakk < alpha * colmax) {
+            double rowmax = 0.0;
+            for (int j = k; j < imax; ++j) rowmax = std::max(rowmax, std::fabs(at(imax, j)));
+            for (int i = imax + 1; i < n; ++i) rowmax = std::max(rowmax, std::fabs(at(i, imax)));
+            if (absakk >= alpha * colmax * (colmax / rowmax)) kp = k;
+            else if (std::fabs(at(imax, imax)) >= alpha * rowmax) kp = imax;
+            else { kp = imax; kstep = 2; }
+        }
+        const int kk = k + kstep - 1;
+        if (kp != kk) {   // symmetric interchange of rows/columns kk and kp in the trailing block
+            for (int i = kp + 1; i < n; ++i) std::swap(at(i, kk), at(i, kp));
+            for (int j = kk + 1; j < kp; ++j) std::swap(at(j, kk), at(kp, j));
+            std::swap(at(kk, kk), at(kp, kp));
+            if (kstep == 2) std::swap(at(k + 1, k), at(kp, k));
+        }
+        if (kstep == 1) {
+            const double piv = at(k, k);
+            (piv > 0 ? F.npos : F.nneg)++;
+            const double r = 1.0 / piv;
+            for (int j = k + 1; j < n; ++j) {
+                const double ajk = at(j, k) * r;
+                if (ajk != 0.0)
+                    for (int i = j; i < n; ++i) at(i, j) -= at(i, k) * ajk;
+            }
+            for (int i = k + 1; i < n; ++i) at(i, k) *= r;
+            F.ipiv[k] = kp;
+        } else {
+            const double a11 = at(k, k), a21 = at(k + 1, k), a22 = at(k + 1, k + 1);
+            const double det = a11 * a22 - a21 * a21, tr = a11 + a22;
+            if (det < 0) { ++F.npos; ++F.nneg; }
+            else if (det > 0) { (tr > 0 ? F.npos : F.nneg) += 2; }
+            else { ++F.nzero; (tr > 0 ? F.npos : F.nneg)++; }
+            if (k + 2 < n) {
+                const double d11 = a22 / a21, d22 = a11 / a21;
+                const double t = 1.0 / (d11 * d22 - 1.0), d21 = t / a21;
+                for (int j = k + 2; j < n; ++j) {
+                    const double wk = d21 * (d11 * at(j, k) - at(j, k + 1));
+                    const double wk1 = d21 * (d22 * at(j, k + 1) - at(j, k));
+                    for (int i = j; i < n; ++i) at(i, j) -= at(i, k) * wk + at(i, k + 1) * wk1;
+                    at(j, k) = wk;
+                    at(j, k + 1) = wk1;
+                }
+            }
+            F.ipiv[k] = F.ipiv[k + 1] = -(kp + 1);
+        }
+        k += kstep;
+    }
+    return ok;
+}
+
+void ldlt_solve(const LdltFactor& F, double* b) {
+    const int n = F.n;
+    const double* A = F.a.data();
+    auto at = [&](int i, int j) -> double { return A[(size_t)i * n + j]; };
+    int k = 0;
+    while (k < n) {   // L D y = P b
+        if (F.ipiv[k] >= 0) {
+            const int kp = F.ipiv[k];
+            if (kp != k) std::swap(b[k], b[kp]);
+            for (int i = k + 1; i < n; ++i) b[i] -= at(i, k) * b[k];
+            b[k] /= at(k, k);
+            ++k;
+        } else {
+            const int kp = -F.ipiv[k] - 1;
+            if (kp != k + 1) std::swap(b[k + 1], b[kp]);
+            for (int i = k + 2; i < n; ++i) b[i] -= at(i, k) * b[k] + at(i, k + 1) * b[k + 1];
+            const double a21 = at(k + 1, k);
+            const double akm1 = at(k, k) / a21, ak = at(k + 1, k + 1) / a21;
+            const double den = akm1 * ak - 1.0;
+            const double bkm1 = b[k] / a21, bk = b[k + 1] / a21;
+            b[k] = (ak * bkm1 - bk) / den;
+            b[k + 1] = (akm1 * bk - bkm1) / den;
+            k += 2;
+        }
+    }
+    k = n - 1;
+    while (k >= 0) {   // L^T x = y, undo P
+        if (F.ipiv[k] >= 0) {
+            double s = b[k];
+            for (int i = k + 1; i < n; ++i) s -= at(i, k) * b[i];
+            b[k] = s;
+            const int kp = F.ipiv[k];
+            if (kp != k) std::swap(b[k], b[kp]);
+            --k;
+        } else {
+            double s0 = b[k - 1], s1 = b[k];
+            for (int i = k + 1; i < n; ++i) {
+                s0 -= at(i, k - 1) * b[i];
+                s1 -= at(i, k) * b[i];
+            }
+            b[k - 1] = s0;
+            b[k] = s1;
+            const int kp = -F.ipiv[k] - 1;
+            if (kp != k) std::swap(b[k], b[kp]);
+            k -= 2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// interior point
+// ---------------------------------------------------------------------------------------------
+// Path rows are elastic:  sigma_j c_j(z) - s - e+ + e- = 0,  cl <= s <= cu,  e+- >= 0, with the
+// exact penalty rho (e+ + e-) in the objective.  A strictly interior start then always exists
+// (a straight-line guess usually crosses keep-outs, where a plain slack formulation jams against
+// the slack bound), and for rho above the row multipliers the minimiser has e = 0, i.e. it is a
+// KKT point of the original problem.  rho is raised and the iteration continued if some e stays
+// positive at convergence.
+namespace {
+
+constexpr double INF_BOUND = 1e19;
+
+struct Iterate {
+    std::vector<double> z, s, e1, e2;             // primal: variables, row slacks, elastics
+    std::vector<double> lam, y;                   // equality multipliers (defects, path rows)
+    std::vector<double> zL, zU, vL, vU, w1, w2;   // bound multipliers (0 where the bound is infinite)
+};
+
+struct Eval {
+    std::vector<double> RES, VALS, H;
+    double cost = 0;
+};
+
+}  // namespace
+
+NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vector<double>& z0) {
+    NlpResult R;
+    const int ns = P.ns, nc = P.nc, np = P.np, M = P.M, nv = ns + nc;
+    const int nz = nv * M, md = ns * M, mc = np * M, nh = nv * (nv + 1) / 2;
+    const int nvals = ns * nv + 2 * np + nv;
+    if (!P.ev || (int)P.zl.size() != nz || (int)P.zu.size() != nz || (int)P.D.size() != M * M ||
+        (int)P.cl.size() != np || (int)P.cu.size() != np || (int)z0.size() != nz) {
+        R.msg = "solve_nlp: inconsistent problem sizes";
+        return R;
+    }
+    const auto tstart = std::chrono::steady_clock::now();
+
+    // free-variable map
+    std::vector<int> fidx(nz, -1);
+    int nf = 0;
+    for (int q = 0; q < nz; ++q)
+        if (P.zu[q] > P.zl[q]) fidx[q] = nf++;
+    auto hasL = [&](int q) { return P.zl[q] > -INF_BOUND; };
+    auto hasU = [&](int q) { return P.zu[q] < INF_BOUND; };
+    // path rows are iterated on in scaled form  sigma_j * c_j  (same KKT points, better
+    // balanced against the defects: a keep-out value is O(a^2 b^2) ~ 1e-3 unscaled)
+    std::vector<double> sig(np, 1.0);
+    if (!P.cscale.empty()) {
+        if ((int)P.cscale.size() != np) { R.msg = "solve_nlp: cscale has the wrong length"; return R; }
+        for (int j = 0; j < np; ++j) sig[j] = P.cscale[j] > 0 ? P.cscale[j] : 1.0;
+    }
+    for (int j = 0; j < np; ++j)
+        if (!(P.cl[j] > -INF_BOUND) && !(P.cu[j] < INF_BOUND)) { R.msg = "solve_nlp: path row without any bound"; return R; }
+    auto shasL = [&](int r) { return P.cl[r / M] > -INF_BOUND; };
+    auto shasU = [&](int r) { return P.cu[r / M] < INF_BOUND; };
+    auto cL = [&](int r) { return shasL(r) ? sig[r / M] * P.cl[r / M] : P.cl[r / M]; };
+    auto cU = [&](int r) { return shasU(r) ? sig[r / M] * P.cu[r / M] : P.cu[r / M]; };
+
+    Iterate it;
+    it.z = z0;
+    // push the start into the interior of the bounds
+    for (int q = 0; q < nz; ++q) {
+        const double l = P.zl[q], u = P.zu[q];
+        if (fidx[q] < 0) { it.z[q] = l; continue; }
+        double pl = 0, pu = 0;
+        if (hasL(q)) pl = opt.bound_push * std::max(1.0, std::fabs(l));
+        if (hasU(q)) pu = opt.bound_push * std::max(1.0, std::fabs(u));
+        if (hasL(q) && hasU(q)) {
+            pl = std::min(pl, opt.bound_frac * (u - l));
+            pu = std::min(pu, opt.bound_frac * (u - l));
+        }
+        if (hasL(q)) it.z[q] = std::max(it.z[q], l + pl);
+        if (hasU(q)) it.z[q] = std::min(it.z[q], u - pu);
+    }
+
+    Eval E;
+    E.RES.resize((size_t)(ns + np) * M);
+    E.VALS.resize((size_t)nvals * M);
+    E.H.resize((size_t)nh * M);
+    auto evaluate = [&](const std::vector<double>& z, Eval& e, bool jac) -> bool {
+        ++R.evaluations;
+        if (P.ev->eval(z.data(), z.data() + (size_t)ns * M, e.RES.data(), jac ? e.VALS.data() : nullptr, &e.cost,
+                       jac) != 0)
+            return false;
+        for (int j = 0; j < np; ++j) {
+            if (sig[j] == 1.0) continue;
+            for (int k = 0; k < M; ++k) {
+                e.RES[(size_t)(ns + j) * M + k] *= sig[j];
+                if (jac) {
+                    e.VALS[(size_t)(ns * nv + 2 * j) * M + k] *= sig[j];
+                    e.VALS[(size_t)(ns * nv + 2 * j + 1) * M + k] *= sig[j];
+                }
+            }
+        }
+        return true;
+    };
+    if (!evaluate(it.z, E, true)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
+
+    double rho = 10.0;
+    it.s.assign(mc, 0.0);
+    it.e1.assign(mc, 0.0);
+    it.e2.assign(mc, 0.0);
+    for (int r = 0; r < mc; ++r) {
+        const double c0 = E.RES[(size_t)md + r];
+        double v = c0;
+        const double l = cL(r), u = cU(r);
+        double pl = shasL(r) ? opt.bound_push * std::max(1.0, std::fabs(l)) : 0;
+        double pu = shasU(r) ? opt.bound_push * std::max(1.0, std::fabs(u)) : 0;
+        if (shasL(r) && shasU(r)) { pl = std::min(pl, opt.bound_frac * (u - l)); pu = std::min(pu, opt.bound_frac * (u - l)); }
+        if (shasL(r)) v = std::max(v, l + pl);
+        if (shasU(r)) v = std::min(v, u - pu);
+        it.s[r] = v;
+        const double gap = c0 - v, ee = opt.bound_push * std::max(1.0, std::fabs(gap));
+        it.e1[r] = std::max(gap, 0.0) + ee;     // residual c - s - e1 + e2 starts at exactly 0
+        it.e2[r] = std::max(-gap, 0.0) + ee;
+    }
+    it.lam.assign(md, 0.0);
+    it.y.assign(mc, 0.0);
+    it.zL.assign(nz, 0.0); it.zU.assign(nz, 0.0);
+    it.vL.assign(mc, 0.0); it.vU.assign(mc, 0.0);
+    it.w1.assign(mc, rho); it.w2.assign(mc, rho);
+    for (int q = 0; q < nz; ++q) if (fidx[q] >= 0) { if (hasL(q)) it.zL[q] = 1.0; if (hasU(q)) it.zU[q] = 1.0; }
+    for (int r = 0; r < mc; ++r) { if (shasL(r)) it.vL[r] = 1.0; if (shasU(r)) it.vU[r] = 1.0; }
+
+    double mu = opt.mu_init, nu = 1.0;
+    double dw_last = 0.0;
+    const double tau_min = 0.99, kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, kappa_sigma = 1e10;
+    std::vector<double> y_unscaled(mc);
+
+    // --- pieces of the KKT residual at the current point --------------------------------------
+    std::vector<double> gradf(nz), jtl(nz);
+    auto grad_and_jt = [&](const Iterate& I) {
+        const double* V = E.VALS.data();
+        for (int v = 0; v < nv; ++v)
+            for (int k = 0; k < M; ++k) gradf[v * M + k] = V[(size_t)(ns * nv + 2 * np + v) * M + k];
+        std::fill(jtl.begin(), jtl.end(), 0.0);
+        // J_d^T lam: off-diagonal D part, then the node blocks (which hold D_kk)
+        for (int i = 0; i < ns; ++i)
+            for (int k = 0; k < M; ++k) {
+                const double l = I.lam[i * M + k];
+                if (l == 0.0) continue;
+                const double* Dk = &P.D[(size_t)k * M];
+                double* col = &jtl[(size_t)i * M];
+                for (int j = 0; j < M; ++j) col[j] += Dk[j] * l;
+                col[k] -= Dk[k] * l;
+                for (int v = 0; v < nv; ++v) jtl[v * M + k] += V[(size_t)(i * nv + v) * M + k] * l;
+            }
+        for (int j = 0; j < np; ++j)
+            for (int k = 0; k < M; ++k) {
+                const double yy = I.y[j * M + k];
+                jtl[P.px * M + k] += V[(size_t)(ns * nv + 2 * j) * M + k] * yy;
+                jtl[P.py * M + k] += V[(size_t)(ns * nv + 2 * j + 1) * M + k] * yy;
+            }
+    };
+    auto row_res = [&](const Eval& e, const std::vector<double>& s, const std::vector<double>& e1,
+                       const std::vector<double>& e2, int r) { return e.RES[(size_t)md + r] - s[r] - e1[r] + e2[r]; };
+    auto kkt_error = [&](const Iterate& I, double mu_t, double* viol_out, double* emax_out) {
+        double sumz = 0, summ = 0;
+        int cntz = 0;
+        for (int q = 0; q < nz; ++q) { sumz += I.zL[q] + I.zU[q]; cntz += (I.zL[q] > 0) + (I.zU[q] > 0); }
+        for (int r = 0; r < mc; ++r) {
+            sumz += I.vL[r] + I.vU[r] + I.w1[r] + I.w2[r];
+            cntz += (I.vL[r] > 0) + (I.vU[r] > 0) + 2;
+            summ += std::fabs(I.y[r]);
+        }
+        for (int r = 0; r < md; ++r) summ += std::fabs(I.lam[r]);
+        const double smax = 100.0;
+        const double sd = std::max(smax, (summ + sumz) / std::max(1, md + mc + cntz)) / smax;
+        const double sc = std::max(smax, sumz / std::max(1, cntz)) / smax;
+        double ed = 0, ep = 0, ec = 0, emax = 0;
+        for (int q = 0; q < nz; ++q)
+            if (fidx[q] >= 0) ed = std::max(ed, std::fabs(gradf[q] + jtl[q] - I.zL[q] + I.zU[q]));
+        for (int r = 0; r < mc; ++r) {
+            ed = std::max(ed, std::fabs(-I.y[r] - I.vL[r] + I.vU[r]));
+            ed = std::max(ed, std::fabs(rho - I.y[r] - I.w1[r]));
+            ed = std::max(ed, std::fabs(rho + I.y[r] - I.w2[r]));
+        }
+        for (int r = 0; r < md; ++r) ep = std::max(ep, std::fabs(E.RES[r]));
+        for (int r = 0; r < mc; ++r) {
+            ep = std::max(ep, std::fabs(row_res(E, I.s, I.e1, I.e2, r)));
+            emax = std::max(emax, std::max(I.e1[r], I.e2[r]));
+        }
+        for (int q = 0; q < nz; ++q) {
+            if (fidx[q] < 0) continue;
+            if (hasL(q)) ec = std::max(ec, std::fabs((I.z[q] - P.zl[q]) * I.zL[q] - mu_t));
+            if (hasU(q)) ec = std::max(ec, std::fabs((P.zu[q] - I.z[q]) * I.zU[q] - mu_t));
+        }
+        for (int r = 0; r < mc; ++r) {
+            if (shasL(r)) ec = std::max(ec, std::fabs((I.s[r] - cL(r)) * I.vL[r] - mu_t));
+            if (shasU(r)) ec = std::max(ec, std::fabs((cU(r) - I.s[r]) * I.vU[r] - mu_t));
+            ec = std::max(ec, std::fabs(I.e1[r] * I.w1[r] - mu_t));
+            ec = std::max(ec, std::fabs(I.e2[r] * I.w2[r] - mu_t));
+        }
+        if (viol_out) *viol_out = ep;
+        if (emax_out) *emax_out = emax;
+        return std::max(std::max(ed / sd, ep), ec / sc);
+    };
+    auto barrier_merit = [&](const std::vector<double>& z, const std::vector<double>& s, const std::vector<double>& e1,
+                             const std::vector<double>& e2, const Eval& e, double mu_t, double nu_t, double* infeas) {
+        double phi = e.cost, viol = 0;
+        for (int q = 0; q < nz; ++q) {
+            if (fidx[q] < 0) continue;
+            if (hasL(q)) phi -= mu_t * std::log(z[q] - P.zl[q]);
+            if (hasU(q)) phi -= mu_t * std::log(P.zu[q] - z[q]);
+        }
+        for (int r = 0; r < mc; ++r) {
+            if (shasL(r)) phi -= mu_t * std::log(s[r] - cL(r));
+            if (shasU(r)) phi -= mu_t * std::log(cU(r) - s[r]);
+            phi += rho * (e1[r] + e2[r]) - mu_t * (std::log(e1[r]) + std::log(e2[r]));
+            viol += std::fabs(row_res(e, s, e1, e2, r));
+        }
+        for (int r = 0; r < md; ++r) viol += std::fabs(e.RES[r]);
+        if (infeas) *infeas = viol;
+        return phi + nu_t * viol;
+    };
+
+    const int N = nf + md;
+    LdltFactor F;
+    std::vector<double> rhs(N), dz(nz), ds(mc), de1(mc), de2(mc), dlam(md), dy(mc), dzL(nz), dzU(nz), dvL(mc), dvU(mc),
+        dw1(mc), dw2(mc);
+    std::vector<double> sig_t(mc), r_t(mc), sig_s(mc), rhat_s(mc);
+    Eval Et;
+    Et.RES.resize(E.RES.size());
+    Et.VALS.resize(E.VALS.size());
+    std::vector<double> zt(nz), st(mc), e1t(mc), e2t(mc);
+
+    grad_and_jt(it);
+    for (int iter = 0;; ++iter) {
+        R.iterations = iter;
+        double viol = 0, emax = 0;
+        const double err0 = kkt_error(it, 0.0, &viol, &emax);
+        R.kkt_error = err0;
+        R.constr_viol = viol;
+        if (opt.print_level >= 5)
+            printf("iter %3d  cost %.10e  inf_pr %.2e  kkt %.2e  mu %.1e  dw %.1e  nu %.1e  emax %.1e  rho %.0e\n", iter,
+                   E.cost, viol, err0, mu, dw_last, nu, emax, rho);
+        if (err0 <= opt.tol) {
+            if (emax <= std::max(opt.tol, 1e-9) * 10.0 || mc == 0) { R.ok = true; R.msg = "converged"; break; }
+            // a path row is still relaxed: the penalty was too small for it
+            if (rho >= 1e12) { R.msg = "converged to a point that violates the path rows (locally infeasible)"; break; }
+            rho *= 10.0;
+            mu = std::max(mu, 1e-2);
+            for (int r = 0; r < mc; ++r) { it.w1[r] = std::max(1e-8, rho - it.y[r]); it.w2[r] = std::max(1e-8, rho + it.y[r]); }
+        }
+        if (iter >= opt.max_iter) { R.msg = "maximum number of iterations exceeded"; break; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count() > opt.max_cpu_time) {
+            R.msg = "time limit exceeded";
+            break;
+        }
+        // barrier update (may fire several times in a row)
+        while (mu > opt.tol / 10.0 && kkt_error(it, mu, nullptr, nullptr) <= kappa_eps * mu)
+            mu = std::max(opt.tol / 10.0, std::min(kappa_mu * mu, std::pow(mu, theta_mu)));
+        const double tau = std::max(tau_min, 1.0 - mu);
+
+        // exact Lagrangian Hessian blocks from the device
+        for (int r = 0; r < mc; ++r) y_unscaled[r] = sig[r / M] * it.y[r];
+        if (P.ev->hess(it.z.data(), it.z.data() + (size_t)ns * M, it.lam.data(), np ? y_unscaled.data() : nullptr, 1.0,
+                       E.H.data()) != 0) {
+            R.msg = "Hessian evaluation failed: " + P.ev->last_error();
+            break;
+        }
+        // eliminate (s, e+, e-) of every path row:  dy = sig_t (J_c dz + r_t)
+        for (int r = 0; r < mc; ++r) {
+            double sg = 0, rh = -it.y[r];
+            if (shasL(r)) { const double g = it.s[r] - cL(r); sg += it.vL[r] / g; rh -= mu / g; }
+            if (shasU(r)) { const double g = cU(r) - it.s[r]; sg += it.vU[r] / g; rh += mu / g; }
+            sig_s[r] = sg;
+            rhat_s[r] = rh;
+            const double a1 = it.e1[r] / it.w1[r], a2 = it.e2[r] / it.w2[r];
+            sig_t[r] = 1.0 / (1.0 / sg + a1 + a2);
+            r_t[r] = row_res(E, it.s, it.e1, it.e2, r) + rh / sg - a1 * (it.y[r] - rho + mu / it.e1[r]) -
+                     a2 * (it.y[r] + rho - mu / it.e2[r]);
+        }
+        // factor with inertia correction
+        bool factored = false;
+        double dw = 0.0, dc = 0.0;
+        for (int attempt = 0; attempt < 40; ++attempt) {
+            F.n = N;
+            F.a.assign((size_t)N * N, 0.0);
+            auto K = [&](int i, int j) -> double& { return i >= j ? F.a[(size_t)i * N + j] : F.a[(size_t)j * N + i]; };
+            const double* V = E.VALS.data();
+            for (int k = 0; k < M; ++k) {
+                for (int v = 0; v < nv; ++v) {
+                    const int fv = fidx[v * M + k];
+                    if (fv < 0) continue;
+                    for (int q = 0; q <= v; ++q) {
+                        const int fq = fidx[q * M + k];
+                        if (fq < 0) continue;
+                        K(fv, fq) += E.H[(size_t)(v * (v + 1) / 2 + q) * M + k];
+                    }
+                    const int qq = v * M + k;
+                    double sg = dw;
+                    if (hasL(qq)) sg += it.zL[qq] / (it.z[qq] - P.zl[qq]);
+                    if (hasU(qq)) sg += it.zU[qq] / (P.zu[qq] - it.z[qq]);
+                    K(fv, fv) += sg;
+                }
+                const int fx = fidx[P.px * M + k], fy = fidx[P.py * M + k];
+                for (int j = 0; j < np; ++j) {
+                    const double gx = V[(size_t)(ns * nv + 2 * j) * M + k], gy = V[(size_t)(ns * nv + 2 * j + 1) * M + k];
+                    const double sg = sig_t[j * M + k];
+                    if (fx >= 0) K(fx, fx) += sg * gx * gx;
+                    if (fy >= 0) K(fy, fy) += sg * gy * gy;
+                    if (fx >= 0 && fy >= 0) K(std::max(fx, fy), std::min(fx, fy)) += sg * gx * gy;
+                }
+            }
+            for (int i = 0; i < ns; ++i)
+                for (int k = 0; k < M; ++k) {
+                    const int row = nf + i * M + k;
+                    for (int j = 0; j < M; ++j) {
+                        if (j == k) continue;
+                        const int f = fidx[i * M + j];
+                        if (f >= 0) F.a[(size_t)row * N + f] += P.D[(size_t)k * M + j];
+                    }
+                    for (int v = 0; v < nv; ++v) {
+                        const int f = fidx[v * M + k];
+                        if (f >= 0) F.a[(size_t)row * N + f] += V[(size_t)(i * nv + v) * M + k];
+                    }
+                    F.a[(size_t)row * N + row] = -dc;
+                }
+            const bool nonsing = ldlt_factor(F);
+            if (nonsing && F.npos == nf && F.nneg == md && F.nzero == 0) { factored = true; break; }
+            if (!nonsing || F.nzero > 0) dc = 1e-8 * std::pow(mu, 0.25);
+            if (dw == 0.0) dw = dw_last == 0.0 ? 1e-4 : std::max(1e-20, dw_last / 3.0);
+            else dw *= (dw_last == 0.0 ? 100.0 : 8.0);
+            if (dw > 1e40) break;
+        }
+        if (!factored) { R.msg = "KKT matrix could not be regularised to the right inertia"; break; }
+        if (dw > 0) dw_last = dw;
+
+        // right-hand side and solve
+        {
+            const double* V = E.VALS.data();
+            std::fill(rhs.begin(), rhs.end(), 0.0);
+            for (int q = 0; q < nz; ++q) {
+                const int f = fidx[q];
+                if (f < 0) continue;
+                double r = gradf[q] + jtl[q];
+                if (hasL(q)) r -= mu / (it.z[q] - P.zl[q]);
+                if (hasU(q)) r += mu / (P.zu[q] - it.z[q]);
+                rhs[f] = -r;
+            }
+            for (int j = 0; j < np; ++j)
+                for (int k = 0; k < M; ++k) {
+                    const int r = j * M + k;
+                    const double t = sig_t[r] * r_t[r];
+                    const int fx = fidx[P.px * M + k], fy = fidx[P.py * M + k];
+                    if (fx >= 0) rhs[fx] -= V[(size_t)(ns * nv + 2 * j) * M + k] * t;
+                    if (fy >= 0) rhs[fy] -= V[(size_t)(ns * nv + 2 * j + 1) * M + k] * t;
+                }
+            for (int r = 0; r < md; ++r) rhs[nf + r] = -E.RES[r];
+            ldlt_solve(F, rhs.data());
+            for (int q = 0; q < nz; ++q) dz[q] = fidx[q] >= 0 ? rhs[fidx[q]] : 0.0;
+            for (int r = 0; r < md; ++r) dlam[r] = rhs[nf + r];
+            for (int j = 0; j < np; ++j)
+                for (int k = 0; k < M; ++k) {
+                    const int r = j * M + k;
+                    const double jcdz = V[(size_t)(ns * nv + 2 * j) * M + k] * dz[P.px * M + k] +
+                                        V[(size_t)(ns * nv + 2 * j + 1) * M + k] * dz[P.py * M + k];
+                    dy[r] = sig_t[r] * (jcdz + r_t[r]);
+                    ds[r] = (dy[r] - rhat_s[r]) / sig_s[r];
+                    de1[r] = it.e1[r] / it.w1[r] * (dy[r] + it.y[r] - rho + mu / it.e1[r]);
+                    de2[r] = it.e2[r] / it.w2[r] * (-dy[r] - it.y[r] - rho + mu / it.e2[r]);
+                    dvL[r] = dvU[r] = 0;
+                    if (shasL(r)) { const double g = it.s[r] - cL(r); dvL[r] = mu / g - it.vL[r] - it.vL[r] / g * ds[r]; }
+                    if (shasU(r)) { const double g = cU(r) - it.s[r]; dvU[r] = mu / g - it.vU[r] + it.vU[r] / g * ds[r]; }
+                    dw1[r] = mu / it.e1[r] - it.w1[r] - it.w1[r] / it.e1[r] * de1[r];
+                    dw2[r] = mu / it.e2[r] - it.w2[r] - it.w2[r] / it.e2[r] * de2[r];
+                }
+            for (int q = 0; q < nz; ++q) {
+                dzL[q] = dzU[q] = 0;
+                if (fidx[q] < 0) continue;
+                if (hasL(q)) { const double g = it.z[q] - P.zl[q]; dzL[q] = mu / g - it.zL[q] - it.zL[q] / g * dz[q]; }
+                if (hasU(q)) { const double g = P.zu[q] - it.z[q]; dzU[q] = mu / g - it.zU[q] + it.zU[q] / g * dz[q]; }
+            }
+        }
+        // fraction to the boundary
+        double apr = 1.0, adu = 1.0;
+        for (int q = 0; q < nz; ++q) {
+            if (fidx[q] < 0) continue;
+            if (hasL(q) && dz[q] < 0) apr = std::min(apr, -tau * (it.z[q] - P.zl[q]) / dz[q]);
+            if (hasU(q) && dz[q] > 0) apr = std::min(apr, tau * (P.zu[q] - it.z[q]) / dz[q]);
+            if (dzL[q] < 0) adu = std::min(adu, -tau * it.zL[q] / dzL[q]);
+            if (dzU[q] < 0) adu = std::min(adu, -tau * it.zU[q] / dzU[q]);
+        }
+        for (int r = 0; r < mc; ++r) {
+            if (shasL(r) && ds[r] < 0) apr = std::min(apr, -tau * (it.s[r] - cL(r)) / ds[r]);
+            if (shasU(r) && ds[r] > 0) apr = std::min(apr, tau * (cU(r) - it.s[r]) / ds[r]);
+            if (de1[r] < 0) apr = std::min(apr, -tau * it.e1[r] / de1[r]);
+            if (de2[r] < 0) apr = std::min(apr, -tau * it.e2[r] / de2[r]);
+            if (dvL[r] < 0) adu = std::min(adu, -tau * it.vL[r] / dvL[r]);
+            if (dvU[r] < 0) adu = std::min(adu, -tau * it.vU[r] / dvU[r]);
+            if (dw1[r] < 0) adu = std::min(adu, -tau * it.w1[r] / dw1[r]);
+            if (dw2[r] < 0) adu = std::min(adu, -tau * it.w2[r] / dw2[r]);
+        }
+        // l1 merit: directional derivative of the barrier function and the penalty weight
+        double dphi = 0, infeas0 = 0;
+        for (int q = 0; q < nz; ++q) {
+            if (fidx[q] < 0) continue;
+            double g = gradf[q];
+            if (hasL(q)) g -= mu / (it.z[q] - P.zl[q]);
+            if (hasU(q)) g += mu / (P.zu[q] - it.z[q]);
+            dphi += g * dz[q];
+        }
+        for (int r = 0; r < mc; ++r) {
+            double g = 0;
+            if (shasL(r)) g -= mu / (it.s[r] - cL(r));
+            if (shasU(r)) g += mu / (cU(r) - it.s[r]);
+            dphi += g * ds[r] + (rho - mu / it.e1[r]) * de1[r] + (rho - mu / it.e2[r]) * de2[r];
+        }
+        const double phi0_base = barrier_merit(it.z, it.s, it.e1, it.e2, E, mu, 0.0, &infeas0);
+        if (infeas0 > 0) {
+            const double need = dphi / (0.9 * infeas0);
+            if (nu < need) nu = need + 1.0;
+        }
+        double mmax = 0;
+        for (int r = 0; r < md; ++r) mmax = std::max(mmax, std::fabs(it.lam[r] + dlam[r]));
+        for (int r = 0; r < mc; ++r) mmax = std::max(mmax, std::fabs(it.y[r] + dy[r]));
+        nu = std::max(nu, std::min(1.1 * mmax, 1e8));
+        const double phi0 = phi0_base + nu * infeas0;
+        const double slope = dphi - nu * infeas0;
+        // backtracking
+        double alpha = apr;
+        bool accepted = false;
+        for (int ls = 0; ls < 40; ++ls) {
+            for (int q = 0; q < nz; ++q) zt[q] = it.z[q] + alpha * dz[q];
+            for (int r = 0; r < mc; ++r) {
+                st[r] = it.s[r] + alpha * ds[r];
+                e1t[r] = it.e1[r] + alpha * de1[r];
+                e2t[r] = it.e2[r] + alpha * de2[r];
+            }
+            if (!evaluate(zt, Et, false)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
+            // slack reset: a row's slack may jump to the value that closes its residual whenever
+            // that lowers the merit function (the keep-out rows are strongly curved, and a step
+            // along a keep-out boundary otherwise shows up as an equality residual c - s)
+            for (int r = 0; r < mc; ++r) {
+                const double target = Et.RES[(size_t)md + r] - e1t[r] + e2t[r];
+                const double lo = shasL(r) ? cL(r) : -INF_BOUND, hi = shasU(r) ? cU(r) : INF_BOUND;
+                if (!(target > lo) || !(target < hi)) continue;
+                double keep = nu * std::fabs(target - st[r]), take = 0.0;
+                if (shasL(r)) { keep -= mu * std::log(st[r] - lo); take -= mu * std::log(target - lo); }
+                if (shasU(r)) { keep -= mu * std::log(hi - st[r]); take -= mu * std::log(hi - target); }
+                if (take < keep) st[r] = target;
+            }
+            const double phit = barrier_merit(zt, st, e1t, e2t, Et, mu, nu, nullptr);
+            if (std::isfinite(phit) && phit <= phi0 + 1e-4 * alpha * std::min(slope, 0.0) + 1e-13 * std::fabs(phi0)) {
+                accepted = true;
+                break;
+            }
+            alpha *= 0.5;
+        }
+        if (opt.print_level >= 6)
+            printf("          apr %.3e  alpha %.3e  adu %.3e  dphi %.3e  infeas1 %.3e  slope %.3e\n", apr, alpha, adu, dphi,
+                   infeas0, slope);
+        if (!accepted) {
+            R.msg = "line search failed";
+            if (err0 <= 1e3 * opt.tol && emax <= 1e-6) { R.ok = true; R.msg = "converged to acceptable level (line search at round-off)"; }
+            break;
+        }
+        // accept
+        it.z = zt;
+        it.s = st;
+        it.e1 = e1t;
+        it.e2 = e2t;
+        auto clampm = [&](double m, double g) { return std::max(std::min(m, kappa_sigma * mu / g), mu / (kappa_sigma * g)); };
+        for (int r = 0; r < md; ++r) it.lam[r] += alpha * dlam[r];
+        for (int r = 0; r < mc; ++r) {
+            it.y[r] += alpha * dy[r];
+            it.vL[r] += adu * dvL[r];
+            it.vU[r] += adu * dvU[r];
+            it.w1[r] += adu * dw1[r];
+            it.w2[r] += adu * dw2[r];
+            if (shasL(r)) it.vL[r] = clampm(it.vL[r], it.s[r] - cL(r));
+            if (shasU(r)) it.vU[r] = clampm(it.vU[r], cU(r) - it.s[r]);
+            it.w1[r] = clampm(it.w1[r], it.e1[r]);
+            it.w2[r] = clampm(it.w2[r], it.e2[r]);
+        }
+        for (int q = 0; q < nz; ++q) {
+            if (fidx[q] < 0) continue;
+            it.zL[q] += adu * dzL[q];
+            it.zU[q] += adu * dzU[q];
+            if (hasL(q)) it.zL[q] = clampm(it.zL[q], it.z[q] - P.zl[q]);
+            if (hasU(q)) it.zU[q] = clampm(it.zU[q], P.zu[q] - it.z[q]);
+        }
+        if (!evaluate(it.z, E, true)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
+        grad_and_jt(it);
+    }
+    R.cost = E.cost;
+    R.z = it.z;
+    R.lamF = it.lam;
+    R.lamC.resize(mc);
+    for (int r = 0; r < mc; ++r) R.lamC[r] = sig[r / M] * it.y[r];
+    return R;
+}
+
+}  // namespace mi355x
+}  // namespace ETOL

@@ -1,0 +1,79 @@
+// emi_nlp.hpp -- the NLP iteration behind eMI355X::solve().
+//
+// ePSOPT hands the transcribed problem to IPOPT with ADOL-C derivatives and an
+// exact Hessian (reference src/ePSOPT/ePSOPT.cpp:62-66, 84).  Neither exists
+// here, so eMI355X owns the iteration: a primal-dual interior-point method
+// (log barrier on variable and path-row bounds, Newton steps on the perturbed
+// KKT system with inertia-correcting regularisation, l1-merit backtracking line
+// search, Fiacco-McCormick barrier schedule).  Every function/Jacobian/Hessian
+// value comes from the device through an NlpEvaluator; the linear algebra of
+// the step (a dense symmetric-indefinite factorisation of the reduced KKT
+// matrix) runs on the host and is sized for the shipped resource/configs
+// problems.  SURVEY.md section 8f ranks a structured device-side KKT solve as
+// the next component.
+#ifndef ETOL_MI355X_EMI_NLP_HPP_
+#define ETOL_MI355X_EMI_NLP_HPP_
+
+#include <string>
+#include <vector>
+
+namespace ETOL {
+namespace mi355x {
+
+// Source of all problem functions (layouts of include/emi355x.h, batch of one).
+class NlpEvaluator {
+ public:
+    virtual ~NlpEvaluator() {}
+    // RES[ns+np][M], VALS[nvals][M] (may be NULL when !jac), COST[1]; returns 0 on success
+    virtual int eval(const double* X, const double* U, double* RES, double* VALS, double* COST, bool jac) = 0;
+    // H[nhess][M] packed lower triangles
+    virtual int hess(const double* X, const double* U, const double* lamF, const double* lamC, double sigma,
+                     double* H) = 0;
+    virtual std::string last_error() const { return std::string(); }
+};
+
+struct NlpProblem {
+    int ns = 0, nc = 0, np = 0, M = 0;
+    int px = 0, py = 1;                 // states the path rows depend on
+    std::vector<double> D;              // M*M differentiation matrix (row-major)
+    std::vector<double> zl, zu;         // (ns+nc)*M variable bounds, index v*M+k; zl==zu fixes a variable
+    std::vector<double> cl, cu;         // np path-row bounds (same at every node)
+    std::vector<double> cscale;         // np positive row scalings applied inside the iteration (empty = 1)
+    NlpEvaluator* ev = nullptr;
+};
+
+struct NlpOptions {
+    double tol = 1e-8;                  // scaled KKT error at mu = 0
+    int max_iter = 200;
+    int print_level = 0;
+    double mu_init = 0.1;
+    double bound_push = 1e-2, bound_frac = 1e-2;
+    double max_cpu_time = 1e9;          // seconds
+};
+
+struct NlpResult {
+    bool ok = false;
+    std::string msg;
+    int iterations = 0;
+    int evaluations = 0;
+    double cost = 0, kkt_error = 0, constr_viol = 0;
+    std::vector<double> z;              // (ns+nc)*M solution
+    std::vector<double> lamF, lamC;     // multipliers of the defect and path rows
+};
+
+NlpResult solve_nlp(const NlpProblem& prob, const NlpOptions& opt, const std::vector<double>& z0);
+
+// Dense symmetric-indefinite LDL^T (Bunch-Kaufman partial pivoting), lower
+// triangle of a row-major n*n array, in place.  Exposed for the unit tests.
+struct LdltFactor {
+    int n = 0;
+    std::vector<double> a;
+    std::vector<int> ipiv;
+    int npos = 0, nneg = 0, nzero = 0;
+};
+bool ldlt_factor(LdltFactor& F);                 // false on an exactly singular pivot
+void ldlt_solve(const LdltFactor& F, double* b); // b <- A^{-1} b
+
+}  // namespace mi355x
+}  // namespace ETOL
+#endif

@@ -1,0 +1,24 @@
+// emi_transcribe.hpp -- mi355x::Prob (the transcribed ETOL problem) -> NlpProblem.
+// Split out of eMI355X::solve() so that the unit tests can exercise the NLP
+// iteration on the same problem construction the eSolver uses.
+#ifndef ETOL_MI355X_EMI_TRANSCRIBE_HPP_
+#define ETOL_MI355X_EMI_TRANSCRIBE_HPP_
+
+#include <vector>
+
+#include <ETOL/eMI355X.hpp>
+
+#include "emi_nlp.hpp"
+
+namespace ETOL {
+namespace mi355x {
+
+// Variable bounds per node (state/control boxes intersected with the event
+// bounds at the first and last node), path-row bounds, mesh.
+NlpProblem make_nlp(const Prob& P, NlpEvaluator* ev);
+// zeros unless Prob::guess_* were pre-filled (reference ePSOPT.cpp:47-56)
+std::vector<double> initial_guess(const Prob& P);
+
+}  // namespace mi355x
+}  // namespace ETOL
+#endif

@@ -1,0 +1,99 @@
+// eMI355X.hpp -- MI355X-native collocation eSolver: a peer of ePSOPT / eGLPK / eGurobi.
+//
+// Same role and shape as ETOL::ePSOPT (reference include/ETOL/ePSOPT.hpp:20-163,
+// src/ePSOPT/ePSOPT.cpp): derives from TrajectoryOptimizer, overrides
+// setup/solve/debug/close, exposes its knobs and results through
+// getAlgorithm()/getSolution()/getProblem().  Where ePSOPT delegates to
+// PSOPT + ADOL-C + IPOPT on the CPU, eMI355X owns mesh, defect, derivative
+// evaluation and the NLP iteration, with every per-node evaluation on the GPU
+// behind the C ABI of include/emi355x.h.
+#ifndef ETOL_MI355X_EMI355X_HPP_
+#define ETOL_MI355X_EMI355X_HPP_
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <ETOL/TrajectoryOptimizer.hpp>
+#include <ETOL/eMI355X_Types.hpp>
+
+namespace ETOL {
+
+namespace mi355x {
+
+// Algorithm knobs (the fields of PSOPT's Alg that ePSOPT::setup sets,
+// reference src/ePSOPT/ePSOPT.cpp:62-72, plus device selection).
+struct Alg {
+    std::string nlp_method = "interior-point (eMI355X)";
+    std::string derivatives = "analytic (device kernels)";
+    std::string hessian = "exact";
+    std::string collocation_method = "Legendre";   // Legendre-Gauss-Lobatto, as PSOPT's "Legendre"
+    std::string mesh_refinement = "none";          // fixed grid of nSteps+1 nodes
+    int nlp_iter_max = 200;
+    double nlp_tolerance = 1.e-6;
+    double max_cpu_time = 1.e9;
+    int print_level = 0;
+    int device = 0;                                 // HIP device ordinal
+};
+
+struct Sol {
+    int error_flag = 0;
+    std::string error_msg;
+    double cost = 0;
+    int nlp_iterations = 0;
+    int evaluations = 0;
+    double kkt_error = 0, constraint_violation = 0;
+    size_t nstates = 0, ncontrols = 0, nodes = 0;
+    std::vector<double> states;     // [nstates][nodes]
+    std::vector<double> controls;   // [ncontrols][nodes]
+    std::vector<double> time;       // [nodes]  LGL times h (tau_k + 1)
+};
+
+// The transcribed problem (what ePSOPT keeps in PSOPT's Prob).
+struct Prob {
+    std::string name = "ETOL Problem";
+    size_t nstates = 0, ncontrols = 0, nodes = 0, npath = 0;
+    int model = -1;
+    std::vector<double> model_params;
+    double t0 = 0, tf = 0;
+    std::vector<double> tau, w, D;                 // LGL mesh
+    std::vector<double> path_records;              // [npath][EMI_PATH_REC]
+    std::vector<double> track_x, track_y;          // [ntracks][nodes]
+    size_t ntracks = 0, px = 0, py = 1;
+    std::vector<double> state_lower, state_upper, control_lower, control_upper;
+    std::vector<double> path_lower, path_upper;
+    std::vector<double> event_lower, event_upper;  // [2*nstates]: x(t0) then x(tf)
+    std::vector<double> guess_states, guess_controls;   // optional warm start, [n][nodes]
+};
+
+}  // namespace mi355x
+
+class eMI355X : public TrajectoryOptimizer {
+ public:
+    eMI355X();
+    virtual ~eMI355X();
+
+    void setup();    // ETOL configuration -> transcribed NLP on the device
+    void solve();    // NLP iteration; fills score and trajectories on success
+    void debug();    // per-iteration log (print_level 5), call after setup()
+    void close();    // releases the device context
+
+    mi355x::Alg* getAlgorithm();
+    mi355x::Sol* getSolution();
+    mi355x::Prob* getProblem();
+
+ protected:
+    mi355x::Alg _algorithm;
+    mi355x::Sol _solution;
+    mi355x::Prob _problem;
+
+ private:
+    struct Device;                       // emi_ctx_t + NlpEvaluator adapter
+    std::unique_ptr<Device> _dev;
+    void traceCallbacks();               // calls every f_t once (see eMI355X_Types.hpp)
+    void addBounds();
+    void getTraj();
+};
+
+}  // namespace ETOL
+#endif

@@ -1,0 +1,271 @@
+// etol_harness.cpp -- extern "C" shim that lets the Python tests drive the C++ host
+// library (ETOL::TrajectoryOptimizer base + ETOL::eMI355X).  Test infrastructure.
+#include <ETOL/eMI355X.hpp>
+
+#include <cstring>
+#include <sstream>
+#include <string>
+
+#include <dlfcn.h>
+
+#include "emi_nlp.hpp"
+#include "emi_transcribe.hpp"
+
+namespace mx = ETOL::mi355x;
+
+namespace {
+
+std::string g_out;
+
+// a TrajectoryOptimizer that can be instantiated without a GPU (for the loader tests)
+class Plain : public ETOL::TrajectoryOptimizer {
+ public:
+    void setup() override {}
+    void solve() override {}
+    void debug() override {}
+    void close() override {}
+    ETOL::paramset_t& params() { return _parameters; }
+};
+
+template <class V> void arr(std::ostringstream& o, const char* key, const V& v, bool last = false) {
+    o << "\"" << key << "\":[";
+    bool first = true;
+    for (auto e : v) { o << (first ? "" : ",") << e; first = false; }
+    o << "]" << (last ? "" : ",");
+}
+
+void dump_configs(ETOL::TrajectoryOptimizer& t, std::ostringstream& o) {
+    o.precision(17);
+    o << "{\"nsteps\":" << t.getNSteps() << ",\"dt\":" << t.getDt() << ",\"nstates\":" << t.getNStates()
+      << ",\"ncontrols\":" << t.getNControls() << ",\"xrhorizon\":" << t.getXrhorizon() << ",\"urhorizon\":"
+      << t.getUrhorizon() << ",\"rhorizon\":" << t.getRhorizon() << ",";
+    arr(o, "xlower", t.getXlower()); arr(o, "xupper", t.getXupper()); arr(o, "x0", t.getX0());
+    arr(o, "xf", t.getXf()); arr(o, "xtol", t.getXtol()); arr(o, "ulower", t.getUlower()); arr(o, "uupper", t.getUupper());
+    std::vector<int> xv, uv;
+    for (auto v : t.getXvartype()) xv.push_back((int)v);
+    for (auto v : t.getUvartype()) uv.push_back((int)v);
+    arr(o, "xvartype", xv); arr(o, "uvartype", uv);
+    o << "\"nexclzones\":" << t.getNExclZones() << ",\"zones\":[";
+    bool fz = true;
+    for (const auto& b : *t.getObstacles_Raw()) {
+        o << (fz ? "" : ",") << "["; fz = false;
+        bool fc = true;
+        for (const auto& c : b) { o << (fc ? "" : ",") << "[" << c[0] << "," << c[1] << "," << c[2] << "]"; fc = false; }
+        o << "]";
+    }
+    o << "],\"tracks\":[";
+    bool ft = true;
+    for (const auto& tr : *t.getTracks()) {
+        o << (ft ? "" : ",") << "{\"radius\":" << tr.radius << ",\"waypoints\":["; ft = false;
+        bool fw = true;
+        for (const auto& w : tr.trajectory) {
+            o << (fw ? "" : ",") << "[" << w.first; fw = false;
+            for (double d : w.second) o << "," << d;
+            o << "]";
+        }
+        o << "]}";
+    }
+    o << "]}";
+}
+
+// the example-1 problem on an eMI355X, optionally without keep-outs
+struct Ex1 {
+    ETOL::eMI355X solver;
+    ETOL::f_t obj, xdot, ydot, obs, saa;
+};
+
+}  // namespace
+
+// ---- the NLP iteration on the CPU oracle (solver-logic tests only; never the product path) ----
+namespace {
+typedef int (*orc_eval_t)(int, const double*, int, int, int, const double*, const double*, const double*, double, double,
+                          int, int, const double*, int, int, int, int, const double*, const double*, const double*,
+                          const double*, double*, double*, double*);
+typedef int (*orc_hess_t)(int, const double*, int, int, int, const double*, double, double, int, int, const double*, int,
+                          int, int, int, const double*, const double*, const double*, const double*, const double*,
+                          const double*, double, double*);
+struct OracleEval : public mx::NlpEvaluator {
+    const mx::Prob* P = nullptr;
+    orc_eval_t ev = nullptr;
+    orc_hess_t hs = nullptr;
+    std::vector<double> vals;
+    int eval(const double* X, const double* U, double* RES, double* VALS, double* COST, bool jac) override {
+        return ev(P->model, P->model_params.data(), 0, (int)P->nodes, 1, P->tau.data(), P->w.data(), P->D.data(), P->t0,
+                  P->tf, (int)P->npath, 1, P->path_records.data(), (int)P->px, (int)P->py, (int)P->ntracks, 1,
+                  P->track_x.data(), P->track_y.data(), X, U, RES, jac ? VALS : nullptr, COST);
+    }
+    int hess(const double* X, const double* U, const double* lamF, const double* lamC, double sigma, double* H) override {
+        return hs(P->model, P->model_params.data(), 0, (int)P->nodes, 1, P->w.data(), P->t0, P->tf, (int)P->npath, 1,
+                  P->path_records.data(), (int)P->px, (int)P->py, (int)P->ntracks, 1, P->track_x.data(),
+                  P->track_y.data(), X, U, lamF, lamC, sigma, H);
+    }
+};
+}  // namespace
+
+extern "C" int harness_solve_example1_oracle(const char* xml, const char* oracle_so, int with_obstacles, double tol,
+                                             int print_level, int max_iter, double* cost, int* M, double* X, double* U,
+                                             int cap, int* iters) {
+    void* h = dlopen(oracle_so, RTLD_NOW);
+    if (!h) { g_out = dlerror(); return 3; }
+    OracleEval oe;
+    oe.ev = (orc_eval_t)dlsym(h, "orc_eval");
+    oe.hs = (orc_hess_t)dlsym(h, "orc_hess");
+    Plain t;
+    t.loadConfigs(xml);
+    mx::Prob P;
+    P.nstates = 2; P.ncontrols = 2; P.nodes = t.getNSteps() + 1; P.t0 = 0; P.tf = t.getNSteps() * t.getDt();
+    P.model = EMI_MODEL_POINTMASS2D;
+    P.tau.resize(P.nodes); P.w.resize(P.nodes); P.D.resize(P.nodes * P.nodes);
+    emi_lgl((int)P.nodes, P.tau.data(), P.w.data(), P.D.data());
+    std::vector<double> node_t(P.nodes);
+    for (size_t k = 0; k < P.nodes; ++k) node_t[k] = P.tf / 2.0 * (P.tau[k] + 1.0);
+    if (with_obstacles) {
+        for (const auto& poly : *t.getObstacles_Raw())
+            for (auto a = poly.begin(); a != poly.end(); ++a) {
+                auto b = std::next(a);
+                if (b == poly.end()) b = poly.begin();
+                double rec[8];
+                emi_edge_ellipse((*a)[0], (*a)[1], (*b)[0], (*b)[1], rec);
+                P.path_records.insert(P.path_records.end(), rec, rec + 8);
+            }
+        for (const auto& trk : *t.getTracks()) {
+            std::vector<double> tt, xx, yy, xc(P.nodes), yc(P.nodes);
+            for (const auto& wp : trk.trajectory) { tt.push_back(wp.first); xx.push_back(wp.second[0]); yy.push_back(wp.second[1]); }
+            emi_track_centres((int)tt.size(), tt.data(), xx.data(), yy.data(), (int)P.nodes, node_t.data(), xc.data(), yc.data());
+            P.track_x.insert(P.track_x.end(), xc.begin(), xc.end());
+            P.track_y.insert(P.track_y.end(), yc.begin(), yc.end());
+            double rec[8] = {(double)EMI_PATH_TRACK, (double)P.ntracks++, trk.radius * trk.radius, 0, 0, 0, 0, 0};
+            P.path_records.insert(P.path_records.end(), rec, rec + 8);
+        }
+    }
+    P.npath = P.path_records.size() / 8;
+    P.state_lower = t.getXlower(); P.state_upper = t.getXupper();
+    P.control_lower = t.getUlower(); P.control_upper = t.getUupper();
+    for (int i = 0; i < 2; ++i) { P.event_lower.push_back(t.getX0()[i]); P.event_upper.push_back(t.getX0()[i]); }
+    for (int i = 0; i < 2; ++i) { P.event_lower.push_back(t.getXf()[i] - t.getXtol()[i]); P.event_upper.push_back(t.getXf()[i] + t.getXtol()[i]); }
+    P.path_lower.assign(P.npath, -1000.0); P.path_upper.assign(P.npath, 0.0);
+    oe.P = &P;
+    mx::NlpProblem nlp = mx::make_nlp(P, &oe);
+    mx::NlpOptions opt;
+    opt.tol = tol; opt.print_level = print_level; opt.max_iter = max_iter;
+    mx::NlpResult r = mx::solve_nlp(nlp, opt, mx::initial_guess(P));
+    *iters = r.iterations;
+    g_out = r.msg;
+    if (!r.ok) { dlclose(h); return 1; }
+    const int m = (int)P.nodes;
+    if (m > cap) { dlclose(h); return 2; }
+    *M = m; *cost = r.cost;
+    for (int i = 0; i < 2 * m; ++i) { X[i] = r.z[i]; U[i] = r.z[2 * m + i]; }
+    dlclose(h);
+    return 0;
+}
+
+extern "C" {
+
+// parsed configuration of an XML file as JSON
+const char* harness_load_configs(const char* xml) {
+    Plain p;
+    p.loadConfigs(xml);
+    std::ostringstream o;
+    dump_configs(p, o);
+    g_out = o.str();
+    return g_out.c_str();
+}
+
+// load -> saveConfigs -> load again; JSON of the second load
+const char* harness_roundtrip_configs(const char* xml, const char* tmp_xml) {
+    Plain p;
+    p.loadConfigs(xml);
+    p.saveConfigs(tmp_xml);
+    Plain q;
+    q.loadConfigs(tmp_xml);
+    std::ostringstream o;
+    dump_configs(q, o);
+    g_out = o.str();
+    return g_out.c_str();
+}
+
+// CSV writer: writes a 3-row 2-column trajectory to `path`, returns the name used
+const char* harness_save_csv(const char* path) {
+    ETOL::traj_t tr = {{0.0, {1.0, 2.5}}, {0.5, {1.25, -3.0}}, {1.0, {1e-7, 4.0}}};
+    g_out = ETOL::TrajectoryOptimizer::save(&tr, path);
+    return g_out.c_str();
+}
+
+// template helpers: linear_interpolation at n points
+void harness_lin_interp(int n, const double* t, int nt, const double* tv, const double* ref, double* out) {
+    ETOL::state_t a(tv, tv + nt), b(ref, ref + nt);
+    for (int i = 0; i < n; ++i) out[i] = ETOL::TrajectoryOptimizer::linear_interpolation<double>(t[i], a, b);
+}
+
+// dense LDL^T: factor + solve + inertia, for the unit test of the KKT factorisation
+int harness_ldlt(int n, const double* A, double* b, int* inertia) {
+    mx::LdltFactor F;
+    F.n = n;
+    F.a.assign(A, A + (size_t)n * n);
+    const bool ok = mx::ldlt_factor(F);
+    mx::ldlt_solve(F, b);
+    inertia[0] = F.npos; inertia[1] = F.nneg; inertia[2] = F.nzero;
+    return ok ? 0 : 1;
+}
+
+// Solve example 1 on the GPU.  with_obstacles=0 drops both constraint groups
+// (the analytic-optimum case).  Outputs: cost, M, then X[2][M], U[2][M], t[M].
+int harness_solve_example1(const char* xml, int with_obstacles, double tol, int print_level, double* cost, int* M,
+                           double* X, double* U, double* T, int cap, int* iters) {
+    Ex1 e;
+    ETOL::TrajectoryOptimizer* t = &e.solver;
+    t->loadConfigs(xml);
+    t->setMaximize(false);
+    e.obj = [](F_ARGS) -> ETOL::scalar_t { return mx::objective(EMI_MODEL_POINTMASS2D); };
+    e.xdot = [](F_ARGS) -> ETOL::scalar_t { return mx::derivative(EMI_MODEL_POINTMASS2D, 0); };
+    e.ydot = [](F_ARGS) -> ETOL::scalar_t { return mx::derivative(EMI_MODEL_POINTMASS2D, 1); };
+    t->setObjective(&e.obj);
+    t->setGradient({&e.xdot, &e.ydot});
+    if (with_obstacles) {
+        const double tspan = t->getDt() * t->getNSteps();
+        const std::vector<ETOL::border_t>* zones = t->getObstacles_Raw();
+        size_t i = 0;
+        for (const auto& z : *zones) {
+            for (size_t j = 0; j < z.size(); ++j)
+                t->addParams({std::pair<PARAM_PAIR>("side_" + std::to_string(i) + "_" + std::to_string(j) + "_0",
+                                                    {ETOL::var_t::CONTINUOUS, -1000., 0., 0., tspan})});
+            ++i;
+        }
+        const std::list<ETOL::track_t>* tracks = t->getTracks();
+        for (size_t k = 0; k < tracks->size(); ++k)
+            t->addParams({std::pair<PARAM_PAIR>("ball_" + std::to_string(k) + "_0_0",
+                                                {ETOL::var_t::CONTINUOUS, -1000., 0., 0., tspan})});
+        e.obs = [zones](F_ARGS) -> ETOL::scalar_t {
+            return mx::ellipse_rows(*zones, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+        };
+        e.saa = [tracks](F_ARGS) -> ETOL::scalar_t {
+            return mx::track_rows(*tracks, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+        };
+        t->setConstraints({&e.obs, &e.saa});
+    }
+    t->setup();
+    e.solver.getAlgorithm()->nlp_tolerance = tol;
+    e.solver.getAlgorithm()->print_level = print_level;
+    t->solve();
+    const mx::Sol* s = e.solver.getSolution();
+    *iters = s->nlp_iterations;
+    if (s->error_flag) { g_out = s->error_msg; return 1; }
+    const int m = (int)s->nodes;
+    if (m > cap) return 2;
+    *M = m;
+    *cost = t->getScore();
+    // read back through the public trajectory API
+    const ETOL::traj_t* xt = t->getXtraj();
+    const ETOL::traj_t* ut = t->getUtraj();
+    for (int k = 0; k < m; ++k) {
+        T[k] = (*xt)[k].first;
+        for (int i = 0; i < 2; ++i) { X[i * m + k] = (*xt)[k].second[i]; U[i * m + k] = (*ut)[k].second[i]; }
+    }
+    t->close();
+    return 0;
+}
+
+const char* harness_last_message(void) { return g_out.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+"""The C-ABI library loads and exports every symbol include/emi355x.h declares; host-only entry
+points (mesh construction, keep-out constants) agree with the golden fixtures.  No GPU needed."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_every_declared_symbol_is_exported(built):
+    import etol_amd._lib as L
+    hdr = open(os.path.join(ROOT, "include", "emi355x.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(emi_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
+    lib = L.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.emi_abi_version() == 1
+    assert lib.emi_status_string(0) == b"ok"
+    assert b"argument" in lib.emi_status_string(1)
+
+
+def test_no_device_is_an_error_not_a_fallback(built):
+    """On a box without a GPU, creating a context must fail loudly (there is no CPU path)."""
+    import torch
+    import etol_amd as E
+    if torch.cuda.is_available():
+        return
+    try:
+        E.Evaluator(0)
+    except E.EmiError as e:
+        assert "NO_DEVICE" in str(e)
+    else:
+        raise AssertionError("Evaluator() succeeded without a GPU")
+
+
+def test_lgl_against_golden(built):
+    import etol_amd as E
+    g = json.load(open(os.path.join(GOLD, "lgl.json")))
+    for M in (3, 4, 5, 9, 33):
+        tau, w, D = E.lgl(M)
+        ref = g[str(M)]
+        assert np.abs(tau - ref["tau"]).max() < 2e-16
+        assert np.abs(w - ref["w"]).max() < 1e-15
+        Dr = np.array(ref["D"])
+        # off-diagonal entries to rounding; the diagonal is the negative row sum (~1e-13 at M=33)
+        off = ~np.eye(M, dtype=bool)
+        assert (np.abs(D - Dr)[off] / np.abs(Dr)[off]).max() < 1e-14
+        assert np.abs(np.diag(D) - np.diag(Dr)).max() < 1e-12 * M * M
+    tau, w, D = E.lgl(256)
+    ref = g["256"]
+    assert np.abs(tau - ref["tau"]).max() < 2e-16 and np.abs(w - ref["w"]).max() < 1e-15
+    for r, row in zip(ref["rows"], ref["D_rows"]):
+        row = np.array(row)
+        m = np.arange(256) != r
+        assert (np.abs(D[r] - row)[m] / np.abs(row)[m]).max() < 1e-13
+    c3 = g["closed"]["3"]
+    tau, w, D = E.lgl(3)
+    assert np.allclose(tau, c3["tau"], atol=0) and np.allclose(w, c3["w"], rtol=1e-16) and np.allclose(D, c3["D"], atol=1e-16)
+    assert E.lgl(2)[2].tolist() == [[-0.5, 0.5], [-0.5, 0.5]]
+
+
+def test_lgl_invariants(built):
+    import etol_amd as E
+    for M in (2, 3, 8, 33, 256, 1024):
+        tau, w, D = E.lgl(M)
+        N = M - 1
+        assert abs(w.sum() - 2.0) < 1e-14
+        assert np.all(np.diff(tau) > 0) and tau[0] == -1 and tau[-1] == 1
+        assert np.array_equal(tau, -tau[::-1])                     # symmetric node set
+        assert np.abs(D.sum(1)).max() < 1e-9 * max(1, N * N / 1e3)  # D annihilates constants
+        assert np.abs(D + D[::-1, ::-1]).max() < 1e-9 * N * N      # centro-antisymmetry
+        for p in range(1, min(N, 6) + 1):                          # exact on low-degree polynomials
+            assert np.abs(D @ tau ** p - p * tau ** (p - 1)).max() < 2e-9 * max(1.0, N * N / 1e4)
+        for p in range(0, min(2 * N - 1, 9) + 1):                  # Lobatto quadrature exact to degree 2N-1
+            exact = 0.0 if p % 2 else 2.0 / (p + 1)
+            assert abs(w @ tau ** p - exact) < 1e-14
+    # the product mesh and the oracle's independent construction agree
+    for M in (5, 64, 1024):
+        a, b = E.lgl(M), O.lgl(M)
+        assert np.abs(a[0] - b[0]).max() < 3e-16 and np.abs(a[1] - b[1]).max() < 1e-15
+        assert np.abs(a[2] - b[2]).max() < 1e-9
+
+
+def test_model_dims_and_errors(built):
+    import etol_amd as E
+    assert E.model_dims(E.MODEL_POINTMASS2D) == (2, 2, 0)
+    assert E.model_dims(E.MODEL_QUADROTOR2D) == (6, 2, 5)
+    assert E.model_dims(E.MODEL_FIXEDWING12) == (12, 4, 16)
+    lib = E.load()
+    assert lib.emi_model_dims(77, None, None, None) == 1
+    assert lib.emi_lgl(1, None, None, None) == 1
+
+
+def test_edge_ellipse_matches_oracle_and_reference_partials(built):
+    import etol_amd as E
+    import cases
+    for poly in cases.OCP2D["exz"]:
+        n = len(poly)
+        for i in range(n):
+            (xa, ya), (xb, yb) = poly[i], poly[(i + 1) % n]
+            rec, ref = E.edge_ellipse(xa, ya, xb, yb), O.edge_ellipse(xa, ya, xb, yb)
+            assert np.array_equal(rec, ref)
+            # centre is the edge midpoint, a^2 the squared half length, b^2 = a^2/5
+            assert abs(rec[1] - (xa + xb) / 2) < 1e-15 and abs(rec[2] - (ya + yb) / 2) < 1e-13  # slope form, as the reference
+            assert abs(rec[5] - ((xb - xa) ** 2 + (yb - ya) ** 2) / 4) < 1e-13 and rec[6] == 0.2 * rec[5]
+            assert abs(rec[3] ** 2 + rec[4] ** 2 - 1) < 1e-15
+    # a vertical edge divides by zero exactly like the reference (etol_psopt_example1.cpp:169)
+    assert np.isnan(E.edge_ellipse(1.0, 0.0, 1.0, 2.0)[2])
+
+
+def test_track_centres(built):
+    import etol_amd as E
+    t, x, y = [0.0, 4.0, 10.0], [1.0, 3.0, 3.0], [0.0, -1.0, 2.0]
+    q = np.array([-1.0, 0.0, 2.0, 4.0, 7.0, 10.0, 12.0])
+    xc, yc = E.track_centres(t, x, y, q)
+    oxc, oyc = O.track_centres(t, x, y, q)
+    assert np.array_equal(xc, oxc) and np.array_equal(yc, oyc)
+    # inside the table it is plain linear interpolation; outside, the end segments extrapolate
+    assert np.allclose(xc[1:6], np.interp(q[1:6], t, x)) and np.allclose(yc[1:6], np.interp(q[1:6], t, y))
+    assert np.isclose(xc[0], 0.5) and np.isclose(yc[0], 0.25) and np.isclose(yc[6], 3.0)

@@ -1,0 +1,78 @@
+"""eMI355X::setup()/solve() on the GPU through the C++ host library.  -m gpu"""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+XML = os.path.join(GOLD, "ocp_2d_ex1.xml").encode()
+
+
+@pytest.fixture(scope="module")
+def H(built):
+    import torch  # noqa: F401
+    lib = C.CDLL(os.path.join(ROOT, "tests", "harness", "libetol_harness.so"))
+    D = C.POINTER(C.c_double)
+    lib.harness_solve_example1.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, D, C.POINTER(C.c_int), D, D, D,
+                                           C.c_int, C.POINTER(C.c_int)]
+    lib.harness_last_message.restype = C.c_char_p
+    return lib
+
+
+def solve(H, with_obstacles, tol=1e-9):
+    cap = 64
+    X, U, T = np.zeros((2, cap)), np.zeros((2, cap)), np.zeros(cap)
+    cost, M, iters = C.c_double(), C.c_int(), C.c_int()
+    D = C.POINTER(C.c_double)
+    rc = H.harness_solve_example1(XML, with_obstacles, tol, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D),
+                                  U.ctypes.data_as(D), T.ctypes.data_as(D), cap, C.byref(iters))
+    assert rc == 0, H.harness_last_message().decode()
+    m = M.value
+    return cost.value, X.reshape(-1)[:2 * m].reshape(2, m), U.reshape(-1)[:2 * m].reshape(2, m), T[:m], iters.value
+
+
+def test_obstacle_free_problem_reaches_the_analytic_optimum(H):
+    """north_star tolerance: trajectories within 1e-6 relative of the known optimum."""
+    g = json.load(open(os.path.join(GOLD, "ocp2d.json")))
+    cost, X, U, T, iters = solve(H, 0)
+    assert X.shape[1] == 33 and iters < 60
+    assert abs(cost - g["cost"]) < 1e-6 * g["cost"]
+    assert np.abs(U[0] - g["u"][0]).max() < 1e-6 and np.abs(U[1] - g["u"][1]).max() < 1e-6
+    tau = O.lgl(33)[0]
+    assert np.abs(T - 8.0 * (tau + 1)).max() < 1e-13            # LGL times, not k*dt (ePSOPT.cpp:157-182)
+    assert np.abs(X[0] - (1 + g["u"][0] * T)).max() < 1e-6 * 5 and np.abs(X[1] - (2 + g["u"][1] * T)).max() < 1e-6 * 4
+    assert X[0, 0] == 1.0 and X[1, 0] == 2.0                      # hard initial state
+
+
+def test_shipped_problem_with_keepouts_solves_and_is_feasible(H):
+    g = json.load(open(os.path.join(GOLD, "ocp2d.json")))
+    cost, X, U, T, iters = solve(H, 1)
+    assert cost > g["cost"]                                       # the straight line crosses exz1
+    assert cost < 2.0 * g["cost"]
+    # independent feasibility check with the CPU oracle
+    M = 33
+    mesh = O.lgl(M)
+    recs, tx, ty = cases.ocp2d_tables(O.edge_ellipse, O.track_centres, 8.0 * (mesh[0] + 1))
+    RES, _, COST = O.evaluate(0, [], M, mesh, 0.0, 16.0, X[None], U[None], recs, (tx, ty))
+    assert np.abs(RES[0, :2]).max() < 1e-7                        # defects
+    assert RES[0, 2:].max() < 1e-7 and RES[0, 2:].min() > -1000    # path rows within [-1000, 0]
+    assert abs(COST[0] - cost) < 1e-9
+    assert np.all(np.abs(U) <= 0.5 + 1e-9) and np.all(X >= -1e-9) and np.all(X <= 7 + 1e-9)
+    assert abs(X[0, -1] - 5) <= 0.01 + 1e-9 and abs(X[1, -1] - 4) <= 0.01 + 1e-9
+
+
+def test_example_program_runs(built, tmp_path):
+    exe = os.path.join(ROOT, "etol_amd", "lib", "etol_mi355x_example1")
+    r = subprocess.run([exe, XML.decode()], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Minimization Score" in r.stdout and "Graceful Exit" in r.stdout
+    rows = open(tmp_path / "state_mi355x1.csv").read().split("\n")
+    assert rows[0] == "time,traj0,traj1" and len(rows) == 34

@@ -1,0 +1,155 @@
+"""Host C++ library (TrajectoryOptimizer base, loader, writers, KKT factorisation) on the CPU."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def H(built):
+    import torch  # noqa: F401  (one HIP runtime per process: see etol_amd/_lib.py)
+    lib = C.CDLL(os.path.join(ROOT, "tests", "harness", "libetol_harness.so"))
+    lib.harness_load_configs.restype = C.c_char_p
+    lib.harness_load_configs.argtypes = [C.c_char_p]
+    lib.harness_roundtrip_configs.restype = C.c_char_p
+    lib.harness_roundtrip_configs.argtypes = [C.c_char_p, C.c_char_p]
+    lib.harness_save_csv.restype = C.c_char_p
+    lib.harness_save_csv.argtypes = [C.c_char_p]
+    D = C.POINTER(C.c_double)
+    lib.harness_lin_interp.argtypes = [C.c_int, D, C.c_int, D, D, D]
+    lib.harness_ldlt.argtypes = [C.c_int, D, D, C.POINTER(C.c_int)]
+    return lib
+
+
+def load(H, name):
+    return json.loads(H.harness_load_configs(os.path.join(GOLD, name).encode()).decode())
+
+
+def test_load_shipped_ocp(H):
+    c = load(H, "ocp_2d_ex1.xml")
+    assert (c["nsteps"], c["dt"], c["nstates"], c["ncontrols"]) == (32, 0.5, 2, 2)
+    assert c["xrhorizon"] == c["urhorizon"] == c["rhorizon"] == 0
+    assert c["xlower"] == [0, 0] and c["xupper"] == [7, 7] and c["x0"] == [1, 2] and c["xf"] == [5, 4]
+    assert c["xtol"] == [0.01, 0.01] and c["ulower"] == [-0.5, -0.5] and c["uupper"] == [0.5, 0.5]
+    assert c["xvartype"] == [0, 0] and c["uvartype"] == [0, 0]
+    assert [len(z) for z in c["zones"]] == [5, 4]
+    assert c["zones"][0][2] == [3.5, 3.4, 0.0] and c["zones"][1][3] == [2.1, 3.5, 0.0]
+    assert c["nexclzones"] == 0          # convex partition (CGAL) is not part of this build
+    assert [t["radius"] for t in c["tracks"]] == [0.5, 0.5]
+    assert c["tracks"][0]["waypoints"] == [[0, 1.51, 2.0], [32, 2.0, 2.0]]
+    assert c["tracks"][1]["waypoints"] == [[0, 1.0, 4.0], [32, 1.0, 3.0]]
+
+
+def test_load_shipped_mip(H):
+    c = load(H, "mip_2d_ex1.xml")
+    assert (c["nsteps"], c["nstates"], c["ncontrols"], c["xrhorizon"], c["rhorizon"]) == (16, 2, 4, 1, 1)
+    assert c["tracks"][0]["waypoints"][0] == [0, 2.0, 2.0]
+
+
+def test_loader_caps_and_unknown_nodes(H):
+    c = load(H, "edge_caps.xml")
+    assert c["nstates"] == 2 and len(c["xlower"]) == 2          # third <state> beyond nstates is skipped
+    assert c["ncontrols"] == 3 and len(c["ulower"]) == 3
+    assert (c["xrhorizon"], c["urhorizon"], c["rhorizon"]) == (2, 3, 3)
+    assert len(c["zones"]) == 1                                  # nzones=1
+    assert len(c["zones"][0]) == 3                               # ncorners=2 admits size<=2 before push: 3 corners
+    assert len(c["tracks"]) == 1 and c["tracks"][0]["waypoints"] == [[0, 1.51]]   # nwaypoints=1, ndatums=1
+    c = load(H, "edge_no_mex_count.xml")
+    assert c["tracks"] == [] and c["zones"] == []                # <mexzones> without nzones loads nothing
+
+
+def test_save_load_roundtrip(H, tmp_path):
+    a = load(H, "ocp_2d_ex1.xml")
+    b = json.loads(H.harness_roundtrip_configs(os.path.join(GOLD, "ocp_2d_ex1.xml").encode(),
+                                               str(tmp_path / "rt.xml").encode()).decode())
+    assert a == b
+
+
+def test_csv_writer_format_and_no_overwrite(H, tmp_path):
+    p = str(tmp_path / "traj.csv")
+    n1 = H.harness_save_csv(p.encode()).decode()
+    n2 = H.harness_save_csv(p.encode()).decode()
+    n3 = H.harness_save_csv(p.encode()).decode()
+    assert n1 == p and n2.endswith("traj1.csv") and n3.endswith("traj2.csv")
+    txt = open(n1).read()
+    assert txt == "time,traj0,traj1\n0.000000,1.000000,2.500000\n0.500000,1.250000,-3.000000\n1.000000,0.000000,4.000000"
+
+
+def test_linear_interpolation_template(H):
+    tv = np.array([0.0, 4.0, 10.0]); ref = np.array([1.0, 3.0, -3.0])
+    q = np.array([-2.0, 0.0, 1.0, 4.0, 9.0, 10.0, 11.0])
+    out = np.zeros(len(q))
+    D = C.POINTER(C.c_double)
+    H.harness_lin_interp(len(q), q.ctypes.data_as(D), 3, tv.ctypes.data_as(D), ref.ctypes.data_as(D), out.ctypes.data_as(D))
+    oxc, _ = O.track_centres(tv, ref, ref, q)
+    assert np.array_equal(out, oxc)
+    assert np.allclose(out[1:6], np.interp(q[1:6], tv, ref)) and np.isclose(out[0], 0.0) and np.isclose(out[6], -4.0)
+
+
+def test_dense_ldlt_inertia_and_solve(H):
+    rng = np.random.default_rng(7)
+    D = C.POINTER(C.c_double)
+    for n, npos in ((1, 1), (2, 1), (7, 3), (40, 25), (133, 60)):
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        ev = np.concatenate([rng.uniform(0.5, 3, npos), -rng.uniform(0.5, 3, n - npos)])
+        A = (Q * ev) @ Q.T
+        A = (A + A.T) / 2
+        b = rng.standard_normal(n)
+        x = b.copy()
+        inertia = (C.c_int * 3)()
+        assert H.harness_ldlt(n, np.ascontiguousarray(A).ctypes.data_as(D), x.ctypes.data_as(D), inertia) == 0
+        assert list(inertia) == [npos, n - npos, 0]
+        assert np.abs(A @ x - b).max() < 1e-10
+    # KKT-shaped matrix with a zero (2,2) block
+    n, m = 30, 12
+    Hm = rng.standard_normal((n, n)); Hm = Hm @ Hm.T + np.eye(n)
+    J = rng.standard_normal((m, n))
+    K = np.block([[Hm, J.T], [J, np.zeros((m, m))]])
+    b = rng.standard_normal(n + m); x = b.copy()
+    inertia = (C.c_int * 3)()
+    assert H.harness_ldlt(n + m, np.ascontiguousarray(K).ctypes.data_as(D), x.ctypes.data_as(D), inertia) == 0
+    assert list(inertia) == [n, m, 0] and np.abs(K @ x - b).max() < 1e-9
+
+
+# ---- NLP iteration logic, driven by the CPU oracle as evaluator (test-only plumbing) -----------
+def _solve_with_oracle(H, with_obstacles, tol=1e-9, max_iter=400):
+    D = C.POINTER(C.c_double)
+    H.harness_solve_example1_oracle.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, D,
+                                                C.POINTER(C.c_int), D, D, C.c_int, C.POINTER(C.c_int)]
+    H.harness_last_message.restype = C.c_char_p
+    X, U = np.zeros((2, 64)), np.zeros((2, 64))
+    cost, M, it = C.c_double(), C.c_int(), C.c_int()
+    rc = H.harness_solve_example1_oracle(os.path.join(GOLD, "ocp_2d_ex1.xml").encode(),
+                                         os.path.join(ROOT, "oracle", "liboracle.so").encode(), with_obstacles, tol, 0,
+                                         max_iter, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D),
+                                         64, C.byref(it))
+    assert rc == 0, H.harness_last_message().decode()
+    m = M.value
+    return cost.value, X.reshape(-1)[:2 * m].reshape(2, m), U.reshape(-1)[:2 * m].reshape(2, m), it.value
+
+
+def test_nlp_iteration_reaches_analytic_optimum(H):
+    g = json.load(open(os.path.join(GOLD, "ocp2d.json")))
+    cost, X, U, iters = _solve_with_oracle(H, 0)
+    assert iters < 40 and abs(cost - g["cost"]) < 1e-6 * g["cost"]
+    assert np.abs(U[0] - g["u"][0]).max() < 1e-6 and np.abs(U[1] - g["u"][1]).max() < 1e-6
+
+
+def test_nlp_iteration_with_keepouts_is_feasible_and_stationary(H):
+    import cases
+    g = json.load(open(os.path.join(GOLD, "ocp2d.json")))
+    cost, X, U, iters = _solve_with_oracle(H, 1)
+    assert iters < 200 and g["cost"] < cost < 2 * g["cost"]
+    M = 33
+    mesh = O.lgl(M)
+    recs, tx, ty = cases.ocp2d_tables(O.edge_ellipse, O.track_centres, 8.0 * (mesh[0] + 1))
+    RES, _, COST = O.evaluate(0, [], M, mesh, 0.0, 16.0, X[None], U[None], recs, (tx, ty))
+    assert np.abs(RES[0, :2]).max() < 1e-8 and RES[0, 2:].max() < 1e-8 and abs(COST[0] - cost) < 1e-10
+    assert np.all(np.abs(U) <= 0.5 + 1e-9) and abs(X[0, -1] - 5) <= 0.01 + 1e-9 and abs(X[1, -1] - 4) <= 0.01 + 1e-9
