@@ -72,7 +72,9 @@ SYMBOLS = {
     "emi_timer_start": (C.c_int, [_P]),
     "emi_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "emi_profile_enable": (C.c_int, [_P, C.c_int]),
-    "emi_profile_read": (C.c_int, [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _I]),
+    "emi_profile_read": (C.c_int, [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _I]),
+    "emi_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "emi_last_path": (C.c_int, [_P, _I]),
 }
 
 _lib = None

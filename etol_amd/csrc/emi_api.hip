@@ -7,6 +7,7 @@
 // buffers.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -25,7 +26,7 @@ struct DevBuf {
 
 struct ProfEvents {
     hipEvent_t e[3];
-    bool has_node, has_defect;
+    bool has_node, has_defect, fused;
 };
 
 }  // namespace
@@ -40,7 +41,11 @@ struct emi_ctx_s {
     // mesh
     int M = 0;
     double t0 = 0, tf = 0;
-    DevBuf d_w, d_t, d_Ddiag, d_D;
+    DevBuf d_w, d_t, d_Ddiag, d_D, d_De, d_Do;
+    bool symmetric = false;   // D is exactly centro-antisymmetric and M is even: De/Do are valid
+    bool allow_fused = true;
+    int fused_ablate = 0;
+    bool fused_attr_set = false;
     std::vector<double> h_tau, h_w;
     // model
     int model = -1, ns = 0, nc = 0, maximize = 0;
@@ -215,7 +220,7 @@ int emi_destroy(emi_ctx_t c) {
     if (!c) return EMI_ERR_ARG;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->d_w, &c->d_t, &c->d_Ddiag, &c->d_D, &c->d_path, &c->d_trkx, &c->d_trky,
+    DevBuf* bufs[] = {&c->d_w, &c->d_t, &c->d_Ddiag, &c->d_D, &c->d_De, &c->d_Do, &c->d_path, &c->d_trkx, &c->d_trky,
                       &c->d_cost_part, &c->s_X, &c->s_U, &c->s_RES, &c->s_VALS, &c->s_COST,
                       &c->s_LF, &c->s_LC, &c->s_H};
     for (DevBuf* b : bufs)
@@ -275,6 +280,27 @@ int emi_set_mesh(emi_ctx_t c, int M, const double* tau, const double* w, const d
     if ((st = upload_real(c, c->d_t, nt.data(), M))) return st;
     if ((st = upload_real(c, c->d_Ddiag, dd.data(), M))) return st;
     if ((st = upload_real(c, c->d_D, D, (size_t)M * M))) return st;
+    // even/odd split of D for the fused kernel: valid only for an exactly centro-antisymmetric D
+    c->symmetric = false;
+    if (M % 2 == 0 && !c->f32) {
+        const int N = M - 1, Hh = M / 2;
+        bool sym = true;
+        for (int i = 0; i < M && sym; ++i)
+            for (int j = 0; j < M; ++j)
+                if (D[(size_t)i * M + j] != -D[(size_t)(N - i) * M + (N - j)]) { sym = false; break; }
+        if (sym) {
+            std::vector<double> De((size_t)Hh * Hh), Do((size_t)Hh * Hh);
+            for (int i = 0; i < Hh; ++i)
+                for (int j = 0; j < Hh; ++j) {
+                    const double p = D[(size_t)i * M + j], q = D[(size_t)i * M + (N - j)];
+                    De[(size_t)i * Hh + j] = 0.5 * (p + q);
+                    Do[(size_t)i * Hh + j] = 0.5 * (p - q);
+                }
+            if ((st = upload_real(c, c->d_De, De.data(), De.size()))) return st;
+            if ((st = upload_real(c, c->d_Do, Do.data(), Do.size()))) return st;
+            c->symmetric = true;
+        }
+    }
     c->h_tau.assign(tau, tau + M);
     c->h_w.assign(w, w + M);
     c->M = M;
@@ -306,7 +332,8 @@ int emi_set_batch(emi_ctx_t c, int B) {
     if (c->M <= 0) return fail(c, EMI_ERR_STATE, "emi_set_mesh must precede emi_set_batch");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t rb = c->f32 ? 4 : 8;
-    int st = ensure(c, c->d_cost_part, (size_t)B * emi::node_chunks(c->M) * rb);
+    const int chunks = std::max(emi::node_chunks(c->M), emi::fused_cost_chunks(c->M));
+    int st = ensure(c, c->d_cost_part, (size_t)B * std::max(chunks, 1) * rb);
     if (st) return st;
     c->B = B;
     return EMI_OK;
@@ -427,6 +454,8 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         HIP_TRY(c, emi::defect_f64_set_attr());
         c->attr_set = true;
     }
+    const bool fused = nodes && defect && !c->f32 && c->allow_fused && c->symmetric &&
+                       emi::fused_supported(c->model, c->M);
     ProfEvents* pe = nullptr;
     if (c->profile) {
         if (c->prof_used == c->prof.size()) {
@@ -437,7 +466,29 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         pe = &c->prof[c->prof_used++];
         pe->has_node = nodes;
         pe->has_defect = defect;
+        pe->fused = fused;
         HIP_TRY(c, hipEventRecord(pe->e[0], c->stream));
+    }
+    if (fused) {
+        emi::FusedArgs a;
+        a.X = (const double*)dX; a.U = (const double*)dU; a.RES = (double*)dRES; a.VALS = (double*)dVALS;
+        a.cost_part = (double*)c->d_cost_part.p;
+        a.w = (const double*)c->d_w.p; a.node_t = (const double*)c->d_t.p; a.Ddiag = (const double*)c->d_Ddiag.p;
+        a.De = (const double*)c->d_De.p; a.Do = (const double*)c->d_Do.p;
+        a.path = (const double*)c->d_path.p; a.track_x = (const double*)c->d_trkx.p; a.track_y = (const double*)c->d_trky.p;
+        a.M = c->M; a.B = c->B; a.np = c->np; a.nres = nres_of(c); a.nvals = nvals_of(c);
+        a.path_sets = c->path_sets; a.track_sets = c->track_sets; a.ntracks = c->ntracks; a.px = c->px; a.py = c->py;
+        a.h = (c->tf - c->t0) / 2.0; a.sgn = c->maximize ? -1.0 : 1.0;
+        a.ablate = c->fused_ablate;
+        a.cost_chunks = emi::fused_cost_chunks(c->M);
+        for (int i = 0; i < EMI_MAX_PARAMS; ++i) a.P.p[i] = c->params[i];
+        HIP_TRY(c, emi::launch_fused(c->model, a, jac, c->stream, !c->fused_attr_set));
+        c->fused_attr_set = true;
+        if (pe) HIP_TRY(c, hipEventRecord(pe->e[1], c->stream));
+        HIP_TRY(c, emi::launch_cost_finish<double>((const double*)c->d_cost_part.p, (double*)dCOST, c->B,
+                                                   emi::fused_cost_chunks(c->M), a.sgn * a.h, c->stream));
+        if (pe) HIP_TRY(c, hipEventRecord(pe->e[2], c->stream));
+        return EMI_OK;
     }
     if (nodes) {
         if (c->f32) {
@@ -564,14 +615,20 @@ int emi_profile_enable(emi_ctx_t c, int on) {
 }
 
 int emi_profile_read(emi_ctx_t c, float* node_ms, int* node_launches, float* defect_ms,
-                     int* defect_launches) {
+                     int* defect_launches, float* fused_ms, int* fused_launches) {
     if (!c) return EMI_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    float nm = 0, dm = 0;
-    int nl = 0, dl = 0;
+    float nm = 0, dm = 0, fm = 0;
+    int nl = 0, dl = 0, fl = 0;
     for (size_t i = 0; i < c->prof_used; ++i) {
         ProfEvents& pe = c->prof[i];
         float ms = 0;
+        if (pe.fused) {
+            HIP_TRY(c, hipEventElapsedTime(&ms, pe.e[0], pe.e[1]));
+            fm += ms;
+            ++fl;
+            continue;
+        }
         if (pe.has_node) {
             HIP_TRY(c, hipEventElapsedTime(&ms, pe.e[0], pe.e[1]));
             nm += ms;
@@ -588,6 +645,22 @@ int emi_profile_read(emi_ctx_t c, float* node_ms, int* node_launches, float* def
     if (node_launches) *node_launches = nl;
     if (defect_ms) *defect_ms = dm;
     if (defect_launches) *defect_launches = dl;
+    if (fused_ms) *fused_ms = fm;
+    if (fused_launches) *fused_launches = fl;
+    return EMI_OK;
+}
+
+int emi_set_option(emi_ctx_t c, const char* name, int value) {
+    if (!c || !name) return EMI_ERR_ARG;
+    if (strcmp(name, "fused") == 0) { c->allow_fused = value != 0; return EMI_OK; }
+    if (strcmp(name, "fused_ablate") == 0) { c->fused_ablate = value; return EMI_OK; }   // diagnostics
+    return fail(c, EMI_ERR_ARG, "unknown option '%s'", name);
+}
+
+int emi_last_path(emi_ctx_t c, int* fused) {
+    if (!c || !fused) return EMI_ERR_ARG;
+    *fused = (!c->f32 && c->allow_fused && c->symmetric && c->M > 0 && c->model >= 0 &&
+              emi::fused_supported(c->model, c->M)) ? 1 : 0;
     return EMI_OK;
 }
 

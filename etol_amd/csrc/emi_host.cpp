@@ -90,6 +90,11 @@ int emi_lgl(int M, double* tau, double* w, double* D) {
             }
             D[(size_t)i * M + i] = (double)(-rs);
         }
+        // The node set is symmetric, so D is centro-antisymmetric: D[N-i][N-j] = -D[i][j].
+        // The off-diagonal entries satisfy this bit for bit; make the summed diagonal do so
+        // too (the kernels split D.X into even and odd halves when it holds exactly).
+        for (int i = 0; i < M / 2; ++i) D[(size_t)(N - i) * M + (N - i)] = -D[(size_t)i * M + i];
+        if (M % 2 == 1) D[(size_t)(N / 2) * M + N / 2] = 0.0;
     }
     return EMI_OK;
 }

@@ -504,6 +504,15 @@ static hipError_t launch_nodes_model(const NodeArgs<T>& a, bool jac, hipStream_t
     return hipGetLastError();
 }
 
+template <typename T>
+hipError_t launch_cost_finish(const T* part, T* cost, int B, int nchunks, T scale, hipStream_t s) {
+    hipLaunchKernelGGL((emi_cost_finish_kernel<T>), dim3((B + 255) / 256), dim3(256), 0, s, part, cost, B, nchunks,
+                       scale);
+    return hipGetLastError();
+}
+template hipError_t launch_cost_finish<double>(const double*, double*, int, int, double, hipStream_t);
+template hipError_t launch_cost_finish<float>(const float*, float*, int, int, float, hipStream_t);
+
 int node_chunks(int M) {
     const int per_block = EMI_NODE_THREADS * ((M % 2 == 0) ? 2 : 1);
     return (M + per_block - 1) / per_block;

@@ -184,7 +184,18 @@ class Evaluator:
         self._ck(self.lib.emi_profile_enable(self.ctx, int(on)), "emi_profile_enable")
 
     def profile_read(self):
-        nm, dm = C.c_float(), C.c_float()
-        nl, dl = C.c_int(), C.c_int()
-        self._ck(self.lib.emi_profile_read(self.ctx, C.byref(nm), C.byref(nl), C.byref(dm), C.byref(dl)), "emi_profile_read")
-        return dict(node_ms=nm.value, node_launches=nl.value, defect_ms=dm.value, defect_launches=dl.value)
+        nm, dm, fm = C.c_float(), C.c_float(), C.c_float()
+        nl, dl, fl = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.lib.emi_profile_read(self.ctx, C.byref(nm), C.byref(nl), C.byref(dm), C.byref(dl), C.byref(fm),
+                                           C.byref(fl)), "emi_profile_read")
+        return dict(node_ms=nm.value, node_launches=nl.value, defect_ms=dm.value, defect_launches=dl.value,
+                    fused_ms=fm.value, fused_launches=fl.value)
+
+    def set_option(self, name, value):
+        self._ck(self.lib.emi_set_option(self.ctx, name.encode(), int(value)), "emi_set_option")
+
+    @property
+    def uses_fused_kernel(self):
+        f = C.c_int()
+        self._ck(self.lib.emi_last_path(self.ctx, C.byref(f)), "emi_last_path")
+        return bool(f.value)

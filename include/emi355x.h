@@ -183,7 +183,16 @@ int emi_timer_stop(emi_ctx_t ctx, float* elapsed_ms); /* synchronises */
 /* Per-kernel event brackets inside emi_eval_dev (adds two events/launch).   */
 int emi_profile_enable(emi_ctx_t ctx, int on);
 int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
-                     float* defect_ms, int* defect_launches); /* syncs+resets */
+                     float* defect_ms, int* defect_launches,
+                     float* fused_ms, int* fused_launches); /* syncs+resets */
+
+/* ---- kernel selection ------------------------------------------------------ */
+/* "fused" (default 1): emi_eval with EMI_EVAL_ALL runs the single fused kernel
+ * (emi_fused.hip) when the mesh allows it (f64, M % 128 == 0, centro-
+ * antisymmetric D, 2- or 6-state model); 0 forces the general two-kernel path. */
+int emi_set_option(emi_ctx_t ctx, const char* name, int value);
+/* 1 if emi_eval(EMI_EVAL_ALL) currently takes the fused kernel               */
+int emi_last_path(emi_ctx_t ctx, int* fused);
 
 #ifdef __cplusplus
 }

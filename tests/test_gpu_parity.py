@@ -191,3 +191,38 @@ def test_jac_structure_matches_dense_jacobian(built):
         gfd[q] = (cp - cm) / (2 * d)
     assert np.abs(J - Jfd).max() < 1e-6 * (np.abs(Jfd).max() + 1)
     assert np.abs(g - gfd).max() < 1e-6 * (np.abs(gfd).max() + 1)
+
+
+def test_fused_and_general_kernels_agree(built):
+    """The fused kernel (even/odd MFMA split + interleaved node work) and the general two-kernel
+    path are two implementations of the same pass; also B off the 16-instance tile."""
+    import etol_amd as E
+    for model, M, B, nobs in ((E.MODEL_QUADROTOR2D, 128, 21, 3), (E.MODEL_QUADROTOR2D, 1024, 5, 20),
+                              (E.MODEL_POINTMASS2D, 256, 33, 2)):
+        ev = E.Evaluator(0)
+        ev.set_mesh(M, 0.0, 12.0)
+        if model == E.MODEL_QUADROTOR2D:
+            from etol_amd import workloads as W
+            ev.set_model(model, W.QUAD_PARAMS)
+            X, U, recs = W.quadrotor_batch(9, B, M, nobs)
+        else:
+            from etol_amd import workloads as W
+            ev.set_model(model, [])
+            X, U = W.pointmass_batch(9, B, M)
+            recs = np.zeros((B, nobs, 8)); recs[:, :, 0] = E.PATH_DISC
+            recs[:, :, 1:4] = np.random.default_rng(2).uniform(0.5, 3, (B, nobs, 3))
+        ev.set_batch(B)
+        ev.set_path(recs, 0, 1)
+        assert ev.uses_fused_kernel
+        fused = ev.eval_host(X, U)
+        fused_nojac = ev.eval_host(X, U, flags=E.EVAL_ALL | E.EVAL_NOJAC)
+        ev.set_option("fused", 0)
+        assert not ev.uses_fused_kernel
+        general = ev.eval_host(X, U)
+        ref = O.evaluate(model, W.QUAD_PARAMS if model == E.MODEL_QUADROTOR2D else [], M, (ev.tau, ev.w, ev.D), 0.0,
+                         12.0, X, U, recs)
+        c = dict(X=X, U=U)
+        check(c, ev, fused, ref)
+        check(c, ev, general, ref)
+        assert np.array_equal(fused[1], general[1])            # node work is the same arithmetic
+        assert np.array_equal(fused_nojac[0], fused[0]) and np.array_equal(fused_nojac[2], fused[2])
