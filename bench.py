@@ -26,6 +26,16 @@ HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8.
 FP64_MFMA_PEAK_TF = 78.6                               # MI355X fp64 matrix
 
 
+def load_pmc_traffic():
+    """HBM bytes per launch from the PMC passes of tools/pmc_traffic.sh (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE), if a summary of this round exists."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        return json.load(open(path)).get("bytes_per_launch", {})
+    except (OSError, ValueError):
+        return {}
+
+
 def usable_cores():
     """CPU threads this process may really use (affinity mask and cgroup quota)."""
     n = len(os.sched_getaffinity(0))
@@ -102,10 +112,11 @@ def main():
     ev.set_mesh(M, 0.0, W.TF)
     ev.set_model(E.MODEL_QUADROTOR2D, W.QUAD_PARAMS)
     ev.set_batch(B)
-    if os.environ.get("EMI_ABLATE"):
-        ev.set_option("fused_ablate", int(os.environ["EMI_ABLATE"]))   # diagnostics: results invalid
-    if os.environ.get("EMI_FUSED", "1") == "0":
-        ev.set_option("fused", 0)          # A/B switch: general two-kernel path
+    if os.environ.get("EMI_OVERLAP", "1") == "0":
+        ev.set_option("overlap", 0)        # A/B switch: sequential general path
+    for opt in ("sym_ct", "overlap_mode"):          # experiment knobs of the overlapped path
+        if os.environ.get("EMI_" + opt.upper()):
+            ev.set_option(opt, int(os.environ["EMI_" + opt.upper()]))
     X, U, recs = W.quadrotor_batch(3, B, M, n_obs, first_instance=rank * B)   # scenario s -> rank s // B
     if n_obs:
         ev.set_path(recs, 0, 1)
@@ -153,29 +164,32 @@ def main():
         gather_ms = 1e3 * (time.perf_counter() - tg)
 
     if rank == 0:
+        # ---- roofline of the dominant kernel (longest average launch, HIP events on its own stream)
         key = "c3" if n_obs == 20 else "c2"
-        alg_bytes = (ALG_BYTES[key] if n_obs in (0, 20) else 560 + 24 * n_obs) * B * M
-        flops = 2.0 * M * 6 * B * M
-        if prof["fused_launches"]:
-            # one kernel does the whole pass: HBM-bound (the D.X flops are halved by the even/odd split)
-            fused_ms = prof["fused_ms"] / prof["fused_launches"]
-            ach = alg_bytes / (fused_ms * 1e-3) / 1e9
-            roof = {"kernel": "emi_fused_f64_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": fused_ms,
-                    "mfma_tflops_algorithmic": flops / (fused_ms * 1e-3) / 1e12}
+        per_node = ALG_BYTES[key] if n_obs in (0, 20) else 560 + 24 * n_obs
+        alg_bytes = per_node * B * M                 # SURVEY.md 8d bytes/node-eval x node-evals per launch
+        flops = 2.0 * M * 6 * B * M                  # SURVEY.md 8d D.X flops/node-eval (2*M*ns) x node-evals
+        node_ms = prof["node_ms"] / max(prof["node_launches"], 1)
+        def_ms = prof["defect_ms"] / max(prof["defect_launches"], 1)
+        overlapped = prof["overlapped_passes"] > 0
+        node_name = "emi_nodes_kernel"
+        def_name = "emi_symdefect_f64_kernel" if overlapped else "emi_defect_f64_kernel"
+        traffic = load_pmc_traffic()
+        if node_ms >= def_ms:
+            ach = alg_bytes / (node_ms * 1e-3) / 1e9
+            roof = {"kernel": node_name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(node_name), "avg_ms": node_ms}
         else:
-            node_ms = prof["node_ms"] / max(prof["node_launches"], 1)
-            def_ms = prof["defect_ms"] / max(prof["defect_launches"], 1)
-            if node_ms >= def_ms:
-                ach = alg_bytes / (node_ms * 1e-3) / 1e9
-                roof = {"kernel": "emi_nodes_kernel", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": node_ms}
-            else:
-                ach = flops / (def_ms * 1e-3) / 1e12
-                roof = {"kernel": "emi_defect_f64_kernel", "bound": "mfma", "achieved": ach,
-                        "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF,
-                        "traffic": None, "avg_ms": def_ms}
-            roof["other_kernel_ms"] = {"emi_nodes_kernel": node_ms, "emi_defect_f64_kernel": def_ms}
+            ach = flops / (def_ms * 1e-3) / 1e12
+            roof = {"kernel": def_name, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF,
+                    "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": traffic.get(def_name),
+                    "avg_ms": def_ms}
+        roof["kernels_ms"] = {node_name: node_ms, def_name: def_ms}
+        roof["concurrent"] = overlapped
+        if overlapped:
+            pass_ms = prof["pass_ms"] / prof["overlapped_passes"]
+            roof["pass_ms"] = pass_ms                # fork -> both kernels -> join
+            roof["pass_hbm_frac"] = alg_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         line = {
             "metric": "collocation-node constraint+Jacobian evals/sec, 6-state VGP N=1024",
             "value": value, "unit": "node-evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

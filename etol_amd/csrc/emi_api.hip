@@ -25,7 +25,8 @@ struct DevBuf {
 };
 
 struct ProfEvents {
-    hipEvent_t e[3];
+    hipEvent_t e[3];        // sequential path: e0 | node | e1 | defect | e2 ; overlapped: e0 fork, e1 join
+    hipEvent_t k[4];        // overlapped path: MFMA kernel k0..k1 (main stream), node kernel k2..k3 (stream 2)
     bool has_node, has_defect, fused;
 };
 
@@ -36,6 +37,8 @@ struct emi_ctx_s {
     bool f32 = false;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream2 = nullptr;          // the node kernel runs here while the MFMA defect kernel runs on `stream`
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
 
     // mesh
@@ -43,9 +46,10 @@ struct emi_ctx_s {
     double t0 = 0, tf = 0;
     DevBuf d_w, d_t, d_Ddiag, d_D, d_De, d_Do;
     bool symmetric = false;   // D is exactly centro-antisymmetric and M is even: De/Do are valid
-    bool allow_fused = true;
-    int fused_ablate = 0;
-    bool fused_attr_set = false;
+    bool allow_fused = true;      // "overlap" option: even/odd MFMA defect kernel || node kernel on two streams
+    int sym_ct = 1;               // column tiles per wave of the MFMA kernel (emi_symdefect.hip)
+    int overlap_mode = 2;         // 2: two streams; 1: same stream, node kernel then MFMA kernel
+    unsigned fused_attr_mask = 0;
     std::vector<double> h_tau, h_w;
     // model
     int model = -1, ns = 0, nc = 0, maximize = 0;
@@ -205,6 +209,12 @@ static int create_impl(int device_id, bool f32, emi_ctx_t* out) {
         return EMI_ERR_HIP;
     }
     c->own_stream = true;
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        return EMI_ERR_HIP;
+    }
     if (hipEventCreate(&c->t_start) != hipSuccess || hipEventCreate(&c->t_stop) != hipSuccess) {
         delete c;
         return EMI_ERR_HIP;
@@ -225,8 +235,13 @@ int emi_destroy(emi_ctx_t c) {
                       &c->s_LF, &c->s_LC, &c->s_H};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
-    for (auto& pe : c->prof)
+    for (auto& pe : c->prof) {
         for (int i = 0; i < 3; ++i) (void)hipEventDestroy(pe.e[i]);
+        for (int i = 0; i < 4; ++i) (void)hipEventDestroy(pe.k[i]);
+    }
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->t_start) (void)hipEventDestroy(c->t_start);
     if (c->t_stop) (void)hipEventDestroy(c->t_stop);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -332,8 +347,7 @@ int emi_set_batch(emi_ctx_t c, int B) {
     if (c->M <= 0) return fail(c, EMI_ERR_STATE, "emi_set_mesh must precede emi_set_batch");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t rb = c->f32 ? 4 : 8;
-    const int chunks = std::max(emi::node_chunks(c->M), emi::fused_cost_chunks(c->M));
-    int st = ensure(c, c->d_cost_part, (size_t)B * std::max(chunks, 1) * rb);
+    int st = ensure(c, c->d_cost_part, (size_t)B * emi::node_chunks(c->M) * rb);
     if (st) return st;
     c->B = B;
     return EMI_OK;
@@ -455,12 +469,13 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         c->attr_set = true;
     }
     const bool fused = nodes && defect && !c->f32 && c->allow_fused && c->symmetric &&
-                       emi::fused_supported(c->model, c->M);
+                       emi::fused_supported(c->model, c->M, c->sym_ct);
     ProfEvents* pe = nullptr;
     if (c->profile) {
         if (c->prof_used == c->prof.size()) {
             ProfEvents n;
             for (int i = 0; i < 3; ++i) HIP_TRY(c, hipEventCreate(&n.e[i]));
+            for (int i = 0; i < 4; ++i) HIP_TRY(c, hipEventCreate(&n.k[i]));
             c->prof.push_back(n);
         }
         pe = &c->prof[c->prof_used++];
@@ -470,35 +485,57 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         HIP_TRY(c, hipEventRecord(pe->e[0], c->stream));
     }
     if (fused) {
-        emi::FusedArgs a;
-        a.X = (const double*)dX; a.U = (const double*)dU; a.RES = (double*)dRES; a.VALS = (double*)dVALS;
-        a.cost_part = (double*)c->d_cost_part.p;
-        a.w = (const double*)c->d_w.p; a.node_t = (const double*)c->d_t.p; a.Ddiag = (const double*)c->d_Ddiag.p;
-        a.De = (const double*)c->d_De.p; a.Do = (const double*)c->d_Do.p;
-        a.path = (const double*)c->d_path.p; a.track_x = (const double*)c->d_trkx.p; a.track_y = (const double*)c->d_trky.p;
-        a.M = c->M; a.B = c->B; a.np = c->np; a.nres = nres_of(c); a.nvals = nvals_of(c);
-        a.path_sets = c->path_sets; a.track_sets = c->track_sets; a.ntracks = c->ntracks; a.px = c->px; a.py = c->py;
-        a.h = (c->tf - c->t0) / 2.0; a.sgn = c->maximize ? -1.0 : 1.0;
-        a.ablate = c->fused_ablate;
-        a.cost_chunks = emi::fused_cost_chunks(c->M);
-        for (int i = 0; i < EMI_MAX_PARAMS; ++i) a.P.p[i] = c->params[i];
-        HIP_TRY(c, emi::launch_fused(c->model, a, jac, c->stream, !c->fused_attr_set));
-        c->fused_attr_set = true;
-        if (pe) HIP_TRY(c, hipEventRecord(pe->e[1], c->stream));
-        HIP_TRY(c, emi::launch_cost_finish<double>((const double*)c->d_cost_part.p, (double*)dCOST, c->B,
-                                                   emi::fused_cost_chunks(c->M), a.sgn * a.h, c->stream));
-        if (pe) HIP_TRY(c, hipEventRecord(pe->e[2], c->stream));
+        // fork: the two kernels read X,U and write disjoint outputs, so they run concurrently.
+        // The MFMA kernel goes first and takes one workgroup per CU (LDS-shaped); the streaming
+        // kernel's waves fill the rest of every CU.
+        emi::SymDefectArgs sa;
+        sa.X = (const double*)dX; sa.U = (const double*)dU; sa.RES = (double*)dRES;
+        sa.node_t = (const double*)c->d_t.p; sa.De = (const double*)c->d_De.p; sa.Do = (const double*)c->d_Do.p;
+        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0;
+        for (int i = 0; i < EMI_MAX_PARAMS; ++i) sa.P.p[i] = c->params[i];
+        emi::NodeArgs<double> na;
+        fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
+        const bool two = c->overlap_mode == 2;
+        hipStream_t s2 = two ? c->stream2 : c->stream;
+        const unsigned bit = 1u << c->sym_ct;
+        if (two) {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        }
+        if (pe) HIP_TRY(c, hipEventRecord(pe->k[0], c->stream));
+        HIP_TRY(c, emi::launch_symdefect(c->model, sa, c->stream, !(c->fused_attr_mask & bit), c->sym_ct));
+        c->fused_attr_mask |= bit;
+        if (pe) {
+            HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
+            HIP_TRY(c, hipEventRecord(pe->k[2], s2));
+        }
+        HIP_TRY(c, emi::launch_nodes<double>(c->model, na, jac, false, s2));
+        if (pe) HIP_TRY(c, hipEventRecord(pe->k[3], s2));
+        HIP_TRY(c, emi::launch_cost_finish<double>(na.cost_part, na.cost, c->B, emi::node_chunks(c->M),
+                                                   na.sgn * na.h, s2));
+        if (two) {
+            HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        }
+        if (pe) {
+            HIP_TRY(c, hipEventRecord(pe->e[1], c->stream));
+            HIP_TRY(c, hipEventRecord(pe->e[2], c->stream));
+        }
         return EMI_OK;
     }
     if (nodes) {
         if (c->f32) {
             emi::NodeArgs<float> a;
             fill_node_args(c, a, dX, dU, dRES, dVALS, dCOST);
-            HIP_TRY(c, emi::launch_nodes<float>(c->model, a, jac, c->stream));
+            HIP_TRY(c, emi::launch_nodes<float>(c->model, a, jac, true, c->stream));
+            HIP_TRY(c, emi::launch_cost_finish<float>(a.cost_part, a.cost, c->B, emi::node_chunks(c->M), a.sgn * a.h,
+                                                      c->stream));
         } else {
             emi::NodeArgs<double> a;
             fill_node_args(c, a, dX, dU, dRES, dVALS, dCOST);
-            HIP_TRY(c, emi::launch_nodes<double>(c->model, a, jac, c->stream));
+            HIP_TRY(c, emi::launch_nodes<double>(c->model, a, jac, true, c->stream));
+            HIP_TRY(c, emi::launch_cost_finish<double>(a.cost_part, a.cost, c->B, emi::node_chunks(c->M), a.sgn * a.h,
+                                                       c->stream));
         }
     }
     if (pe) HIP_TRY(c, hipEventRecord(pe->e[1], c->stream));
@@ -615,9 +652,10 @@ int emi_profile_enable(emi_ctx_t c, int on) {
 }
 
 int emi_profile_read(emi_ctx_t c, float* node_ms, int* node_launches, float* defect_ms,
-                     int* defect_launches, float* fused_ms, int* fused_launches) {
+                     int* defect_launches, float* pass_ms, int* overlapped_passes) {
     if (!c) return EMI_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream2));
     float nm = 0, dm = 0, fm = 0;
     int nl = 0, dl = 0, fl = 0;
     for (size_t i = 0; i < c->prof_used; ++i) {
@@ -627,6 +665,12 @@ int emi_profile_read(emi_ctx_t c, float* node_ms, int* node_launches, float* def
             HIP_TRY(c, hipEventElapsedTime(&ms, pe.e[0], pe.e[1]));
             fm += ms;
             ++fl;
+            HIP_TRY(c, hipEventElapsedTime(&ms, pe.k[0], pe.k[1]));
+            dm += ms;
+            ++dl;
+            HIP_TRY(c, hipEventElapsedTime(&ms, pe.k[2], pe.k[3]));
+            nm += ms;
+            ++nl;
             continue;
         }
         if (pe.has_node) {
@@ -645,22 +689,31 @@ int emi_profile_read(emi_ctx_t c, float* node_ms, int* node_launches, float* def
     if (node_launches) *node_launches = nl;
     if (defect_ms) *defect_ms = dm;
     if (defect_launches) *defect_launches = dl;
-    if (fused_ms) *fused_ms = fm;
-    if (fused_launches) *fused_launches = fl;
+    if (pass_ms) *pass_ms = fm;
+    if (overlapped_passes) *overlapped_passes = fl;
     return EMI_OK;
 }
 
 int emi_set_option(emi_ctx_t c, const char* name, int value) {
     if (!c || !name) return EMI_ERR_ARG;
-    if (strcmp(name, "fused") == 0) { c->allow_fused = value != 0; return EMI_OK; }
-    if (strcmp(name, "fused_ablate") == 0) { c->fused_ablate = value; return EMI_OK; }   // diagnostics
+    if (strcmp(name, "overlap") == 0 || strcmp(name, "fused") == 0) { c->allow_fused = value != 0; return EMI_OK; }
+    if (strcmp(name, "sym_ct") == 0) {
+        if (value != 1 && value != 2) return fail(c, EMI_ERR_ARG, "sym_ct must be 1 or 2");
+        c->sym_ct = value;
+        return EMI_OK;
+    }
+    if (strcmp(name, "overlap_mode") == 0) {
+        if (value != 1 && value != 2) return fail(c, EMI_ERR_ARG, "overlap_mode must be 1 or 2");
+        c->overlap_mode = value;
+        return EMI_OK;
+    }
     return fail(c, EMI_ERR_ARG, "unknown option '%s'", name);
 }
 
 int emi_last_path(emi_ctx_t c, int* fused) {
     if (!c || !fused) return EMI_ERR_ARG;
     *fused = (!c->f32 && c->allow_fused && c->symmetric && c->M > 0 && c->model >= 0 &&
-              emi::fused_supported(c->model, c->M)) ? 1 : 0;
+              emi::fused_supported(c->model, c->M, c->sym_ct)) ? 1 : 0;
     return EMI_OK;
 }
 

@@ -66,8 +66,14 @@ template <typename T> EMI_DEV T wave_sum(T v) {
 //        RES path rows    = c_j
 //        VALS             = Jacobian values, cost gradient
 //        cost_part[b][chunk] = sum_k w_k L_k  over this block (wave DPP + LDS)
+// DEFROWS = false leaves the defect rows alone: the even/odd defect kernel
+// (emi_symdefect.hip) then produces them, concurrently, on another stream.
+// A thread issues all its loads first and only stores afterwards: vmcnt
+// retires in order, so a load behind the ~116 streaming stores would wait for
+// every one of them.  For the same reason the wave-uniform keep-out records
+// are read through the constant address space (scalar loads, lgkmcnt).
 // ---------------------------------------------------------------------------
-template <typename T, class Model, int VEC, bool JAC>
+template <typename T, class Model, int VEC, bool JAC, bool DEFROWS>
 __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T> a) {
     constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
     const int b = blockIdx.y;
@@ -101,13 +107,17 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T>
                 T ze[NV], fe[NS];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) ze[v] = z[v][e];
-                Model::f(a.P, ze, tk[e], fe);
+                if (DEFROWS) {
+                    Model::f(a.P, ze, tk[e], fe);
 #pragma unroll
-                for (int i = 0; i < NS; ++i) fo[i][e] = -h * fe[i];
+                    for (int i = 0; i < NS; ++i) fo[i][e] = -h * fe[i];
+                }
                 lsum += wk[e] * Model::cost(a.P, ze, tk[e]);
             }
+            if (DEFROWS) {
 #pragma unroll
-            for (int i = 0; i < NS; ++i) store_vec<T, VEC>(Rb + (size_t)i * M + k0, fo[i]);
+                for (int i = 0; i < NS; ++i) store_vec<T, VEC>(Rb + (size_t)i * M + k0, fo[i]);
+            }
         }
         if (JAC) {
             // ---- K1' dynamics Jacobian block + K5 placement ---------------
@@ -142,7 +152,8 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T>
         const int np = a.np;
         if (np > 0) {
             const int set = a.path_sets > 1 ? b : 0;
-            const T* __restrict__ rec = a.path + (size_t)set * np * EMI_PATH_REC;
+            typedef const __attribute__((address_space(4))) T* cptr_t;   // read-only table: scalar loads
+            cptr_t rec = (cptr_t)(a.path + (size_t)set * np * EMI_PATH_REC);
             T* __restrict__ Cb = Rb + (size_t)NS * M;
             T* __restrict__ JCb = JAC ? Vb + (size_t)(NS * NV) * M : nullptr;
             // the keep-outs act on two runtime-chosen states: select with
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T>
                 }
             }
             for (int j = 0; j < np; ++j) {
-                const T* __restrict__ r = rec + j * EMI_PATH_REC;
+                cptr_t r = rec + j * EMI_PATH_REC;
                 const int kind = (int)r[0];
                 T c[VEC], cx[VEC], cy[VEC];
                 if (kind == EMI_PATH_DISC) {
@@ -483,24 +494,19 @@ __global__ __launch_bounds__(256) void emi_defect_f32_kernel(DefectArgsF32 a) {
 // ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
-template <typename T, class Model>
+template <typename T, class Model, bool DEFROWS>
 static hipError_t launch_nodes_model(const NodeArgs<T>& a, bool jac, hipStream_t s) {
     const int M = a.M;
     const bool vec2 = (M % 2 == 0);
     const int per_block = EMI_NODE_THREADS * (vec2 ? 2 : 1);
     dim3 grid((M + per_block - 1) / per_block, a.B), block(EMI_NODE_THREADS);
     if (vec2) {
-        if (jac) hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 2, true>), grid, block, 0, s, a);
-        else     hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 2, false>), grid, block, 0, s, a);
+        if (jac) hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 2, true, DEFROWS>), grid, block, 0, s, a);
+        else     hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 2, false, DEFROWS>), grid, block, 0, s, a);
     } else {
-        if (jac) hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 1, true>), grid, block, 0, s, a);
-        else     hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 1, false>), grid, block, 0, s, a);
+        if (jac) hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 1, true, DEFROWS>), grid, block, 0, s, a);
+        else     hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 1, false, DEFROWS>), grid, block, 0, s, a);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const int nchunks = grid.x;
-    hipLaunchKernelGGL((emi_cost_finish_kernel<T>), dim3((a.B + 255) / 256), dim3(256), 0, s,
-                       a.cost_part, a.cost, a.B, nchunks, a.sgn * a.h);
     return hipGetLastError();
 }
 
@@ -518,17 +524,25 @@ int node_chunks(int M) {
     return (M + per_block - 1) / per_block;
 }
 
+// node kernel only; the caller launches launch_cost_finish(node_chunks(M)) behind it
 template <typename T>
-hipError_t launch_nodes(int model, const NodeArgs<T>& a, bool jac, hipStream_t s) {
-    switch (model) {
-        case 0: return launch_nodes_model<T, PointMass2D<T>>(a, jac, s);
-        case 1: return launch_nodes_model<T, Quadrotor2D<T>>(a, jac, s);
-        case 2: return launch_nodes_model<T, FixedWing12<T>>(a, jac, s);
+hipError_t launch_nodes(int model, const NodeArgs<T>& a, bool jac, bool defect_rows, hipStream_t s) {
+    if (defect_rows) {
+        switch (model) {
+            case 0: return launch_nodes_model<T, PointMass2D<T>, true>(a, jac, s);
+            case 1: return launch_nodes_model<T, Quadrotor2D<T>, true>(a, jac, s);
+            case 2: return launch_nodes_model<T, FixedWing12<T>, true>(a, jac, s);
+        }
+    } else {
+        switch (model) {
+            case 0: return launch_nodes_model<T, PointMass2D<T>, false>(a, jac, s);
+            case 1: return launch_nodes_model<T, Quadrotor2D<T>, false>(a, jac, s);
+        }
     }
     return hipErrorInvalidValue;
 }
-template hipError_t launch_nodes<double>(int, const NodeArgs<double>&, bool, hipStream_t);
-template hipError_t launch_nodes<float>(int, const NodeArgs<float>&, bool, hipStream_t);
+template hipError_t launch_nodes<double>(int, const NodeArgs<double>&, bool, bool, hipStream_t);
+template hipError_t launch_nodes<float>(int, const NodeArgs<float>&, bool, bool, hipStream_t);
 
 template <typename T>
 hipError_t launch_hess(int model, const HessArgs<T>& a, hipStream_t s) {

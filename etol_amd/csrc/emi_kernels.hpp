@@ -13,9 +13,8 @@
 #define DEF_TN 128
 #define DEF_BK 16
 
-// fused pass (emi_fused.hip): 16 instances x 64 half-indices per workgroup, K tile 16
+// even/odd defect kernel (emi_symdefect.hip): 16 instances x 64*CT half-indices per workgroup, K tile 16
 #define FUSED_TI 16
-#define FUSED_TN 64
 #define FUSED_BK 16
 
 #include "emi_models.hpp"
@@ -56,26 +55,15 @@ template <typename T> struct HessArgs {
     ModelParams<T> P;
 };
 
-struct FusedArgs {
+struct SymDefectArgs {
     const double* X;
     const double* U;
     double* RES;
-    double* VALS;
-    double* cost_part;      // [B][cost_chunks]
-    const double* w;
     const double* node_t;
-    const double* Ddiag;
     const double* De;       // [M/2][M/2]  (D[i][j] + D[i][N-j]) / 2
     const double* Do;       // [M/2][M/2]  (D[i][j] - D[i][N-j]) / 2
-    const double* path;
-    const double* track_x;
-    const double* track_y;
-    int M, B, np, nres, nvals;
-    int path_sets, track_sets, ntracks;
-    int px, py;
-    int cost_chunks;        // cost partials per instance (fused_cost_chunks(M))
-    int ablate;             // diagnostics only: 1 = skip the MFMAs, 2 = skip the node items (results invalid)
-    double h, sgn;
+    int M, B, nres;
+    double h;
     ModelParams<double> P;
 };
 
@@ -93,15 +81,15 @@ struct DefectArgsF32 {
 };
 
 int node_chunks(int M);
-template <typename T> hipError_t launch_nodes(int model, const NodeArgs<T>& a, bool jac, hipStream_t s);
+template <typename T>
+hipError_t launch_nodes(int model, const NodeArgs<T>& a, bool jac, bool defect_rows, hipStream_t s);
 template <typename T> hipError_t launch_hess(int model, const HessArgs<T>& a, hipStream_t s);
 hipError_t launch_defect_f64(const DefectArgs& a, hipStream_t s);
 hipError_t launch_defect_f32(const DefectArgsF32& a, hipStream_t s);
 hipError_t defect_f64_set_attr();
 template <typename T>
 hipError_t launch_cost_finish(const T* part, T* cost, int B, int nchunks, T scale, hipStream_t s);
-bool fused_supported(int model, int M);
-int fused_cost_chunks(int M);
-hipError_t launch_fused(int model, const FusedArgs& a, bool jac, hipStream_t s, bool set_attr);
+bool fused_supported(int model, int M, int ct);
+hipError_t launch_symdefect(int model, const SymDefectArgs& a, hipStream_t s, bool set_attr, int ct);
 
 }  // namespace emi

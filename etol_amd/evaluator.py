@@ -189,7 +189,7 @@ class Evaluator:
         self._ck(self.lib.emi_profile_read(self.ctx, C.byref(nm), C.byref(nl), C.byref(dm), C.byref(dl), C.byref(fm),
                                            C.byref(fl)), "emi_profile_read")
         return dict(node_ms=nm.value, node_launches=nl.value, defect_ms=dm.value, defect_launches=dl.value,
-                    fused_ms=fm.value, fused_launches=fl.value)
+                    pass_ms=fm.value, overlapped_passes=fl.value)
 
     def set_option(self, name, value):
         self._ck(self.lib.emi_set_option(self.ctx, name.encode(), int(value)), "emi_set_option")

@@ -180,18 +180,24 @@ int emi_hess_host(emi_ctx_t ctx, const double* X, const double* U,
 /* HIP-event timers on the context's stream.                                 */
 int emi_timer_start(emi_ctx_t ctx);
 int emi_timer_stop(emi_ctx_t ctx, float* elapsed_ms); /* synchronises */
-/* Per-kernel event brackets inside emi_eval_dev (adds two events/launch).   */
+/* Per-kernel event brackets inside emi_eval_dev (adds two events/launch).
+ * node/defect: the two kernels of the sequential path; fused: the whole
+ * overlapped pass (fork -> both kernels -> join).                            */
 int emi_profile_enable(emi_ctx_t ctx, int on);
 int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
                      float* defect_ms, int* defect_launches,
                      float* fused_ms, int* fused_launches); /* syncs+resets */
 
 /* ---- kernel selection ------------------------------------------------------ */
-/* "fused" (default 1): emi_eval with EMI_EVAL_ALL runs the single fused kernel
- * (emi_fused.hip) when the mesh allows it (f64, M % 128 == 0, centro-
- * antisymmetric D, 2- or 6-state model); 0 forces the general two-kernel path. */
+/* "overlap" (default 1): emi_eval with EMI_EVAL_ALL runs the even/odd MFMA defect
+ * kernel (emi_symdefect.hip) and the streaming node kernel CONCURRENTLY on two
+ * streams when the mesh allows it (f64, M % 128 == 0, centro-antisymmetric D,
+ * 2- or 6-state model); 0 forces the general node-then-defect sequence.
+ * "sym_ct" (1 or 2, default 1): 16-column tiles per wave of the MFMA kernel
+ * (2 needs M % 256 == 0).  "overlap_mode" (2 = two streams, default; 1 = same
+ * stream back to back).                                                        */
 int emi_set_option(emi_ctx_t ctx, const char* name, int value);
-/* 1 if emi_eval(EMI_EVAL_ALL) currently takes the fused kernel               */
+/* 1 if emi_eval(EMI_EVAL_ALL) currently takes the overlapped path             */
 int emi_last_path(emi_ctx_t ctx, int* fused);
 
 #ifdef __cplusplus

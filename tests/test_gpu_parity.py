@@ -197,8 +197,8 @@ def test_fused_and_general_kernels_agree(built):
     """The fused kernel (even/odd MFMA split + interleaved node work) and the general two-kernel
     path are two implementations of the same pass; also B off the 16-instance tile."""
     import etol_amd as E
-    for model, M, B, nobs in ((E.MODEL_QUADROTOR2D, 128, 21, 3), (E.MODEL_QUADROTOR2D, 1024, 5, 20),
-                              (E.MODEL_POINTMASS2D, 256, 33, 2)):
+    for model, M, B, nobs in ((E.MODEL_QUADROTOR2D, 256, 21, 3), (E.MODEL_QUADROTOR2D, 1024, 5, 20),
+                              (E.MODEL_POINTMASS2D, 512, 33, 2)):
         ev = E.Evaluator(0)
         ev.set_mesh(M, 0.0, 12.0)
         if model == E.MODEL_QUADROTOR2D:
@@ -216,7 +216,7 @@ def test_fused_and_general_kernels_agree(built):
         assert ev.uses_fused_kernel
         fused = ev.eval_host(X, U)
         fused_nojac = ev.eval_host(X, U, flags=E.EVAL_ALL | E.EVAL_NOJAC)
-        ev.set_option("fused", 0)
+        ev.set_option("overlap", 0)
         assert not ev.uses_fused_kernel
         general = ev.eval_host(X, U)
         ref = O.evaluate(model, W.QUAD_PARAMS if model == E.MODEL_QUADROTOR2D else [], M, (ev.tau, ev.w, ev.D), 0.0,
