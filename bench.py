@@ -99,10 +99,19 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # rehearsal knobs (never set by the driver): control plane over gloo, all ranks on one GPU
+    backend = os.environ.get("EMI_BENCH_BACKEND", "nccl")
+    if os.environ.get("EMI_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    ctl = dev if backend == "nccl" else torch.device("cpu")   # where control-plane tensors live
 
     import etol_amd as E
     from etol_amd import workloads as W
@@ -120,7 +129,6 @@ def main():
     X, U, recs = W.quadrotor_batch(3, B, M, n_obs, first_instance=rank * B)   # scenario s -> rank s // B
     if n_obs:
         ev.set_path(recs, 0, 1)
-    dev = torch.device("cuda", local)
     dX = torch.from_numpy(X).to(dev)
     dU = torch.from_numpy(U).to(dev)
     RES, VALS, COST = ev.alloc_outputs()
@@ -145,7 +153,7 @@ def main():
     prof = ev.profile_read()
     ev.profile(False)
 
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=ctl)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     el = float(el.item())
@@ -155,13 +163,15 @@ def main():
     # the path's one collective: gather the trajectories to rank 0 (once per batch, untimed)
     gather_ms = None
     if world > 1:
-        traj = torch.cat([dX.reshape(B, -1), dU.reshape(B, -1)], dim=1).contiguous()
-        out = [torch.empty_like(traj) for _ in range(world)] if rank == 0 else None
+        from etol_amd import batch
+        gX, gU = (dX, dU) if backend == "nccl" else (dX.cpu(), dU.cpu())
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        dist.gather(traj, out, dst=0)
+        got = batch.gather_trajectories(gX, gU, world * B, dst=0)
         torch.cuda.synchronize()
         gather_ms = 1e3 * (time.perf_counter() - tg)
+        if rank == 0:
+            assert got[0].shape[0] == world * B and torch.equal(got[0][:B].to(dX.device), dX)
 
     if rank == 0:
         # ---- roofline of the dominant kernel (longest average launch, HIP events on its own stream)

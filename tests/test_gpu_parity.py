@@ -226,3 +226,51 @@ def test_fused_and_general_kernels_agree(built):
         check(c, ev, general, ref)
         assert np.array_equal(fused[1], general[1])            # node work is the same arithmetic
         assert np.array_equal(fused_nojac[0], fused[0]) and np.array_equal(fused_nojac[2], fused[2])
+
+
+def test_f32_context_fixedwing(built):
+    """Config-5 arithmetic type: f32 storage and node arithmetic, D.X accumulated in f64.
+    Tolerances: 2e-6 of the row scale (f32 rounding of the inputs), defect rows against
+    sum|D_kj||x_j| (an f32 accumulator would lose every digit: |D| reaches N(N+1)/4)."""
+    import etol_amd as E
+    from etol_amd import workloads as W
+    M, B = 256, 3
+    X, U = W.fixedwing_batch(4, B, M)
+    X = X.astype(np.float32).astype(np.float64)       # what the device will see
+    U = U.astype(np.float32).astype(np.float64)
+    ev = E.Evaluator(0, f32=True)
+    ev.set_mesh(M, 0.0, 20.0)
+    ev.set_model(E.MODEL_FIXEDWING12, W.FW_PARAMS)
+    ev.set_batch(B)
+    assert ev.layout.real_bytes == 4 and not ev.uses_fused_kernel
+    RES, VALS, COST = ev.eval_host(X, U)
+    rRES, rVALS, rCOST = O.evaluate(E.MODEL_FIXEDWING12, W.FW_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, 20.0, X, U)
+    scale = np.einsum("kj,bij->bik", np.abs(ev.D), np.abs(X)) + np.abs(rRES) + 1.0
+    assert (np.abs(RES - rRES) / scale).max() < 2e-6
+    for e in range(VALS.shape[1]):
+        assert np.abs(VALS[:, e] - rVALS[:, e]).max() / (np.abs(rVALS[:, e]).max() + 1.0) < 2e-6
+    assert np.abs(COST - rCOST).max() / np.abs(rCOST).max() < 2e-6
+    # device-pointer form with f32 torch tensors
+    import torch
+    dX = torch.from_numpy(X.astype(np.float32)).cuda()
+    dU = torch.from_numpy(U.astype(np.float32)).cuda()
+    dRES, dVALS, dCOST = ev.alloc_outputs()
+    ev.eval_dev(dX, dU, dRES, dVALS, dCOST)
+    ev.synchronize()
+    assert np.array_equal(dRES.cpu().numpy().astype(np.float64), RES)
+
+
+def test_device_pointer_form_matches_host_form(built):
+    import etol_amd as E
+    import torch
+    c, ev, got, _ = run_case("quad_1024_obs")
+    dX, dU = torch.from_numpy(c["X"]).cuda(), torch.from_numpy(c["U"]).cuda()
+    RES, VALS, COST = ev.alloc_outputs()
+    for _ in range(3):      # repeated passes on the same buffers give the same bits
+        ev.eval_dev(dX, dU, RES, VALS, COST)
+    ev.synchronize()
+    torch.cuda.synchronize()
+    assert np.array_equal(RES.cpu().numpy(), got[0]) and np.array_equal(VALS.cpu().numpy(), got[1])
+    assert np.array_equal(COST.cpu().numpy(), got[2])
+    with pytest.raises(ValueError):
+        ev.eval_dev(dX[:1], dU, RES, VALS, COST)
