@@ -123,7 +123,7 @@ def main():
     ev.set_batch(B)
     if os.environ.get("EMI_OVERLAP", "1") == "0":
         ev.set_option("overlap", 0)        # A/B switch: sequential general path
-    for opt in ("sym_ct", "overlap_mode"):          # experiment knobs of the overlapped path
+    for opt in ("sym_ct", "overlap_mode", "sym_order", "sym_ablate"):          # experiment knobs of the overlapped path
         if os.environ.get("EMI_" + opt.upper()):
             ev.set_option(opt, int(os.environ["EMI_" + opt.upper()]))
     X, U, recs = W.quadrotor_batch(3, B, M, n_obs, first_instance=rank * B)   # scenario s -> rank s // B
@@ -183,7 +183,9 @@ def main():
         def_ms = prof["defect_ms"] / max(prof["defect_launches"], 1)
         overlapped = prof["overlapped_passes"] > 0
         node_name = "emi_nodes_kernel"
-        def_name = "emi_symdefect_f64_kernel" if overlapped else "emi_defect_f64_kernel"
+        ring = os.environ.get("EMI_SYM_CT", "3") == "3"
+        def_name = (("emi_symdefect_ring_f64_kernel" if ring else "emi_symdefect_f64_kernel") if overlapped
+                    else "emi_defect_f64_kernel")
         traffic = load_pmc_traffic()
         if node_ms >= def_ms:
             ach = alg_bytes / (node_ms * 1e-3) / 1e9

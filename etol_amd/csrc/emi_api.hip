@@ -47,7 +47,9 @@ struct emi_ctx_s {
     DevBuf d_w, d_t, d_Ddiag, d_D, d_De, d_Do;
     bool symmetric = false;   // D is exactly centro-antisymmetric and M is even: De/Do are valid
     bool allow_fused = true;      // "overlap" option: even/odd MFMA defect kernel || node kernel on two streams
-    int sym_ct = 1;               // column tiles per wave of the MFMA kernel (emi_symdefect.hip)
+    int sym_ct = 3;               // MFMA kernel variant (emi_symdefect.hip): 3 = LDS-DMA ring, 1/2 = register-staged
+    int sym_order = 1;
+    int sym_ablate = 0;
     int overlap_mode = 2;         // 2: two streams; 1: same stream, node kernel then MFMA kernel
     unsigned fused_attr_mask = 0;
     std::vector<double> h_tau, h_w;
@@ -491,7 +493,7 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         emi::SymDefectArgs sa;
         sa.X = (const double*)dX; sa.U = (const double*)dU; sa.RES = (double*)dRES;
         sa.node_t = (const double*)c->d_t.p; sa.De = (const double*)c->d_De.p; sa.Do = (const double*)c->d_Do.p;
-        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0;
+        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0; sa.order = c->sym_order; sa.ablate = c->sym_ablate;
         for (int i = 0; i < EMI_MAX_PARAMS; ++i) sa.P.p[i] = c->params[i];
         emi::NodeArgs<double> na;
         fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
@@ -698,10 +700,12 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
     if (!c || !name) return EMI_ERR_ARG;
     if (strcmp(name, "overlap") == 0 || strcmp(name, "fused") == 0) { c->allow_fused = value != 0; return EMI_OK; }
     if (strcmp(name, "sym_ct") == 0) {
-        if (value != 1 && value != 2) return fail(c, EMI_ERR_ARG, "sym_ct must be 1 or 2");
+        if (value < 1 || value > 3) return fail(c, EMI_ERR_ARG, "sym_ct must be 1, 2 or 3 (3 = LDS-DMA ring)");
         c->sym_ct = value;
         return EMI_OK;
     }
+    if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }
+    if (strcmp(name, "sym_ablate") == 0) { c->sym_ablate = value; return EMI_OK; }   // diagnostics only
     if (strcmp(name, "overlap_mode") == 0) {
         if (value != 1 && value != 2) return fail(c, EMI_ERR_ARG, "overlap_mode must be 1 or 2");
         c->overlap_mode = value;

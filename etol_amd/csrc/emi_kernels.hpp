@@ -63,6 +63,8 @@ struct SymDefectArgs {
     const double* De;       // [M/2][M/2]  (D[i][j] + D[i][N-j]) / 2
     const double* Do;       // [M/2][M/2]  (D[i][j] - D[i][N-j]) / 2
     int M, B, nres;
+    int order;              // block -> tile order within an XCD (see emi_symdefect.hip)
+    int ablate;             // diagnostics (results invalid): 1 skip MFMAs, 2 skip operand DMA, 4 skip epilogue
     double h;
     ModelParams<double> P;
 };

@@ -193,9 +193,11 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * kernel (emi_symdefect.hip) and the streaming node kernel CONCURRENTLY on two
  * streams when the mesh allows it (f64, M % 128 == 0, centro-antisymmetric D,
  * 2- or 6-state model); 0 forces the general node-then-defect sequence.
- * "sym_ct" (1 or 2, default 1): 16-column tiles per wave of the MFMA kernel
- * (2 needs M % 256 == 0).  "overlap_mode" (2 = two streams, default; 1 = same
- * stream back to back).                                                        */
+ * "sym_ct": MFMA kernel variant, 3 (default) = LDS-DMA operand ring, 1 / 2 =
+ * register-staged with 64 / 128 columns per workgroup (2 needs M % 256 == 0).
+ * "sym_order" (default 1): workgroup -> tile order within an XCD.
+ * "overlap_mode" (2 = two streams, default; 1 = same stream back to back).
+ * "sym_ablate": diagnostics only, results invalid.                             */
 int emi_set_option(emi_ctx_t ctx, const char* name, int value);
 /* 1 if emi_eval(EMI_EVAL_ALL) currently takes the overlapped path             */
 int emi_last_path(emi_ctx_t ctx, int* fused);

@@ -216,6 +216,21 @@ def test_fused_and_general_kernels_agree(built):
         assert ev.uses_fused_kernel
         fused = ev.eval_host(X, U)
         fused_nojac = ev.eval_host(X, U, flags=E.EVAL_ALL | E.EVAL_NOJAC)
+        # every variant of the even/odd MFMA kernel: register-staged 64- and 128-column tiles (1, 2),
+        # LDS-DMA ring (3); and both launch modes
+        for ct in (1, 2, 3):
+            if ct == 2 and M % 256:
+                continue
+            for mode in (2, 1):
+                ev.set_option("sym_ct", ct)
+                ev.set_option("overlap_mode", mode)
+                assert ev.uses_fused_kernel
+                other = ev.eval_host(X, U)
+                assert np.array_equal(other[1], fused[1]) and np.array_equal(other[2], fused[2])
+                s = np.einsum("kj,bij->bik", np.abs(ev.D), np.abs(X)) + 1.0
+                assert (np.abs(other[0][:, :X.shape[1]] - fused[0][:, :X.shape[1]]) / s).max() < 1e-13
+        ev.set_option("sym_ct", 3)
+        ev.set_option("overlap_mode", 2)
         ev.set_option("overlap", 0)
         assert not ev.uses_fused_kernel
         general = ev.eval_host(X, U)
