@@ -160,6 +160,114 @@ extern "C" int harness_solve_example1_oracle(const char* xml, const char* oracle
     return 0;
 }
 
+// ---- quadrotor VGP (the headline model) as an ETOL problem set up through the public API --------
+namespace {
+struct QuadSetup {
+    std::vector<std::array<double, 3>> discs;
+    ETOL::f_t obj, obs;
+    std::vector<ETOL::f_t> grad;
+    std::vector<double> params{1.0, 0.01, 9.81, 1.0, 1.0};
+};
+void configure_quadrotor(ETOL::TrajectoryOptimizer* t, QuadSetup& q, int nsteps, double dt, int ndiscs) {
+    t->setNSteps(nsteps); t->setDt(dt); t->setNStates(6); t->setNControls(2);
+    t->setX0({1, 1, 0, 0, 0, 0}); t->setXf({8, 6, 0, 0, 0, 0}); t->setXtol({0.01, 0.01, 0.01, 0.05, 0.05, 0.05});
+    t->setXlower({0, 0, -1.2, -6, -6, -4}); t->setXupper({10, 10, 1.2, 6, 6, 4});
+    t->setUlower({0, -1}); t->setUupper({25, 1});
+    t->setMaximize(false);
+    const std::array<double, 3> all[3] = {{4.0, 3.2, 0.8}, {6.3, 4.4, 0.7}, {2.5, 1.2, 0.4}};
+    for (int i = 0; i < ndiscs; ++i) q.discs.push_back(all[i]);
+    auto mp = q.params;
+    q.obj = [mp](F_ARGS) -> ETOL::scalar_t { return mx::objective(EMI_MODEL_QUADROTOR2D, mp); };
+    t->setObjective(&q.obj);
+    q.grad.resize(6);
+    std::vector<ETOL::f_t*> gp;
+    for (int i = 0; i < 6; ++i) {
+        q.grad[i] = [mp, i](F_ARGS) -> ETOL::scalar_t { return mx::derivative(EMI_MODEL_QUADROTOR2D, i, mp); };
+        gp.push_back(&q.grad[i]);
+    }
+    t->setGradient(gp);
+    if (ndiscs > 0) {
+        for (int i = 0; i < ndiscs; ++i)
+            t->addParams({std::pair<PARAM_PAIR>("disc_" + std::to_string(i), {ETOL::var_t::CONTINUOUS, -1000., 0., 0., nsteps * dt})});
+        auto discs = q.discs;
+        q.obs = [discs](F_ARGS) -> ETOL::scalar_t {
+            return mx::disc_rows(discs, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+        };
+        t->setConstraints({&q.obs});
+    }
+}
+}  // namespace
+
+// Solve the quadrotor VGP on the GPU through ETOL::eMI355X.  Outputs X[6][M], U[2][M].
+extern "C" int harness_solve_quadrotor(int nsteps, double dt, int ndiscs, double tol, int print_level, double* cost,
+                                       int* M, double* X, double* U, int cap, int* iters) {
+    ETOL::eMI355X solver;
+    QuadSetup q;
+    configure_quadrotor(&solver, q, nsteps, dt, ndiscs);
+    solver.setup();
+    solver.getAlgorithm()->nlp_tolerance = tol;
+    solver.getAlgorithm()->print_level = print_level;
+    solver.getAlgorithm()->nlp_iter_max = 400;
+    solver.solve();
+    const mx::Sol* s = solver.getSolution();
+    *iters = s->nlp_iterations;
+    g_out = s->error_msg;
+    if (s->error_flag) return 1;
+    const int m = (int)s->nodes;
+    if (m > cap) return 2;
+    *M = m; *cost = solver.getScore();
+    for (int k = 0; k < m; ++k) {
+        for (int i = 0; i < 6; ++i) X[i * m + k] = (*solver.getXtraj())[k].second[i];
+        for (int i = 0; i < 2; ++i) U[i * m + k] = (*solver.getUtraj())[k].second[i];
+    }
+    solver.close();
+    return 0;
+}
+
+// Same problem, NLP iteration driven by the CPU oracle (solver-logic tests; never the product path).
+extern "C" int harness_solve_quadrotor_oracle(const char* oracle_so, int nsteps, double dt, int ndiscs, double tol,
+                                              int print_level, double* cost, int* M, double* X, double* U, int cap,
+                                              int* iters) {
+    void* h = dlopen(oracle_so, RTLD_NOW);
+    if (!h) { g_out = dlerror(); return 3; }
+    OracleEval oe;
+    oe.ev = (orc_eval_t)dlsym(h, "orc_eval");
+    oe.hs = (orc_hess_t)dlsym(h, "orc_hess");
+    Plain t;
+    QuadSetup q;
+    configure_quadrotor(&t, q, nsteps, dt, ndiscs);
+    mx::Prob P;
+    P.nstates = 6; P.ncontrols = 2; P.nodes = nsteps + 1; P.t0 = 0; P.tf = nsteps * dt;
+    P.model = EMI_MODEL_QUADROTOR2D; P.model_params = q.params;
+    P.tau.resize(P.nodes); P.w.resize(P.nodes); P.D.resize(P.nodes * P.nodes);
+    emi_lgl((int)P.nodes, P.tau.data(), P.w.data(), P.D.data());
+    for (const auto& d : q.discs) {
+        double rec[8] = {(double)EMI_PATH_DISC, d[0], d[1], d[2] * d[2], 0, 0, 0, 0};
+        P.path_records.insert(P.path_records.end(), rec, rec + 8);
+    }
+    P.npath = q.discs.size();
+    P.state_lower = t.getXlower(); P.state_upper = t.getXupper();
+    P.control_lower = t.getUlower(); P.control_upper = t.getUupper();
+    for (int i = 0; i < 6; ++i) { P.event_lower.push_back(t.getX0()[i]); P.event_upper.push_back(t.getX0()[i]); }
+    for (int i = 0; i < 6; ++i) { P.event_lower.push_back(t.getXf()[i] - t.getXtol()[i]); P.event_upper.push_back(t.getXf()[i] + t.getXtol()[i]); }
+    P.path_lower.assign(P.npath, -1000.0); P.path_upper.assign(P.npath, 0.0);
+    oe.P = &P;
+    mx::NlpProblem nlp = mx::make_nlp(P, &oe);
+    mx::NlpOptions opt;
+    opt.tol = tol; opt.print_level = print_level; opt.max_iter = 400;
+    mx::NlpResult r = mx::solve_nlp(nlp, opt, mx::initial_guess(P));
+    *iters = r.iterations;
+    g_out = r.msg;
+    dlclose(h);
+    if (!r.ok) return 1;
+    const int m = (int)P.nodes;
+    if (m > cap) return 2;
+    *M = m; *cost = r.cost;
+    for (int i = 0; i < 6 * m; ++i) X[i] = r.z[i];
+    for (int i = 0; i < 2 * m; ++i) U[i] = r.z[6 * m + i];
+    return 0;
+}
+
 extern "C" {
 
 // parsed configuration of an XML file as JSON

@@ -76,3 +76,25 @@ def test_example_program_runs(built, tmp_path):
     assert "Minimization Score" in r.stdout and "Graceful Exit" in r.stdout
     rows = open(tmp_path / "state_mi355x1.csv").read().split("\n")
     assert rows[0] == "time,traj0,traj1" and len(rows) == 34
+
+
+def test_quadrotor_vgp_solves_on_the_gpu(H):
+    """6-state quadrotor VGP (the headline model), 41 LGL nodes, two disc keep-outs, through
+    ETOL::eMI355X setup()/solve(); feasibility checked independently with the CPU oracle."""
+    D = C.POINTER(C.c_double)
+    H.harness_solve_quadrotor.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, D, C.POINTER(C.c_int), D, D,
+                                          C.c_int, C.POINTER(C.c_int)]
+    X, U = np.zeros(6 * 64), np.zeros(2 * 64)
+    cost, M, it = C.c_double(), C.c_int(), C.c_int()
+    rc = H.harness_solve_quadrotor(40, 0.1, 2, 1e-8, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D),
+                                   U.ctypes.data_as(D), 64, C.byref(it))
+    assert rc == 0, H.harness_last_message().decode()
+    m = M.value
+    assert m == 41 and it.value < 300
+    X, U = X[:6 * m].reshape(6, m), U[:2 * m].reshape(2, m)
+    mesh = O.lgl(m)
+    recs = np.array([[1, 4.0, 3.2, 0.64, 0, 0, 0, 0], [1, 6.3, 4.4, 0.49, 0, 0, 0, 0]], dtype=float)
+    RES, _, COST = O.evaluate(1, [1.0, 0.01, 9.81, 1.0, 1.0], m, mesh, 0.0, 4.0, X[None], U[None], recs)
+    assert np.abs(RES[0, :6]).max() < 1e-7 and RES[0, 6:].max() < 1e-7 and abs(COST[0] - cost.value) < 1e-8
+    assert np.allclose(X[:, 0], [1, 1, 0, 0, 0, 0]) and np.all(np.abs(X[:3, -1] - [8, 6, 0]) <= 0.01 + 1e-9)
+    assert 380 < cost.value < 450      # ~ hover effort g^2 * tf plus the manoeuvre

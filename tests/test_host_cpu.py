@@ -153,3 +153,25 @@ def test_nlp_iteration_with_keepouts_is_feasible_and_stationary(H):
     RES, _, COST = O.evaluate(0, [], M, mesh, 0.0, 16.0, X[None], U[None], recs, (tx, ty))
     assert np.abs(RES[0, :2]).max() < 1e-8 and RES[0, 2:].max() < 1e-8 and abs(COST[0] - cost) < 1e-10
     assert np.all(np.abs(U) <= 0.5 + 1e-9) and abs(X[0, -1] - 5) <= 0.01 + 1e-9 and abs(X[1, -1] - 4) <= 0.01 + 1e-9
+
+
+def test_nlp_iteration_quadrotor_vgp(H):
+    """The headline model as an NLP: 6-state quadrotor, 25 LGL nodes, two disc keep-outs."""
+    D = C.POINTER(C.c_double)
+    H.harness_solve_quadrotor_oracle.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, D,
+                                                 C.POINTER(C.c_int), D, D, C.c_int, C.POINTER(C.c_int)]
+    H.harness_last_message.restype = C.c_char_p
+    X, U = np.zeros(6 * 64), np.zeros(2 * 64)
+    cost, M, it = C.c_double(), C.c_int(), C.c_int()
+    rc = H.harness_solve_quadrotor_oracle(os.path.join(ROOT, "oracle", "liboracle.so").encode(), 24, 0.16, 2, 1e-8, 0,
+                                          C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D), 64,
+                                          C.byref(it))
+    assert rc == 0, H.harness_last_message().decode()
+    m = M.value
+    X, U = X[:6 * m].reshape(6, m), U[:2 * m].reshape(2, m)
+    mesh = O.lgl(m)
+    recs = np.array([[1, 4.0, 3.2, 0.64, 0, 0, 0, 0], [1, 6.3, 4.4, 0.49, 0, 0, 0, 0]], dtype=float)
+    RES, _, COST = O.evaluate(1, [1.0, 0.01, 9.81, 1.0, 1.0], m, mesh, 0.0, 24 * 0.16, X[None], U[None], recs)
+    assert np.abs(RES[0, :6]).max() < 1e-7 and RES[0, 6:].max() < 1e-7 and abs(COST[0] - cost.value) < 1e-8
+    assert np.allclose(X[:, 0], [1, 1, 0, 0, 0, 0]) and np.all(np.abs(X[:3, -1] - [8, 6, 0]) <= 0.01 + 1e-9)
+    assert U[0].min() >= -1e-9 and U[0].max() <= 25 + 1e-9 and np.abs(U[1]).max() <= 1 + 1e-9
