@@ -18,3 +18,11 @@ def built():
     import __graft_entry__ as g
     g.build(quiet=True)
     return True
+
+
+@pytest.fixture(scope="session")
+def xmls(tmp_path_factory):
+    """Problem-definition XML files, generated for this session (tests/golden/gen_xml_fixtures.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import gen_xml_fixtures
+    return gen_xml_fixtures.write_all(str(tmp_path_factory.mktemp("etol_xml")))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Writes the problem-definition fixtures tests/golden/*.xml.
+"""Writes the problem-definition XML fixtures (into a directory the tests choose: tests/conftest.py
+generates them per session; nothing is committed as .xml).
 
 ocp_2d_ex1.xml / mip_2d_ex1.xml carry the DATA of the two configurations the reference ships under
 resource/configs (numbers as listed in SURVEY.md section 6 and tests/cases.py); the edge_* files
@@ -57,11 +58,26 @@ T_OCP = [dict(radius=0.5, wp=[(0, [1.51, 2.0]), (32, [2.0, 2.0])]),
 T_MIP = [dict(radius=0.5, wp=[(0, [2.0, 2.0]), (32, [2.5, 2.0])]),
          dict(radius=0.5, wp=[(0, [1.0, 4.0]), (32, [1.0, 3.0])])]
 
-if __name__ == "__main__":
-    open("ocp_2d_ex1.xml", "w").write(xml(32, 0.5, S, 0, C2, 0, Z, T_OCP))
-    open("mip_2d_ex1.xml", "w").write(xml(16, 0.5, S, 1, C4, 0, Z, T_MIP))
+def write_all(dirpath):
+    """-> dict name -> path of the XML files written into dirpath"""
+    import os
     S3 = S + [("I", -1, 1, 0, 0, 0.5)]
-    open("edge_caps.xml", "w").write(xml(8, 0.25, S3, 2, C4, 3, Z, T_OCP, nstates=2, ncontrols=3, nzones=1,
-                                         ncorners=2, nmex=1, nway=1, ndat=1,
-                                         extra='\t<unknown foo="1"><state vartype="C"/></unknown>'))
-    open("edge_no_mex_count.xml", "w").write(xml(4, 1.0, S, 0, C2, 0, [], T_OCP, nmex=None))
+    files = {
+        "ocp_2d_ex1.xml": xml(32, 0.5, S, 0, C2, 0, Z, T_OCP),
+        "mip_2d_ex1.xml": xml(16, 0.5, S, 1, C4, 0, Z, T_MIP),
+        "edge_caps.xml": xml(8, 0.25, S3, 2, C4, 3, Z, T_OCP, nstates=2, ncontrols=3, nzones=1, ncorners=2, nmex=1,
+                             nway=1, ndat=1, extra='\t<unknown foo="1"><state vartype="C"/></unknown>'),
+        "edge_no_mex_count.xml": xml(4, 1.0, S, 0, C2, 0, [], T_OCP, nmex=None),
+    }
+    out = {}
+    for name, text in files.items():
+        path = os.path.join(dirpath, name)
+        with open(path, "w") as f:
+            f.write(text)
+        out[name] = path
+    return out
+
+
+if __name__ == "__main__":
+    import sys
+    print(write_all(sys.argv[1] if len(sys.argv) > 1 else "."))

@@ -13,7 +13,6 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
-XML = os.path.join(GOLD, "ocp_2d_ex1.xml").encode()
 
 
 @pytest.fixture(scope="module")
@@ -27,22 +26,22 @@ def H(built):
     return lib
 
 
-def solve(H, with_obstacles, tol=1e-9):
+def solve(H, xml, with_obstacles, tol=1e-9):
     cap = 64
     X, U, T = np.zeros((2, cap)), np.zeros((2, cap)), np.zeros(cap)
     cost, M, iters = C.c_double(), C.c_int(), C.c_int()
     D = C.POINTER(C.c_double)
-    rc = H.harness_solve_example1(XML, with_obstacles, tol, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D),
+    rc = H.harness_solve_example1(xml.encode(), with_obstacles, tol, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D),
                                   U.ctypes.data_as(D), T.ctypes.data_as(D), cap, C.byref(iters))
     assert rc == 0, H.harness_last_message().decode()
     m = M.value
     return cost.value, X.reshape(-1)[:2 * m].reshape(2, m), U.reshape(-1)[:2 * m].reshape(2, m), T[:m], iters.value
 
 
-def test_obstacle_free_problem_reaches_the_analytic_optimum(H):
+def test_obstacle_free_problem_reaches_the_analytic_optimum(H, xmls):
     """north_star tolerance: trajectories within 1e-6 relative of the known optimum."""
     g = json.load(open(os.path.join(GOLD, "ocp2d.json")))
-    cost, X, U, T, iters = solve(H, 0)
+    cost, X, U, T, iters = solve(H, xmls["ocp_2d_ex1.xml"], 0)
     assert X.shape[1] == 33 and iters < 60
     assert abs(cost - g["cost"]) < 1e-6 * g["cost"]
     assert np.abs(U[0] - g["u"][0]).max() < 1e-6 and np.abs(U[1] - g["u"][1]).max() < 1e-6
@@ -52,9 +51,9 @@ def test_obstacle_free_problem_reaches_the_analytic_optimum(H):
     assert X[0, 0] == 1.0 and X[1, 0] == 2.0                      # hard initial state
 
 
-def test_shipped_problem_with_keepouts_solves_and_is_feasible(H):
+def test_shipped_problem_with_keepouts_solves_and_is_feasible(H, xmls):
     g = json.load(open(os.path.join(GOLD, "ocp2d.json")))
-    cost, X, U, T, iters = solve(H, 1)
+    cost, X, U, T, iters = solve(H, xmls["ocp_2d_ex1.xml"], 1)
     assert cost > g["cost"]                                       # the straight line crosses exz1
     assert cost < 2.0 * g["cost"]
     # independent feasibility check with the CPU oracle
@@ -69,9 +68,9 @@ def test_shipped_problem_with_keepouts_solves_and_is_feasible(H):
     assert abs(X[0, -1] - 5) <= 0.01 + 1e-9 and abs(X[1, -1] - 4) <= 0.01 + 1e-9
 
 
-def test_example_program_runs(built, tmp_path):
+def test_example_program_runs(built, tmp_path, xmls):
     exe = os.path.join(ROOT, "etol_amd", "lib", "etol_mi355x_example1")
-    r = subprocess.run([exe, XML.decode()], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, xmls["ocp_2d_ex1.xml"]], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "Minimization Score" in r.stdout and "Graceful Exit" in r.stdout
     rows = open(tmp_path / "state_mi355x1.csv").read().split("\n")

@@ -28,12 +28,12 @@ def H(built):
     return lib
 
 
-def load(H, name):
-    return json.loads(H.harness_load_configs(os.path.join(GOLD, name).encode()).decode())
+def load(H, path):
+    return json.loads(H.harness_load_configs(path.encode()).decode())
 
 
-def test_load_shipped_ocp(H):
-    c = load(H, "ocp_2d_ex1.xml")
+def test_load_shipped_ocp(H, xmls):
+    c = load(H, xmls["ocp_2d_ex1.xml"])
     assert (c["nsteps"], c["dt"], c["nstates"], c["ncontrols"]) == (32, 0.5, 2, 2)
     assert c["xrhorizon"] == c["urhorizon"] == c["rhorizon"] == 0
     assert c["xlower"] == [0, 0] and c["xupper"] == [7, 7] and c["x0"] == [1, 2] and c["xf"] == [5, 4]
@@ -47,27 +47,27 @@ def test_load_shipped_ocp(H):
     assert c["tracks"][1]["waypoints"] == [[0, 1.0, 4.0], [32, 1.0, 3.0]]
 
 
-def test_load_shipped_mip(H):
-    c = load(H, "mip_2d_ex1.xml")
+def test_load_shipped_mip(H, xmls):
+    c = load(H, xmls["mip_2d_ex1.xml"])
     assert (c["nsteps"], c["nstates"], c["ncontrols"], c["xrhorizon"], c["rhorizon"]) == (16, 2, 4, 1, 1)
     assert c["tracks"][0]["waypoints"][0] == [0, 2.0, 2.0]
 
 
-def test_loader_caps_and_unknown_nodes(H):
-    c = load(H, "edge_caps.xml")
+def test_loader_caps_and_unknown_nodes(H, xmls):
+    c = load(H, xmls["edge_caps.xml"])
     assert c["nstates"] == 2 and len(c["xlower"]) == 2          # third <state> beyond nstates is skipped
     assert c["ncontrols"] == 3 and len(c["ulower"]) == 3
     assert (c["xrhorizon"], c["urhorizon"], c["rhorizon"]) == (2, 3, 3)
     assert len(c["zones"]) == 1                                  # nzones=1
     assert len(c["zones"][0]) == 3                               # ncorners=2 admits size<=2 before push: 3 corners
     assert len(c["tracks"]) == 1 and c["tracks"][0]["waypoints"] == [[0, 1.51]]   # nwaypoints=1, ndatums=1
-    c = load(H, "edge_no_mex_count.xml")
+    c = load(H, xmls["edge_no_mex_count.xml"])
     assert c["tracks"] == [] and c["zones"] == []                # <mexzones> without nzones loads nothing
 
 
-def test_save_load_roundtrip(H, tmp_path):
-    a = load(H, "ocp_2d_ex1.xml")
-    b = json.loads(H.harness_roundtrip_configs(os.path.join(GOLD, "ocp_2d_ex1.xml").encode(),
+def test_save_load_roundtrip(H, tmp_path, xmls):
+    a = load(H, xmls["ocp_2d_ex1.xml"])
+    b = json.loads(H.harness_roundtrip_configs(xmls["ocp_2d_ex1.xml"].encode(),
                                                str(tmp_path / "rt.xml").encode()).decode())
     assert a == b
 
@@ -119,14 +119,14 @@ def test_dense_ldlt_inertia_and_solve(H):
 
 
 # ---- NLP iteration logic, driven by the CPU oracle as evaluator (test-only plumbing) -----------
-def _solve_with_oracle(H, with_obstacles, tol=1e-9, max_iter=400):
+def _solve_with_oracle(H, xml, with_obstacles, tol=1e-9, max_iter=400):
     D = C.POINTER(C.c_double)
     H.harness_solve_example1_oracle.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, D,
                                                 C.POINTER(C.c_int), D, D, C.c_int, C.POINTER(C.c_int)]
     H.harness_last_message.restype = C.c_char_p
     X, U = np.zeros((2, 64)), np.zeros((2, 64))
     cost, M, it = C.c_double(), C.c_int(), C.c_int()
-    rc = H.harness_solve_example1_oracle(os.path.join(GOLD, "ocp_2d_ex1.xml").encode(),
+    rc = H.harness_solve_example1_oracle(xml.encode(),
                                          os.path.join(ROOT, "oracle", "liboracle.so").encode(), with_obstacles, tol, 0,
                                          max_iter, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D),
                                          64, C.byref(it))
@@ -135,17 +135,17 @@ def _solve_with_oracle(H, with_obstacles, tol=1e-9, max_iter=400):
     return cost.value, X.reshape(-1)[:2 * m].reshape(2, m), U.reshape(-1)[:2 * m].reshape(2, m), it.value
 
 
-def test_nlp_iteration_reaches_analytic_optimum(H):
+def test_nlp_iteration_reaches_analytic_optimum(H, xmls):
     g = json.load(open(os.path.join(GOLD, "ocp2d.json")))
-    cost, X, U, iters = _solve_with_oracle(H, 0)
+    cost, X, U, iters = _solve_with_oracle(H, xmls["ocp_2d_ex1.xml"], 0)
     assert iters < 40 and abs(cost - g["cost"]) < 1e-6 * g["cost"]
     assert np.abs(U[0] - g["u"][0]).max() < 1e-6 and np.abs(U[1] - g["u"][1]).max() < 1e-6
 
 
-def test_nlp_iteration_with_keepouts_is_feasible_and_stationary(H):
+def test_nlp_iteration_with_keepouts_is_feasible_and_stationary(H, xmls):
     import cases
     g = json.load(open(os.path.join(GOLD, "ocp2d.json")))
-    cost, X, U, iters = _solve_with_oracle(H, 1)
+    cost, X, U, iters = _solve_with_oracle(H, xmls["ocp_2d_ex1.xml"], 1)
     assert iters < 200 and g["cost"] < cost < 2 * g["cost"]
     M = 33
     mesh = O.lgl(M)
