@@ -289,3 +289,103 @@ def test_device_pointer_form_matches_host_form(built):
     assert np.array_equal(COST.cpu().numpy(), got[2])
     with pytest.raises(ValueError):
         ev.eval_dev(dX[:1], dU, RES, VALS, COST)
+
+
+def test_random_shapes_against_oracle(built):
+    """Seeded sweep over ragged shapes: node counts on and off every tile size, batch sizes on and
+    off the 16-instance tile, every keep-out kind, shared and per-instance tables, both models
+    with second derivatives, sign flip."""
+    import etol_amd as E
+    from etol_amd import workloads as W
+    rng = np.random.default_rng(20251003)
+    for trial in range(14):
+        model = [E.MODEL_POINTMASS2D, E.MODEL_QUADROTOR2D][trial % 2]
+        M = int(rng.choice([2, 3, 17, 64, 127, 128, 130, 256, 384]))
+        B = int(rng.choice([1, 2, 15, 16, 17, 40]))
+        npth = int(rng.choice([0, 1, 4, 7]))
+        per_inst = bool(rng.integers(2))
+        maximize = bool(rng.integers(2))
+        t0, tf = float(rng.uniform(-1, 1)), float(rng.uniform(2, 20))
+        ev = E.Evaluator(0)
+        ev.set_mesh(M, t0, tf)
+        params = W.QUAD_PARAMS if model == E.MODEL_QUADROTOR2D else []
+        ev.set_model(model, params, maximize=maximize)
+        ev.set_batch(B)
+        ns = 6 if model == E.MODEL_QUADROTOR2D else 2
+        X = rng.uniform(-2, 8, (B, ns, M))
+        U = rng.uniform(-1, 12, (B, 2, M))
+        nsets = B if per_inst else 1
+        ntracks = 0
+        recs = np.zeros((nsets, npth, 8))
+        for s in range(nsets):
+            for j in range(npth):
+                kind = int(rng.integers(3))
+                if kind == E.PATH_ELLIPSE:
+                    tt = rng.uniform(-3, 3)
+                    a2 = rng.uniform(0.05, 2.0)
+                    recs[s, j] = [kind, rng.uniform(0, 6), rng.uniform(0, 6), np.cos(tt), np.sin(tt), a2, 0.2 * a2, 0]
+                elif kind == E.PATH_DISC:
+                    recs[s, j] = [kind, rng.uniform(0, 6), rng.uniform(0, 6), rng.uniform(0.1, 2), 0, 0, 0, 0]
+                else:
+                    recs[s, j] = [kind, 0, rng.uniform(0.1, 2), 0, 0, 0, 0, 0]   # track index set below
+        # tracks: give every TRACK row of set 0 its own track index; other sets reuse the indices in order
+        if npth:
+            is_trk = recs[:, :, 0] == E.PATH_TRACK
+            ntracks = int(is_trk.sum(1).max())
+            for s in range(nsets):
+                recs[s, is_trk[s], 1] = np.arange(int(is_trk[s].sum()))
+        tracks = None
+        if ntracks:
+            tsets = nsets
+            tx = rng.uniform(0, 6, (tsets, ntracks, M))
+            ty = rng.uniform(0, 6, (tsets, ntracks, M))
+            ev.set_tracks(tx, ty)
+            tracks = (tx, ty)
+        if npth:
+            ev.set_path(recs, 0, 1)
+        got = ev.eval_host(X, U)
+        ref = O.evaluate(model, params, M, (ev.tau, ev.w, ev.D), t0, tf, X, U, recs if npth else None, tracks,
+                         maximize=maximize)
+        check(dict(X=X, U=U), ev, got, ref)
+        lamF = rng.standard_normal((B, ns, M))
+        lamC = rng.standard_normal((B, npth, M))
+        H = ev.hess_host(X, U, lamF, lamC, sigma=1.3)
+        Href = O.hessian(model, params, M, (ev.tau, ev.w, ev.D), t0, tf, X, U, lamF, lamC, 1.3, recs if npth else None,
+                         tracks, maximize=maximize)
+        assert np.abs(H - Href).max() / (np.abs(Href).max() + 1.0) < 1e-6, f"trial {trial}"
+        ev.close()
+
+
+def test_abi_error_paths(built):
+    """Wrong call order and bad arguments come back as status codes with a message, never a crash."""
+    import ctypes as C
+    import etol_amd as E
+    from etol_amd import _lib as L
+    lib = L.load()
+    ctx = C.c_void_p()
+    assert lib.emi_create(99, C.byref(ctx)) == 1                     # no such device: EMI_ERR_ARG
+    assert lib.emi_create(0, C.byref(ctx)) == 0
+    z = (C.c_double * 4)()
+    assert lib.emi_set_batch(ctx, 4) == 2                            # before the mesh: EMI_ERR_STATE
+    assert b"emi_set_mesh" in lib.emi_last_error(ctx)
+    assert lib.emi_eval_dev(ctx, None, None, None, None, None, 3) == 2
+    tau, w, D = E.lgl(8)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert lib.emi_set_mesh(ctx, 8, dp(tau), dp(w), dp(D), 1.0, 1.0) == 1      # tf must exceed t0
+    assert lib.emi_set_mesh(ctx, 8, dp(tau), dp(w), dp(D), 0.0, 2.0) == 0
+    assert lib.emi_set_path(ctx, 1, 1, z, 0, 1) == 2                 # before the model
+    assert lib.emi_set_model(ctx, 1, None, 0, 0) == 1                # quadrotor wants 5 parameters
+    assert lib.emi_set_model(ctx, 0, None, 0, 0) == 0
+    bad = np.zeros(8); bad[0] = 9
+    assert lib.emi_set_path(ctx, 1, 1, dp(bad), 0, 1) == 1           # unknown row kind
+    assert lib.emi_set_path(ctx, 1, 1, dp(np.zeros(8)), 0, 0) == 1   # px == py
+    assert lib.emi_set_batch(ctx, 0) == 1
+    assert lib.emi_set_batch(ctx, 3) == 0
+    assert lib.emi_set_path(ctx, 1, 2, dp(np.zeros(16)), 0, 1) == 0  # 2 sets for a batch of 3 ...
+    assert lib.emi_eval_dev(ctx, C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), 3) == 2
+    assert b"sets" in lib.emi_last_error(ctx)                        # ... is caught before any launch
+    assert lib.emi_set_option(ctx, b"no_such_option", 1) == 1
+    assert lib.emi_eval_dev(ctx, None, None, None, None, None, 0) in (1, 2)
+    assert lib.emi_hess_dev(ctx, None, None, None, None, 1.0, None) in (1, 2)
+    assert lib.emi_destroy(ctx) == 0
+    assert lib.emi_destroy(None) == 1
