@@ -7,6 +7,7 @@
 // no host counterpart here: they are the kernels behind include/emi355x.h.
 #include <ETOL/eMI355X.hpp>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -149,13 +150,9 @@ void eMI355X::traceCallbacks() {
                     std::to_string(i) + " of the objective's model");
         }
         P.path_records.clear();
-        P.track_x.clear();
-        P.track_y.clear();
+        P.tracks.clear();
         P.ntracks = 0;
-        std::vector<std::array<double, EMI_PATH_REC>> track_recs_pending;
         bool have_xy = false;
-        std::vector<double> node_t(P.nodes);
-        for (size_t k = 0; k < P.nodes; ++k) node_t[k] = P.t0 + (P.tf - P.t0) / 2.0 * (P.tau[k] + 1.0);
         for (size_t c = 0; c < _constraints.size(); ++c) {
             vector_t params = {std::string()};
             std::vector<std::string> pnames = {std::string("")};
@@ -169,11 +166,8 @@ void eMI355X::traceCallbacks() {
             have_xy = true;
             for (const auto& r : blk.rows) P.path_records.insert(P.path_records.end(), r.begin(), r.end());
             for (const mi355x::TrackTable& tb : blk.tracks) {
-                std::vector<double> xc(P.nodes), yc(P.nodes);
-                must(emi_track_centres((int)tb.t.size(), tb.t.data(), tb.x.data(), tb.y.data(), (int)P.nodes,
-                                       node_t.data(), xc.data(), yc.data()), nullptr, "emi_track_centres");
-                P.track_x.insert(P.track_x.end(), xc.begin(), xc.end());
-                P.track_y.insert(P.track_y.end(), yc.begin(), yc.end());
+                if (tb.t.size() < 2) die("a moving exclusion zone needs at least two waypoints");
+                P.tracks.push_back(tb);
                 std::array<double, EMI_PATH_REC> rec{};
                 rec[0] = (double)EMI_PATH_TRACK;
                 rec[1] = (double)P.ntracks++;
@@ -228,12 +222,9 @@ void eMI355X::setup() {
     P.t0 = 0.;
     P.tf = getNSteps() * getDt();                    // fixed horizon, ePSOPT.cpp:151-154
     if (P.nodes < 2 || !(P.tf > 0)) die("nsteps and dt must be positive");
-    P.tau.resize(P.nodes);
-    P.w.resize(P.nodes);
-    P.D.resize(P.nodes * P.nodes);
-    must(emi_lgl((int)P.nodes, P.tau.data(), P.w.data(), P.D.data()), nullptr, "emi_lgl");
 
     traceCallbacks();
+    setMesh(P.nodes);
     int ns = 0, nc = 0, npar = 0;
     if (emi_model_dims(P.model, &ns, &nc, &npar) != EMI_OK) die("unknown device model");
     if ((size_t)ns != P.nstates || (size_t)nc != P.ncontrols)
@@ -245,11 +236,46 @@ void eMI355X::setup() {
     addBounds();
 
     _dev.reset(new Device());
-    const int st = emi_create(_algorithm.device, &_dev->ctx);
-    if (st != EMI_OK)
-        die(std::string("cannot open MI355X device ") + std::to_string(_algorithm.device) + ": " +
-            emi_status_string(st) + " (there is no CPU fallback)");
-    emi_ctx_t c = _dev->ctx;
+    configureDevice(_dev.get());
+
+    // algorithm defaults of ePSOPT::setup (:62-72) that have a meaning here
+    _algorithm.nlp_iter_max = 200;
+    _algorithm.nlp_tolerance = 1.e-6;
+    _algorithm.mesh_refinement = "automatic";
+    _algorithm.mr_max_iterations = 10;
+    _algorithm.ode_tolerance = 1.e-4;
+    _algorithm.print_level = 0;
+}
+
+// LGL nodes / weights / D for `nodes` collocation points and the moving-zone centres at the
+// node times (PSOPT builds the same per mesh-refinement iteration).
+void eMI355X::setMesh(size_t nodes) {
+    mi355x::Prob& P = _problem;
+    P.nodes = nodes;
+    P.tau.resize(nodes);
+    P.w.resize(nodes);
+    P.D.resize(nodes * nodes);
+    must(emi_lgl((int)nodes, P.tau.data(), P.w.data(), P.D.data()), nullptr, "emi_lgl");
+    std::vector<double> node_t(nodes);
+    for (size_t k = 0; k < nodes; ++k) node_t[k] = P.t0 + (P.tf - P.t0) / 2.0 * (P.tau[k] + 1.0);
+    P.track_x.assign(P.tracks.size() * nodes, 0.0);
+    P.track_y.assign(P.tracks.size() * nodes, 0.0);
+    for (size_t i = 0; i < P.tracks.size(); ++i) {
+        const mi355x::TrackTable& tb = P.tracks[i];
+        must(emi_track_centres((int)tb.t.size(), tb.t.data(), tb.x.data(), tb.y.data(), (int)nodes, node_t.data(),
+                               &P.track_x[i * nodes], &P.track_y[i * nodes]), nullptr, "emi_track_centres");
+    }
+}
+
+void eMI355X::configureDevice(Device* dev) {
+    mi355x::Prob& P = _problem;
+    if (!dev->ctx) {
+        const int st = emi_create(_algorithm.device, &dev->ctx);
+        if (st != EMI_OK)
+            die(std::string("cannot open MI355X device ") + std::to_string(_algorithm.device) + ": " +
+                emi_status_string(st) + " (there is no CPU fallback)");
+    }
+    emi_ctx_t c = dev->ctx;
     must(emi_set_mesh(c, (int)P.nodes, P.tau.data(), P.w.data(), P.D.data(), P.t0, P.tf), c, "emi_set_mesh");
     must(emi_set_model(c, P.model, P.model_params.data(), (int)P.model_params.size(), isMaximized() ? 1 : 0), c,
          "emi_set_model");
@@ -257,11 +283,65 @@ void eMI355X::setup() {
     if (P.ntracks)
         must(emi_set_tracks(c, (int)P.ntracks, 1, P.track_x.data(), P.track_y.data()), c, "emi_set_tracks");
     must(emi_set_path(c, (int)P.npath, 1, P.path_records.data(), (int)P.px, (int)P.py), c, "emi_set_path");
+}
 
-    // algorithm defaults of ePSOPT::setup (:62-72) that have a meaning here
-    _algorithm.nlp_iter_max = 200;
-    _algorithm.nlp_tolerance = 1.e-6;
-    _algorithm.print_level = 0;
+namespace {
+// Barycentric Lagrange interpolation from the LGL nodes (tau, w) to the points t2.  For LGL
+// nodes the barycentric weights are (-1)^j sqrt(w_j) up to a common factor, because
+// w_j = 2 / (N (N+1) P_N(tau_j)^2) and the Lagrange weights are proportional to 1 / P_N(tau_j).
+void interp_lgl(const std::vector<double>& tau, const std::vector<double>& w, const double* v, size_t M,
+                const std::vector<double>& t2, double* out) {
+    for (size_t q = 0; q < t2.size(); ++q) {
+        double num = 0, den = 0;
+        bool hit = false;
+        for (size_t j = 0; j < M; ++j) {
+            const double d = t2[q] - tau[j];
+            if (d == 0.0) { out[q] = v[j]; hit = true; break; }
+            const double lam = ((j & 1) ? -1.0 : 1.0) * std::sqrt(w[j]) / d;
+            num += lam * v[j];
+            den += lam;
+        }
+        if (!hit) out[q] = num / den;
+    }
+}
+}  // namespace
+
+// Relative ODE error of the solution z on the current mesh: its interpolant is put on the LGL
+// grid with twice the intervals and the collocation defect there is evaluated ON THE DEVICE
+// (values-only pass).  error_i = max_k |defect_ik| / (h (1 + max_k |xdot_ik|)).
+double eMI355X::odeError(const std::vector<double>& z, std::vector<double>* z_fine, size_t* nodes_fine) {
+    mi355x::Prob& P = _problem;
+    const size_t ns = P.nstates, nc = P.ncontrols, nv = ns + nc, M = P.nodes, M2 = 2 * M - 1;
+    const std::vector<double> tau = P.tau, w = P.w;          // coarse mesh (P is re-meshed below)
+    const std::vector<double> D_keep = P.D, tx_keep = P.track_x, ty_keep = P.track_y;
+    setMesh(M2);
+    std::vector<double> zf(nv * M2);
+    for (size_t v = 0; v < nv; ++v) interp_lgl(tau, w, &z[v * M], M, P.tau, &zf[v * M2]);
+    for (size_t j = 0; j < nc; ++j)      // the interpolant of a bounded control may overshoot: clip
+        for (size_t k = 0; k < M2; ++k)
+            zf[(ns + j) * M2 + k] = std::min(std::max(zf[(ns + j) * M2 + k], P.control_lower[j]), P.control_upper[j]);
+    Device fine;
+    configureDevice(&fine);
+    std::vector<double> RES((ns + P.npath) * M2), cost(1);
+    must(emi_eval_host(fine.ctx, zf.data(), zf.data() + ns * M2, RES.data(), nullptr, cost.data(),
+                       EMI_EVAL_ALL | EMI_EVAL_NOJAC), fine.ctx, "emi_eval_host (ODE error)");
+    const double h = (P.tf - P.t0) / 2.0;
+    double err = 0;
+    for (size_t i = 0; i < ns; ++i) {
+        double dmax = 0, rate = 0;
+        for (size_t k = 0; k < M2; ++k) {
+            dmax = std::max(dmax, std::fabs(RES[i * M2 + k]));
+            double dx = 0;
+            for (size_t j = 0; j < M2; ++j) dx += P.D[k * M2 + j] * zf[i * M2 + j];
+            rate = std::max(rate, std::fabs(dx));
+        }
+        err = std::max(err, dmax / (h * (1.0 + rate / h)));
+    }
+    if (z_fine) *z_fine = zf;
+    if (nodes_fine) *nodes_fine = M2;
+    // back to the coarse mesh (the caller decides whether to adopt a finer one)
+    P.nodes = M; P.tau = tau; P.w = w; P.D = D_keep; P.track_x = tx_keep; P.track_y = ty_keep;
+    return err;
 }
 
 namespace mi355x {
@@ -357,17 +437,50 @@ std::vector<double> initial_guess(const Prob& P) {
 void eMI355X::solve() {
     if (!_dev || !_dev->ctx) die("solve() called before setup()");
     mi355x::Prob& P = _problem;
-    const size_t ns = P.nstates, nc = P.ncontrols, M = P.nodes;
-
-    mi355x::NlpProblem nlp = mi355x::make_nlp(P, _dev.get());
-    const std::vector<double> z0 = mi355x::initial_guess(P);
+    const size_t ns = P.nstates, nc = P.ncontrols;
 
     mi355x::NlpOptions opt;
     opt.tol = _algorithm.nlp_tolerance;
     opt.max_iter = _algorithm.nlp_iter_max;
     opt.print_level = _algorithm.print_level;
     opt.max_cpu_time = _algorithm.max_cpu_time;
-    const mi355x::NlpResult r = mi355x::solve_nlp(nlp, opt, z0);
+
+    // PSOPT's mesh refinement ("automatic", ePSOPT.cpp:69-71): solve, estimate the ODE error,
+    // add nodes and re-solve from the interpolated solution until the tolerance is met.
+    mi355x::NlpResult r;
+    const bool refine = _algorithm.mesh_refinement == "automatic";
+    _solution.mesh_iterations = 0;
+    _solution.ode_error = 0;
+    for (int mr = 0;; ++mr) {
+        mi355x::NlpProblem nlp = mi355x::make_nlp(P, _dev.get());
+        r = mi355x::solve_nlp(nlp, opt, mi355x::initial_guess(P));
+        ++_solution.mesh_iterations;
+        if (!r.ok || !refine) break;
+        std::vector<double> zf;
+        size_t M2 = 0;
+        _solution.ode_error = odeError(r.z, &zf, &M2);
+        if (_algorithm.print_level >= 5)
+            printf("mesh iteration %d: %zu nodes, cost %.10e, relative ODE error %.3e\n", mr, P.nodes, r.cost,
+                   _solution.ode_error);
+        if (_solution.ode_error <= _algorithm.ode_tolerance || mr + 1 >= _algorithm.mr_max_iterations) break;
+        const size_t Mnew = std::min((size_t)_algorithm.mr_max_nodes, P.nodes + std::max<size_t>(4, (P.nodes - 1) / 2));
+        if (Mnew <= P.nodes) break;
+        // warm start: the solution interpolated to the new nodes
+        const std::vector<double> tau = P.tau, w = P.w;
+        const size_t M = P.nodes;
+        setMesh(Mnew);
+        configureDevice(_dev.get());
+        P.guess_states.assign(ns * Mnew, 0.0);
+        P.guess_controls.assign(nc * Mnew, 0.0);
+        for (size_t i = 0; i < ns; ++i) interp_lgl(tau, w, &r.z[i * M], M, P.tau, &P.guess_states[i * Mnew]);
+        for (size_t j = 0; j < nc; ++j) {
+            interp_lgl(tau, w, &r.z[(ns + j) * M], M, P.tau, &P.guess_controls[j * Mnew]);
+            for (size_t k = 0; k < Mnew; ++k)
+                P.guess_controls[j * Mnew + k] =
+                    std::min(std::max(P.guess_controls[j * Mnew + k], P.control_lower[j]), P.control_upper[j]);
+        }
+    }
+    const size_t M = P.nodes;
 
     _solution.error_flag = r.ok ? 0 : 1;
     _solution.error_msg = r.msg;

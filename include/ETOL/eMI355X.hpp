@@ -28,7 +28,10 @@ struct Alg {
     std::string derivatives = "analytic (device kernels)";
     std::string hessian = "exact";
     std::string collocation_method = "Legendre";   // Legendre-Gauss-Lobatto, as PSOPT's "Legendre"
-    std::string mesh_refinement = "none";          // fixed grid of nSteps+1 nodes
+    std::string mesh_refinement = "automatic";     // "automatic" or "none" (ePSOPT.cpp:69)
+    int mr_max_iterations = 10;                    // ePSOPT.cpp:70
+    double ode_tolerance = 1.e-4;                  // ePSOPT.cpp:71
+    int mr_max_nodes = 129;                        // the host KKT factorisation is dense: keep it small
     int nlp_iter_max = 200;
     double nlp_tolerance = 1.e-6;
     double max_cpu_time = 1.e9;
@@ -43,6 +46,8 @@ struct Sol {
     int nlp_iterations = 0;
     int evaluations = 0;
     double kkt_error = 0, constraint_violation = 0;
+    int mesh_iterations = 0;        // NLP solves performed (1 = no refinement happened)
+    double ode_error = 0;           // relative ODE error estimate on the doubled grid
     size_t nstates = 0, ncontrols = 0, nodes = 0;
     std::vector<double> states;     // [nstates][nodes]
     std::vector<double> controls;   // [ncontrols][nodes]
@@ -59,6 +64,7 @@ struct Prob {
     std::vector<double> tau, w, D;                 // LGL mesh
     std::vector<double> path_records;              // [npath][EMI_PATH_REC]
     std::vector<double> track_x, track_y;          // [ntracks][nodes]
+    std::vector<TrackTable> tracks;                // waypoint tables (re-tabulated when the mesh changes)
     size_t ntracks = 0, px = 0, py = 1;
     std::vector<double> state_lower, state_upper, control_lower, control_upper;
     std::vector<double> path_lower, path_upper;
@@ -93,6 +99,9 @@ class eMI355X : public TrajectoryOptimizer {
     void traceCallbacks();               // calls every f_t once (see eMI355X_Types.hpp)
     void addBounds();
     void getTraj();
+    void setMesh(size_t nodes);          // LGL mesh + track tables for this node count
+    void configureDevice(Device* dev);   // mesh, model, batch of one, path table -> device context
+    double odeError(const std::vector<double>& z, std::vector<double>* z_fine, size_t* nodes_fine);
 };
 
 }  // namespace ETOL

@@ -162,6 +162,7 @@ extern "C" int harness_solve_example1_oracle(const char* xml, const char* oracle
 
 // ---- quadrotor VGP (the headline model) as an ETOL problem set up through the public API --------
 namespace {
+double g_quad_tau_max = 1.0;   // torque bound of the quadrotor test problem (harness_set_quad_tau_max)
 struct QuadSetup {
     std::vector<std::array<double, 3>> discs;
     ETOL::f_t obj, obs;
@@ -172,7 +173,7 @@ void configure_quadrotor(ETOL::TrajectoryOptimizer* t, QuadSetup& q, int nsteps,
     t->setNSteps(nsteps); t->setDt(dt); t->setNStates(6); t->setNControls(2);
     t->setX0({1, 1, 0, 0, 0, 0}); t->setXf({8, 6, 0, 0, 0, 0}); t->setXtol({0.01, 0.01, 0.01, 0.05, 0.05, 0.05});
     t->setXlower({0, 0, -1.2, -6, -6, -4}); t->setXupper({10, 10, 1.2, 6, 6, 4});
-    t->setUlower({0, -1}); t->setUupper({25, 1});
+    t->setUlower({0, -g_quad_tau_max}); t->setUupper({25, g_quad_tau_max});
     t->setMaximize(false);
     const std::array<double, 3> all[3] = {{4.0, 3.2, 0.8}, {6.3, 4.4, 0.7}, {2.5, 1.2, 0.4}};
     for (int i = 0; i < ndiscs; ++i) q.discs.push_back(all[i]);
@@ -198,9 +199,12 @@ void configure_quadrotor(ETOL::TrajectoryOptimizer* t, QuadSetup& q, int nsteps,
 }
 }  // namespace
 
+extern "C" void harness_set_quad_tau_max(double v) { g_quad_tau_max = v; }
+
 // Solve the quadrotor VGP on the GPU through ETOL::eMI355X.  Outputs X[6][M], U[2][M].
-extern "C" int harness_solve_quadrotor(int nsteps, double dt, int ndiscs, double tol, int print_level, double* cost,
-                                       int* M, double* X, double* U, int cap, int* iters) {
+extern "C" int harness_solve_quadrotor(int nsteps, double dt, int ndiscs, double tol, int print_level, int refine,
+                                       double ode_tol, double* cost, int* M, double* X, double* U, int cap, int* iters,
+                                       int* mesh_iters, double* ode_err) {
     ETOL::eMI355X solver;
     QuadSetup q;
     configure_quadrotor(&solver, q, nsteps, dt, ndiscs);
@@ -208,9 +212,13 @@ extern "C" int harness_solve_quadrotor(int nsteps, double dt, int ndiscs, double
     solver.getAlgorithm()->nlp_tolerance = tol;
     solver.getAlgorithm()->print_level = print_level;
     solver.getAlgorithm()->nlp_iter_max = 400;
+    solver.getAlgorithm()->mesh_refinement = refine ? "automatic" : "none";
+    solver.getAlgorithm()->ode_tolerance = ode_tol;
     solver.solve();
     const mx::Sol* s = solver.getSolution();
     *iters = s->nlp_iterations;
+    *mesh_iters = s->mesh_iterations;
+    *ode_err = s->ode_error;
     g_out = s->error_msg;
     if (s->error_flag) return 1;
     const int m = (int)s->nodes;
