@@ -37,12 +37,14 @@ $(LIBDIR)/emi_kernels.o: $(CSRC)/emi_kernels.hip $(CSRC)/emi_kernels.hpp $(CSRC)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(LIBDIR)/emi_symdefect.o: $(CSRC)/emi_symdefect.hip $(CSRC)/emi_kernels.hpp $(CSRC)/emi_models.hpp include/emi355x.h | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(LIBDIR)/emi_defect_f32.o: $(CSRC)/emi_defect_f32.hip $(CSRC)/emi_kernels.hpp $(CSRC)/emi_models.hpp include/emi355x.h | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(LIBDIR)/emi_api.o: $(CSRC)/emi_api.hip $(CSRC)/emi_kernels.hpp $(CSRC)/emi_models.hpp include/emi355x.h | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(LIBDIR)/emi_host.o: $(CSRC)/emi_host.cpp include/emi355x.h | $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(LIBDIR)/libemi355x.so: $(LIBDIR)/emi_kernels.o $(LIBDIR)/emi_symdefect.o $(LIBDIR)/emi_api.o $(LIBDIR)/emi_host.o
+$(LIBDIR)/libemi355x.so: $(LIBDIR)/emi_kernels.o $(LIBDIR)/emi_symdefect.o $(LIBDIR)/emi_defect_f32.o $(LIBDIR)/emi_api.o $(LIBDIR)/emi_host.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 HOST_SRC := $(HOST)/TrajectoryOptimizer.cpp $(HOST)/eMI355X.cpp $(HOST)/emi_nlp.cpp

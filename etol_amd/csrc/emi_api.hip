@@ -296,7 +296,26 @@ int emi_set_mesh(emi_ctx_t c, int M, const double* tau, const double* w, const d
     if ((st = upload_real(c, c->d_w, w, M))) return st;
     if ((st = upload_real(c, c->d_t, nt.data(), M))) return st;
     if ((st = upload_real(c, c->d_Ddiag, dd.data(), M))) return st;
-    if ((st = upload_real(c, c->d_D, D, (size_t)M * M))) return st;
+    if (c->f32) {
+        // f32 copy of D whose rows sum to EXACTLY zero in f32 arithmetic terms: off-diagonals rounded,
+        // diagonal = -(f64 sum of the rounded off-diagonals), rounded.  The shifted-difference form of
+        // the f32 defect kernel (emi_defect_f32.hip) relies on it.
+        std::vector<float> Df((size_t)M * M);
+        for (int i = 0; i < M; ++i) {
+            double rs = 0.0;
+            for (int j = 0; j < M; ++j) {
+                if (j == i) continue;
+                Df[(size_t)i * M + j] = (float)D[(size_t)i * M + j];
+                rs += (double)Df[(size_t)i * M + j];
+            }
+            Df[(size_t)i * M + i] = (float)(-rs);
+        }
+        if ((st = ensure(c, c->d_D, Df.size() * 4))) return st;
+        HIP_TRY(c, hipMemcpyAsync(c->d_D.p, Df.data(), Df.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else if ((st = upload_real(c, c->d_D, D, (size_t)M * M))) {
+        return st;
+    }
     // even/odd split of D for the fused kernel: valid only for an exactly centro-antisymmetric D
     c->symmetric = false;
     if (M % 2 == 0 && !c->f32) {
@@ -545,7 +564,8 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         if (c->f32) {
             emi::DefectArgsF32 a{(const float*)dX, (const float*)c->d_D.p, (float*)dRES, c->B * c->ns,
                                  c->M, c->ns, nres_of(c)};
-            HIP_TRY(c, emi::launch_defect_f32(a, c->stream));
+            if (emi::defect_f32_mfma_supported(c->M) && c->allow_fused) HIP_TRY(c, emi::launch_defect_f32_mfma(a, c->stream));
+            else HIP_TRY(c, emi::launch_defect_f32(a, c->stream));
         } else {
             emi::DefectArgs a{(const double*)dX, (const double*)c->d_D.p, (double*)dRES, c->B * c->ns,
                               c->M, c->ns, nres_of(c)};

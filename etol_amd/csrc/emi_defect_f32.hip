@@ -1,0 +1,139 @@
+// emi_defect_f32.hip -- K4 for fp32 contexts (BASELINE config 5): defect rows += D.X on the f32
+// matrix cores (v_mfma_f32_32x32x2_f32), in a form that survives single precision.
+//
+// A plain f32 GEMM of D.X is useless at M = 4096: |D_ij| reaches N(N+1)/4 ~ 4e6 and the terms
+// cancel to O(1), so rounding X and D to f32 alone costs ~6e-8 * sum|D_ij x_j| ~ O(1) absolute.
+// Because every row of D sums to zero, any constant may be subtracted from x first:
+//        (D x)_i = sum_j D_ij (x_j - s)            for every s.
+// Each 32-column output tile uses s = x at the tile's centre node: near the diagonal, where D is
+// large, x_j - s is small (and exact in f32 by Sterbenz), so the products are O(x') instead of
+// O(N^2 x).  The shift is applied when the A fragment is read from LDS (one v_sub per MFMA), so
+// the contraction is still an ordinary MFMA GEMM.  The f32 copy of D is built on the host with
+// an EXACTLY zero row sum in f32 (diagonal = -(f64 sum of the rounded off-diagonals)), which is
+// what makes the shift free of bias (emi_api.hip, emi_set_mesh).
+//
+// Workgroup tile 64 rows x 128 columns, K tile 32, 4 waves as 2 x 2 (each 32 rows x 64 columns =
+// two 32x32 accumulators), double-buffered LDS with register prefetch; LDS rows padded to 33 floats
+// (conflict-free ds_read_b32 of the [row = lane & 31][k = lane >> 5] fragments).
+// Requires M % 128 == 0; other shapes take the f64-accumulating fallback in emi_kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include "emi_kernels.hpp"
+
+namespace emi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 2) void emi_defect_f32_mfma_kernel(DefectArgsF32 a) {
+    constexpr int TM = 64, TN = 128, BK = 32, LDK = BK + 1;
+    __shared__ float As[2][TM][LDK];
+    __shared__ float Bs[2][TN][LDK];
+
+    const int R = a.R, M = a.M;
+    const int ntiles = M / TN;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: workgroups that share a D column panel share blockIdx % 8
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    const int mtiles = gridDim.x / ntiles;
+    const int ntile = bid / mtiles, mtile = bid - ntile * mtiles;
+    const int m0 = mtile * TM, n0 = ntile * TN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int l32 = lane & 31, lk = lane >> 5;
+
+    // per-lane shift of each of the wave's two column tiles: x[row][centre node of the tile]
+    const int row = m0 + wr * 32 + l32;
+    float shift[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        shift[c] = row < R ? a.X[(size_t)row * M + n0 + wc * 64 + c * 32 + 16] : 0.f;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+    float4 pa[2], pb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int idx = tid + 256 * p, r = idx >> 3, c4 = idx & 7;
+            const float4 v = (m0 + r < R) ? *reinterpret_cast<const float4*>(a.X + (size_t)(m0 + r) * M + k0 + 4 * c4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            pa[p] = make_float4(v.x, v.y, v.z, v.w);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = tid + 256 * p, r = idx >> 3, c4 = idx & 7;
+            const float4 v = *reinterpret_cast<const float4*>(a.D + (size_t)(n0 + r) * M + k0 + 4 * c4);
+            pb[p] = make_float4(v.x, v.y, v.z, v.w);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int idx = tid + 256 * p, r = idx >> 3, c4 = idx & 7;
+            float* d = &As[buf][r][4 * c4];
+            d[0] = pa[p].x; d[1] = pa[p].y; d[2] = pa[p].z; d[3] = pa[p].w;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int idx = tid + 256 * p, r = idx >> 3, c4 = idx & 7;
+            float* d = &Bs[buf][r][4 * c4];
+            d[0] = pb[p].x; d[1] = pb[p].y; d[2] = pb[p].z; d[3] = pb[p].w;
+        }
+    };
+
+    const int nkt = M / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) gload((kt + 1) * BK);
+        const float* Ar = &As[cur][wr * 32 + l32][lk];
+        const float* B0 = &Bs[cur][wc * 64 + l32][lk];
+        const float* B1 = &Bs[cur][wc * 64 + 32 + l32][lk];
+#pragma unroll 8
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const float av = Ar[2 * ks];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av - shift[0], B0[2 * ks], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av - shift[1], B1[2 * ks], acc[1], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) {
+            lstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // C/D map of the 32x32 f32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n = n0 + wc * 64 + c * 32 + l32;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = m0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;
+            if (r < R) {
+                const int inst = r / a.ns, st = r - inst * a.ns;
+                float* o = a.RES + ((size_t)inst * a.nres + st) * M + n;
+                *o += acc[c][i];
+            }
+        }
+    }
+}
+
+bool defect_f32_mfma_supported(int M) { return M >= 128 && M % 128 == 0; }
+
+hipError_t launch_defect_f32_mfma(const DefectArgsF32& a, hipStream_t s) {
+    const int mtiles = (a.R + 63) / 64, ntiles = a.M / 128;
+    dim3 grid(mtiles * ntiles), block(256);
+    hipLaunchKernelGGL(emi_defect_f32_mfma_kernel, grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace emi

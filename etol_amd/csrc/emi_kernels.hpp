@@ -88,6 +88,8 @@ hipError_t launch_nodes(int model, const NodeArgs<T>& a, bool jac, bool defect_r
 template <typename T> hipError_t launch_hess(int model, const HessArgs<T>& a, hipStream_t s);
 hipError_t launch_defect_f64(const DefectArgs& a, hipStream_t s);
 hipError_t launch_defect_f32(const DefectArgsF32& a, hipStream_t s);
+bool defect_f32_mfma_supported(int M);
+hipError_t launch_defect_f32_mfma(const DefectArgsF32& a, hipStream_t s);
 hipError_t defect_f64_set_attr();
 template <typename T>
 hipError_t launch_cost_finish(const T* part, T* cost, int B, int nchunks, T scale, hipStream_t s);

@@ -71,7 +71,7 @@ def main():
     rows.append(run("c4 shard: 128 scenarios of c3 per GPU", E.MODEL_QUADROTOR2D, W.QUAD_PARAMS, 1024, 128, 20))
     print(json.dumps(rows[-1]), flush=True)
     for B in (16, 256):
-        rows.append(run("c5 fixed wing N=4096 (f32 storage, f64-accumulated D.X, untuned)", E.MODEL_FIXEDWING12,
+        rows.append(run("c5 fixed wing N=4096 (f32, shifted-difference D.X on f32 MFMA)", E.MODEL_FIXEDWING12,
                         W.FW_PARAMS, 4096, B, 0, f32=True, steps=5))
         print(json.dumps(rows[-1]), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
