@@ -47,7 +47,7 @@ $(LIBDIR)/emi_host.o: $(CSRC)/emi_host.cpp include/emi355x.h | $(LIBDIR)
 $(LIBDIR)/libemi355x.so: $(LIBDIR)/emi_kernels.o $(LIBDIR)/emi_symdefect.o $(LIBDIR)/emi_defect_f32.o $(LIBDIR)/emi_api.o $(LIBDIR)/emi_host.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
-HOST_SRC := $(HOST)/TrajectoryOptimizer.cpp $(HOST)/eMI355X.cpp $(HOST)/emi_nlp.cpp
+HOST_SRC := $(HOST)/TrajectoryOptimizer.cpp $(HOST)/eMI355X.cpp $(HOST)/emi_nlp.cpp $(HOST)/emi_trace.cpp
 HOST_HDR := $(wildcard include/ETOL/*.hpp) $(wildcard $(HOST)/*.hpp) include/emi355x.h
 
 $(LIBDIR)/libetol_mi355x.so: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libemi355x.so

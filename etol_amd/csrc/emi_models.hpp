@@ -25,6 +25,22 @@ template <typename T> struct ModelParams { T p[EMI_MAX_PARAMS]; };
 EMI_DEV void emi_sincos(double a, double* s, double* c) { sincos(a, s, c); }
 EMI_DEV void emi_sincos(float a, float* s, float* c) { sincosf(a, s, c); }
 
+// elementary functions used by generated (traced) models, emi_trace.cpp
+EMI_DEV double emi_sin(double a) { return sin(a); }
+EMI_DEV double emi_cos(double a) { return cos(a); }
+EMI_DEV double emi_tan(double a) { return tan(a); }
+EMI_DEV double emi_exp(double a) { return exp(a); }
+EMI_DEV double emi_log(double a) { return log(a); }
+EMI_DEV double emi_sqrt(double a) { return sqrt(a); }
+EMI_DEV double emi_pow(double a, double c) { return pow(a, c); }
+EMI_DEV float emi_sin(float a) { return sinf(a); }
+EMI_DEV float emi_cos(float a) { return cosf(a); }
+EMI_DEV float emi_tan(float a) { return tanf(a); }
+EMI_DEV float emi_exp(float a) { return expf(a); }
+EMI_DEV float emi_log(float a) { return logf(a); }
+EMI_DEV float emi_sqrt(float a) { return sqrtf(a); }
+EMI_DEV float emi_pow(float a, float c) { return powf(a, c); }
+
 // ---------------------------------------------------------------------------
 // 2-state single integrator: reference etol_psopt_example1.cpp
 //   dxdt :116-126 (xdot = u0), dydt :128-138 (ydot = u1),

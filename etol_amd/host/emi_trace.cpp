@@ -1,0 +1,363 @@
+// emi_trace.cpp -- see emi_trace.hpp.
+#include "emi_trace.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <set>
+#include <sstream>
+
+namespace ETOL {
+namespace mi355x {
+
+Trace& Trace::active() {
+    static Trace t;
+    return t;
+}
+
+void Trace::clear() {
+    _nodes.clear();
+    _cse.clear();
+}
+
+int Trace::intern(const Node& n) {
+    const auto key = std::make_tuple((int)n.op, n.a, n.b, n.c);
+    auto it = _cse.find(key);
+    if (it != _cse.end()) return it->second;
+    _nodes.push_back(n);
+    const int id = (int)_nodes.size() - 1;
+    _cse[key] = id;
+    return id;
+}
+
+bool Trace::is_const(int n, double* v) const {
+    if (n < 0 || _nodes[n].op != CONST) return false;
+    if (v) *v = _nodes[n].c;
+    return true;
+}
+
+int Trace::constant(double c) { return intern(Node{CONST, -1, -1, c}); }
+int Trace::input(Op kind, int index) { return intern(Node{kind, index, -1, 0.0}); }
+
+int Trace::unary(Op op, int a, double c) {
+    double va;
+    if (is_const(a, &va)) {
+        switch (op) {
+            case NEG: return constant(-va);
+            case SIN: return constant(std::sin(va));
+            case COS: return constant(std::cos(va));
+            case TAN: return constant(std::tan(va));
+            case EXP: return constant(std::exp(va));
+            case LOG: return constant(std::log(va));
+            case SQRT: return constant(std::sqrt(va));
+            case POWC: return constant(std::pow(va, c));
+            default: break;
+        }
+    }
+    if (op == NEG && _nodes[a].op == NEG) return _nodes[a].a;
+    if (op == POWC) {
+        if (c == 0.0) return constant(1.0);
+        if (c == 1.0) return a;
+        if (c == 2.0) return binary(MUL, a, a);
+    }
+    return intern(Node{op, a, -1, c});
+}
+
+int Trace::binary(Op op, int a, int b) {
+    double va = 0, vb = 0;
+    const bool ca = is_const(a, &va), cb = is_const(b, &vb);
+    if (ca && cb) {
+        switch (op) {
+            case ADD: return constant(va + vb);
+            case SUB: return constant(va - vb);
+            case MUL: return constant(va * vb);
+            case DIV: return constant(va / vb);
+            default: break;
+        }
+    }
+    switch (op) {
+        case ADD:
+            if (ca && va == 0.0) return b;
+            if (cb && vb == 0.0) return a;
+            if (a > b) std::swap(a, b);       // commutative: one canonical form for the CSE table
+            break;
+        case SUB:
+            if (cb && vb == 0.0) return a;
+            if (ca && va == 0.0) return unary(NEG, b);
+            if (a == b) return constant(0.0);
+            break;
+        case MUL:
+            if ((ca && va == 0.0) || (cb && vb == 0.0)) return constant(0.0);
+            if (ca && va == 1.0) return b;
+            if (cb && vb == 1.0) return a;
+            if (ca && va == -1.0) return unary(NEG, b);
+            if (cb && vb == -1.0) return unary(NEG, a);
+            if (a > b) std::swap(a, b);
+            break;
+        case DIV:
+            if (ca && va == 0.0) return constant(0.0);
+            if (cb && vb == 1.0) return a;
+            if (cb) return binary(MUL, a, constant(1.0 / vb));
+            break;
+        default: break;
+    }
+    return intern(Node{op, a, b, 0.0});
+}
+
+// Reverse sweep over the nodes below `out` (operands always have smaller ids than their users).
+std::vector<int> Trace::adjoints(int out) {
+    std::vector<int> adj(out + 1, -1);
+    adj[out] = constant(1.0);
+    auto add = [&](int n, int contribution) {
+        adj[n] = adj[n] < 0 ? contribution : binary(ADD, adj[n], contribution);
+    };
+    for (int n = out; n >= 0; --n) {
+        if (adj[n] < 0) continue;
+        const Node nd = _nodes[n];          // copy: _nodes grows below
+        const int g = adj[n];
+        switch (nd.op) {
+            case ADD: add(nd.a, g); add(nd.b, g); break;
+            case SUB: add(nd.a, g); add(nd.b, unary(NEG, g)); break;
+            case MUL: add(nd.a, binary(MUL, g, nd.b)); add(nd.b, binary(MUL, g, nd.a)); break;
+            case DIV:
+                add(nd.a, binary(DIV, g, nd.b));
+                add(nd.b, unary(NEG, binary(DIV, binary(MUL, g, n), nd.b)));
+                break;
+            case NEG: add(nd.a, unary(NEG, g)); break;
+            case SIN: add(nd.a, binary(MUL, g, unary(COS, nd.a))); break;
+            case COS: add(nd.a, unary(NEG, binary(MUL, g, unary(SIN, nd.a)))); break;
+            case TAN: add(nd.a, binary(MUL, g, binary(ADD, constant(1.0), binary(MUL, n, n)))); break;
+            case EXP: add(nd.a, binary(MUL, g, n)); break;
+            case LOG: add(nd.a, binary(DIV, g, nd.a)); break;
+            case SQRT: add(nd.a, binary(DIV, g, binary(MUL, constant(2.0), n))); break;
+            case POWC: add(nd.a, binary(MUL, g, binary(MUL, constant(nd.c), unary(POWC, nd.a, nd.c - 1.0)))); break;
+            default: break;   // CONST and inputs: leaves
+        }
+    }
+    return adj;
+}
+
+double Trace::eval(int node, const std::vector<double>& x, const std::vector<double>& u, double t,
+                   const std::vector<double>& coef) const {
+    std::vector<double> v(node + 1, 0.0);
+    for (int n = 0; n <= node; ++n) {
+        const Node& nd = _nodes[n];
+        switch (nd.op) {
+            case CONST: v[n] = nd.c; break;
+            case IN_STATE: v[n] = x.at(nd.a); break;
+            case IN_CONTROL: v[n] = u.at(nd.a); break;
+            case IN_TIME: v[n] = t; break;
+            case IN_COEF: v[n] = coef.at(nd.a); break;
+            case ADD: v[n] = v[nd.a] + v[nd.b]; break;
+            case SUB: v[n] = v[nd.a] - v[nd.b]; break;
+            case MUL: v[n] = v[nd.a] * v[nd.b]; break;
+            case DIV: v[n] = v[nd.a] / v[nd.b]; break;
+            case NEG: v[n] = -v[nd.a]; break;
+            case SIN: v[n] = std::sin(v[nd.a]); break;
+            case COS: v[n] = std::cos(v[nd.a]); break;
+            case TAN: v[n] = std::tan(v[nd.a]); break;
+            case EXP: v[n] = std::exp(v[nd.a]); break;
+            case LOG: v[n] = std::log(v[nd.a]); break;
+            case SQRT: v[n] = std::sqrt(v[nd.a]); break;
+            case POWC: v[n] = std::pow(v[nd.a], nd.c); break;
+        }
+    }
+    return v[node];
+}
+
+// Straight-line code for the nodes the outputs depend on, then the assignments to `targets`.
+std::string Trace::emit(const std::vector<int>& outs, const std::vector<std::string>& targets, bool accumulate,
+                        const std::string& ind) const {
+    std::set<int> need;
+    std::vector<int> stack(outs.begin(), outs.end());
+    while (!stack.empty()) {
+        const int n = stack.back();
+        stack.pop_back();
+        if (n < 0 || need.count(n)) continue;
+        need.insert(n);
+        const Node& nd = _nodes[n];
+        if (nd.op >= ADD) {
+            stack.push_back(nd.a);
+            if (nd.b >= 0) stack.push_back(nd.b);
+        }
+    }
+    std::ostringstream o;
+    o.precision(17);
+    auto ref = [&](int n) -> std::string {
+        const Node& nd = _nodes[n];
+        std::ostringstream r;
+        r.precision(17);
+        switch (nd.op) {
+            case CONST: r << "T(" << std::scientific << nd.c << ")"; return r.str();
+            case IN_STATE: r << "z[" << nd.a << "]"; return r.str();
+            case IN_CONTROL: r << "z[NS + " << nd.a << "]"; return r.str();
+            case IN_TIME: return "tk";
+            case IN_COEF: r << "cc[" << nd.a << "]"; return r.str();
+            default: r << "v" << n; return r.str();
+        }
+    };
+    for (int n : need) {
+        const Node& nd = _nodes[n];
+        if (nd.op < ADD) continue;
+        o << ind << "const T v" << n << " = ";
+        switch (nd.op) {
+            case ADD: o << ref(nd.a) << " + " << ref(nd.b); break;
+            case SUB: o << ref(nd.a) << " - " << ref(nd.b); break;
+            case MUL: o << ref(nd.a) << " * " << ref(nd.b); break;
+            case DIV: o << ref(nd.a) << " / " << ref(nd.b); break;
+            case NEG: o << "-" << ref(nd.a); break;
+            case SIN: o << "emi_sin(" << ref(nd.a) << ")"; break;
+            case COS: o << "emi_cos(" << ref(nd.a) << ")"; break;
+            case TAN: o << "emi_tan(" << ref(nd.a) << ")"; break;
+            case EXP: o << "emi_exp(" << ref(nd.a) << ")"; break;
+            case LOG: o << "emi_log(" << ref(nd.a) << ")"; break;
+            case SQRT: o << "emi_sqrt(" << ref(nd.a) << ")"; break;
+            case POWC: o << "emi_pow(" << ref(nd.a) << ", T(" << std::scientific << nd.c << "))"; break;
+            default: break;
+        }
+        o << ";\n";
+    }
+    for (size_t i = 0; i < outs.size(); ++i) {
+        if (outs[i] < 0) continue;
+        o << ind << targets[i] << (accumulate ? " += " : " = ") << ref(outs[i]) << ";\n";
+    }
+    return o.str();
+}
+
+std::string Trace::generate_model(const std::string& name, int ns, int nc, const std::vector<int>& f, int L) {
+    const int nv = ns + nc;
+    auto in_node = [&](int v) { return v < ns ? input(IN_STATE, v) : input(IN_CONTROL, v - ns); };
+    // first derivatives
+    std::vector<std::vector<int>> J(ns, std::vector<int>(nv, -1));
+    for (int i = 0; i < ns; ++i) {
+        const std::vector<int> adj = adjoints(f[i]);
+        for (int v = 0; v < nv; ++v) {
+            const int n = in_node(v);
+            J[i][v] = n < (int)adj.size() ? adj[n] : -1;
+        }
+    }
+    std::vector<int> gL(nv, -1);
+    {
+        const std::vector<int> adj = adjoints(L);
+        for (int v = 0; v < nv; ++v) {
+            const int n = in_node(v);
+            gL[v] = n < (int)adj.size() ? adj[n] : -1;
+        }
+    }
+    // Lagrangian Hessian: phi = cc[0] * L + sum_i cc[1+i] * f_i ; H = d/dz (d phi/dz)
+    int phi = binary(MUL, input(IN_COEF, 0), L);
+    for (int i = 0; i < ns; ++i) phi = binary(ADD, phi, binary(MUL, input(IN_COEF, 1 + i), f[i]));
+    std::vector<int> g(nv, -1);
+    {
+        const std::vector<int> adj = adjoints(phi);
+        for (int v = 0; v < nv; ++v) {
+            const int n = in_node(v);
+            g[v] = n < (int)adj.size() ? adj[n] : -1;
+        }
+    }
+    std::vector<int> H;
+    std::vector<std::string> Ht;
+    for (int v = 0; v < nv; ++v) {
+        std::vector<int> adj;
+        if (g[v] >= 0) adj = adjoints(g[v]);
+        for (int q = 0; q <= v; ++q) {
+            const int n = in_node(q);
+            int h = (g[v] >= 0 && n < (int)adj.size()) ? adj[n] : -1;
+            double c;
+            if (h >= 0 && is_const(h, &c) && c == 0.0) h = -1;
+            H.push_back(h);
+            Ht.push_back("H[" + std::to_string(v * (v + 1) / 2 + q) + "]");
+        }
+    }
+
+    std::ostringstream o;
+    o << "template <typename T> struct " << name << " {\n";
+    o << "    static constexpr int NS = " << ns << ", NC = " << nc << ", NV = " << nv << ", NPARAM = 0;\n";
+    // f
+    o << "    EMI_DEV static void f(const ModelParams<T>&, const T* z, T tk, T* fo) {\n";
+    {
+        std::vector<std::string> t;
+        for (int i = 0; i < ns; ++i) t.push_back("fo[" + std::to_string(i) + "]");
+        o << emit(f, t, false, "        ");
+    }
+    o << "        (void)tk;\n    }\n";
+    // jac
+    o << "    EMI_DEV static void jac(const ModelParams<T>&, const T* z, T tk, T (*J)[NV]) {\n";
+    o << "        for (int i = 0; i < NS; ++i)\n            for (int v = 0; v < NV; ++v) J[i][v] = T(0);\n";
+    {
+        std::vector<int> outs;
+        std::vector<std::string> t;
+        for (int i = 0; i < ns; ++i)
+            for (int v = 0; v < nv; ++v) {
+                double c;
+                if (J[i][v] < 0 || (is_const(J[i][v], &c) && c == 0.0)) continue;
+                outs.push_back(J[i][v]);
+                t.push_back("J[" + std::to_string(i) + "][" + std::to_string(v) + "]");
+            }
+        o << emit(outs, t, false, "        ");
+    }
+    o << "        (void)tk; (void)z;\n    }\n";
+    // cost
+    o << "    EMI_DEV static T cost(const ModelParams<T>&, const T* z, T tk) {\n        T Lv;\n";
+    o << emit({L}, {"Lv"}, false, "        ");
+    o << "        (void)tk;\n        return Lv;\n    }\n";
+    // grad
+    o << "    EMI_DEV static void grad(const ModelParams<T>&, const T* z, T tk, T* g) {\n";
+    o << "        for (int v = 0; v < NV; ++v) g[v] = T(0);\n";
+    {
+        std::vector<int> outs;
+        std::vector<std::string> t;
+        for (int v = 0; v < nv; ++v) {
+            if (gL[v] < 0) continue;
+            outs.push_back(gL[v]);
+            t.push_back("g[" + std::to_string(v) + "]");
+        }
+        o << emit(outs, t, false, "        ");
+    }
+    o << "        (void)tk; (void)z;\n    }\n";
+    // hess: cc[0] = cL, cc[1+i] = cf[i]
+    o << "    EMI_DEV static void hess(const ModelParams<T>&, const T* z, T tk, T cL, const T* cf, T* H) {\n";
+    o << "        T cc[NS + 1];\n        cc[0] = cL;\n        for (int i = 0; i < NS; ++i) cc[1 + i] = cf[i];\n";
+    o << emit(H, Ht, true, "        ");
+    o << "        (void)tk; (void)z; (void)cc;\n    }\n";
+    o << "};\n";
+    return o.str();
+}
+
+// ---- Var arithmetic (declared in include/ETOL/eMI355X_Types.hpp) -------------------------------
+namespace {
+int node_of(const Var& v) {
+    if (v.node < 0) {
+        fprintf(stderr, "mi355x::Var used outside a callback trace\n");
+        exit(EXIT_FAILURE);
+    }
+    return v.node;
+}
+Var wrap(int n) {
+    Var r;
+    r.kind = Var::EXPR;
+    r.node = n;
+    return r;
+}
+}  // namespace
+
+Var::Var(double constant) : kind(EXPR), index(0), node(Trace::active().constant(constant)) {}
+Var::Var(Kind k, size_t i) : kind(k), index(i), node(-1) {
+    Trace& t = Trace::active();
+    node = t.input(k == STATE ? Trace::IN_STATE : (k == CONTROL ? Trace::IN_CONTROL : Trace::IN_TIME), (int)i);
+}
+Var operator+(const Var& a, const Var& b) { return wrap(Trace::active().binary(Trace::ADD, node_of(a), node_of(b))); }
+Var operator-(const Var& a, const Var& b) { return wrap(Trace::active().binary(Trace::SUB, node_of(a), node_of(b))); }
+Var operator*(const Var& a, const Var& b) { return wrap(Trace::active().binary(Trace::MUL, node_of(a), node_of(b))); }
+Var operator/(const Var& a, const Var& b) { return wrap(Trace::active().binary(Trace::DIV, node_of(a), node_of(b))); }
+Var operator-(const Var& a) { return wrap(Trace::active().unary(Trace::NEG, node_of(a))); }
+Var sin(const Var& a) { return wrap(Trace::active().unary(Trace::SIN, node_of(a))); }
+Var cos(const Var& a) { return wrap(Trace::active().unary(Trace::COS, node_of(a))); }
+Var tan(const Var& a) { return wrap(Trace::active().unary(Trace::TAN, node_of(a))); }
+Var exp(const Var& a) { return wrap(Trace::active().unary(Trace::EXP, node_of(a))); }
+Var log(const Var& a) { return wrap(Trace::active().unary(Trace::LOG, node_of(a))); }
+Var sqrt(const Var& a) { return wrap(Trace::active().unary(Trace::SQRT, node_of(a))); }
+Var pow(const Var& a, double c) { return wrap(Trace::active().unary(Trace::POWC, node_of(a), c)); }
+
+}  // namespace mi355x
+}  // namespace ETOL

@@ -11,16 +11,17 @@
 // removes.  eMI355X therefore calls each callback ONCE, inside setup() (as the
 // MILP eSolvers do to build their expressions, reference src/eGurobi/eGurobi.cpp:
 // 149-157), with
-//     x[i], u[j] : mi355x::Symbol   (which state / control the slot stands for)
-//     k          : mi355x::Symbol   (kind TIME)
+//     x[i], u[j] : mi355x::Var      (handle of state i / control j; alias mi355x::Symbol)
+//     k          : mi355x::Var      (kind TIME)
 //     dt         : double
 // and expects back
-//     objective      -> mi355x::ModelTerm  with row == -1
-//     gradient[i]    -> mi355x::ModelTerm  with row == i     (state derivative i)
+//     objective      -> mi355x::ModelTerm with row == -1,  or the mi355x::Var of the integrand
+//     gradient[i]    -> mi355x::ModelTerm with row == i,   or the mi355x::Var of d x_i / dt
 //     constraints[c] -> fout_mi355x_t      (keep-out rows, in path-row order)
 // A ModelTerm names one of the hand-written device models (include/emi355x.h,
-// EMI_MODEL_*) and its parameter block; the rows of a fout_mi355x_t become the
-// path table of the device evaluator.  A wrong type in an any ends, like in
+// EMI_MODEL_*) and its parameter block; Vars are traced expressions that are
+// differentiated and compiled into the same kernels at setup(); the rows of a
+// fout_mi355x_t become the path table of the device evaluator.  A wrong type in an any ends, like in
 // ePSOPT, in errorHandler(): message on stderr and exit(EXIT_FAILURE).
 #ifndef ETOL_MI355X_EMI355X_TYPES_HPP_
 #define ETOL_MI355X_EMI355X_TYPES_HPP_
@@ -36,10 +37,38 @@
 namespace ETOL {
 namespace mi355x {
 
-struct Symbol {
-    enum Kind { STATE = 0, CONTROL = 1, TIME = 2 } kind;
-    size_t index;
+// What x[i], u[j] and k hold when eMI355X calls a callback: a handle into the expression trace of
+// the current setup().  A callback may either ignore the arithmetic and return a descriptor of a
+// built-in device model (mi355x::objective / mi355x::derivative), or compute with the handles --
+// +, -, *, /, sin, cos, tan, exp, log, sqrt, pow(x, c) -- and return the resulting Var.  In the
+// second case eMI355X differentiates the recorded expressions symbolically (Jacobian, cost
+// gradient, Lagrangian Hessian), generates a model struct for the hand-written kernel templates
+// and compiles them for gfx950 at setup() (hiprtc): any smooth user model runs in the same
+// kernels as the built-in ones.  `kind`/`index` identify input handles (states, controls, time).
+class Var {
+ public:
+    enum Kind { STATE = 0, CONTROL = 1, TIME = 2, EXPR = 3 };
+    Kind kind = EXPR;
+    size_t index = 0;
+    int node = -1;                       // node of the active trace (-1: not part of a trace)
+    Var() {}
+    Var(double constant);                // NOLINT: numbers mix freely with handles
+    Var(Kind k, size_t i);               // input handle (registers it in the active trace)
 };
+typedef Var Symbol;                      // the name used by descriptor-only callbacks
+
+Var operator+(const Var& a, const Var& b);
+Var operator-(const Var& a, const Var& b);
+Var operator*(const Var& a, const Var& b);
+Var operator/(const Var& a, const Var& b);
+Var operator-(const Var& a);
+Var sin(const Var& a);
+Var cos(const Var& a);
+Var tan(const Var& a);
+Var exp(const Var& a);
+Var log(const Var& a);
+Var sqrt(const Var& a);
+Var pow(const Var& a, double c);
 
 struct ModelTerm {
     int model = -1;                 // EMI_MODEL_*

@@ -10,6 +10,7 @@
 
 #include "emi_nlp.hpp"
 #include "emi_transcribe.hpp"
+#include "emi_trace.hpp"
 
 namespace mx = ETOL::mi355x;
 
@@ -274,6 +275,45 @@ extern "C" int harness_solve_quadrotor_oracle(const char* oracle_so, int nsteps,
     for (int i = 0; i < 6 * m; ++i) X[i] = r.z[i];
     for (int i = 0; i < 2 * m; ++i) U[i] = r.z[6 * m + i];
     return 0;
+}
+
+// ---- traced models: the quadrotor written with mi355x::Var arithmetic, as a user would -----------
+namespace {
+// x = (px, pz, theta, vx, vz, omega), u = (T, tau); same equations as EMI_MODEL_QUADROTOR2D
+mx::Var traced_quad_rhs(const std::vector<mx::Var>& x, const std::vector<mx::Var>& u, int i) {
+    const double m = 1.0, I = 0.01, g = 9.81;
+    switch (i) {
+        case 0: return x[3];
+        case 1: return x[4];
+        case 2: return x[5];
+        case 3: return -(u[0] / m) * mx::sin(x[2]);
+        case 4: return (u[0] / m) * mx::cos(x[2]) - g;
+        default: return u[1] / I;
+    }
+}
+mx::Var traced_quad_cost(const std::vector<mx::Var>& u) { return 1.0 * u[0] * u[0] + 1.0 * u[1] * u[1]; }
+}  // namespace
+
+// Source of the generated model struct for the traced quadrotor (or, with which=1, a model that
+// exercises every traced operation).  Host-only: used to check trace + derivatives + code generation.
+extern "C" const char* harness_traced_model_source(int which) {
+    mx::Trace& tr = mx::Trace::active();
+    tr.clear();
+    if (which == 0) {
+        std::vector<mx::Var> x, u;
+        for (size_t i = 0; i < 6; ++i) x.push_back(mx::Var(mx::Var::STATE, i));
+        for (size_t j = 0; j < 2; ++j) u.push_back(mx::Var(mx::Var::CONTROL, j));
+        std::vector<int> f;
+        for (int i = 0; i < 6; ++i) f.push_back(traced_quad_rhs(x, u, i).node);
+        g_out = tr.generate_model("TracedModel", 6, 2, f, traced_quad_cost(u).node);
+    } else {
+        mx::Var a(mx::Var::STATE, 0), b(mx::Var::STATE, 1), c(mx::Var::CONTROL, 0), t(mx::Var::TIME, 0);
+        std::vector<int> f;
+        f.push_back((mx::exp(a * 0.3) / (1.0 + b * b) + mx::tan(c) * mx::sqrt(2.0 + a * a) - t).node);
+        f.push_back((mx::log(3.0 + a * b + c * c) * mx::pow(2.0 + b, 1.5) - mx::cos(a - c) / mx::sin(1.0 + b * 0.1)).node);
+        g_out = tr.generate_model("TracedModel", 2, 1, f, (c * c * mx::exp(-a) + b * mx::sin(a * c)).node);
+    }
+    return g_out.c_str();
 }
 
 extern "C" {
