@@ -33,19 +33,27 @@ host: $(LIBDIR)/libetol_mi355x.so $(LIBDIR)/etol_mi355x_example1 tests/harness/l
 $(LIBDIR):
 	mkdir -p $(LIBDIR)
 
-$(LIBDIR)/emi_kernels.o: $(CSRC)/emi_kernels.hip $(CSRC)/emi_kernels.hpp $(CSRC)/emi_models.hpp include/emi355x.h | $(LIBDIR)
+CSRC_HDR  := $(wildcard $(CSRC)/*.hpp) include/emi355x.h
+# headers a model program compiled at run time (hiprtc, emi_rtc.hip) includes: embedded as text
+RTC_HDR   := $(CSRC)/emi_models.hpp $(CSRC)/emi_args.hpp $(CSRC)/emi_node_kernels.hpp $(CSRC)/emi_symdefect_kernels.hpp
+
+$(LIBDIR)/emi_kernels.o: $(CSRC)/emi_kernels.hip $(CSRC_HDR) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(LIBDIR)/emi_symdefect.o: $(CSRC)/emi_symdefect.hip $(CSRC)/emi_kernels.hpp $(CSRC)/emi_models.hpp include/emi355x.h | $(LIBDIR)
+$(LIBDIR)/emi_symdefect.o: $(CSRC)/emi_symdefect.hip $(CSRC_HDR) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(LIBDIR)/emi_defect_f32.o: $(CSRC)/emi_defect_f32.hip $(CSRC)/emi_kernels.hpp $(CSRC)/emi_models.hpp include/emi355x.h | $(LIBDIR)
+$(LIBDIR)/emi_defect_f32.o: $(CSRC)/emi_defect_f32.hip $(CSRC_HDR) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(LIBDIR)/emi_api.o: $(CSRC)/emi_api.hip $(CSRC)/emi_kernels.hpp $(CSRC)/emi_models.hpp include/emi355x.h | $(LIBDIR)
+$(LIBDIR)/emi_api.o: $(CSRC)/emi_api.hip $(CSRC_HDR) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(LIBDIR)/emi_rtc_sources.inc: $(RTC_HDR) tools/embed_src.py | $(LIBDIR)
+	python3 tools/embed_src.py $@ $(RTC_HDR)
+$(LIBDIR)/emi_rtc.o: $(CSRC)/emi_rtc.hip $(LIBDIR)/emi_rtc_sources.inc $(CSRC_HDR) | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -I$(LIBDIR) -c $< -o $@
 $(LIBDIR)/emi_host.o: $(CSRC)/emi_host.cpp include/emi355x.h | $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(LIBDIR)/libemi355x.so: $(LIBDIR)/emi_kernels.o $(LIBDIR)/emi_symdefect.o $(LIBDIR)/emi_defect_f32.o $(LIBDIR)/emi_api.o $(LIBDIR)/emi_host.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+$(LIBDIR)/libemi355x.so: $(LIBDIR)/emi_kernels.o $(LIBDIR)/emi_symdefect.o $(LIBDIR)/emi_defect_f32.o $(LIBDIR)/emi_api.o $(LIBDIR)/emi_rtc.o $(LIBDIR)/emi_host.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lhiprtc
 
 HOST_SRC := $(HOST)/TrajectoryOptimizer.cpp $(HOST)/eMI355X.cpp $(HOST)/emi_nlp.cpp $(HOST)/emi_trace.cpp
 HOST_HDR := $(wildcard include/ETOL/*.hpp) $(wildcard $(HOST)/*.hpp) include/emi355x.h

@@ -18,6 +18,7 @@ STATUS = {0: "EMI_OK", 1: "EMI_ERR_ARG", 2: "EMI_ERR_STATE", 3: "EMI_ERR_HIP",
           4: "EMI_ERR_NO_DEVICE", 5: "EMI_ERR_UNSUPPORTED", 6: "EMI_ERR_COMM"}
 
 MODEL_POINTMASS2D, MODEL_QUADROTOR2D, MODEL_FIXEDWING12 = 0, 1, 2
+MODEL_SOURCE = 100   # installed by emi_set_model_source
 PATH_ELLIPSE, PATH_DISC, PATH_TRACK = 0, 1, 2
 PATH_REC = 8
 EVAL_NODES, EVAL_DEFECT, EVAL_ALL, EVAL_NOJAC = 1, 2, 3, 4
@@ -56,6 +57,8 @@ SYMBOLS = {
     "emi_synchronize": (C.c_int, [_P]),
     "emi_set_mesh": (C.c_int, [_P, C.c_int, _D, _D, _D, C.c_double, C.c_double]),
     "emi_set_model": (C.c_int, [_P, C.c_int, _D, C.c_int, C.c_int]),
+    "emi_set_model_source": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_int, _D, C.c_int, C.c_int]),
+    "emi_check_model_source": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "emi_set_batch": (C.c_int, [_P, C.c_int]),
     "emi_set_path": (C.c_int, [_P, C.c_int, C.c_int, _D, C.c_int, C.c_int]),
     "emi_set_tracks": (C.c_int, [_P, C.c_int, C.c_int, _D, _D]),

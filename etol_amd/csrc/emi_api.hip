@@ -56,6 +56,7 @@ struct emi_ctx_s {
     // model
     int model = -1, ns = 0, nc = 0, maximize = 0;
     double params[EMI_MAX_PARAMS] = {0};
+    emi::RtcModel* rtc = nullptr;   // model == EMI_MODEL_SOURCE: code object compiled at emi_set_model_source
     // batch / path
     int B = 0;
     int np = 0, path_sets = 0, px = 0, py = 1;
@@ -132,6 +133,13 @@ int download_real(emi_ctx_t c, double* dst, const void* dsrc, size_t n) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return EMI_OK;
+}
+
+// the even/odd MFMA defect kernel beside the node kernel: needs an exactly centro-antisymmetric D
+bool overlapped_path(emi_ctx_t c) {
+    if (c->f32 || !c->allow_fused || !c->symmetric || c->M <= 0 || c->model < 0) return false;
+    if (c->model == EMI_MODEL_SOURCE) return emi::rtc_has_symdefect(c->rtc) && c->M % 128 == 0;
+    return emi::fused_supported(c->model, c->M, c->sym_ct);
 }
 
 int nvals_of(emi_ctx_t c) { return c->ns * (c->ns + c->nc) + 2 * c->np + (c->ns + c->nc); }
@@ -247,6 +255,7 @@ int emi_destroy(emi_ctx_t c) {
     if (c->t_start) (void)hipEventDestroy(c->t_start);
     if (c->t_stop) (void)hipEventDestroy(c->t_stop);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    emi::rtc_destroy(c->rtc);
     delete c;
     return EMI_OK;
 }
@@ -354,6 +363,11 @@ int emi_set_model(emi_ctx_t c, int model, const double* params, int nparams, int
     if (emi_model_dims(model, &ns, &nc, &np_expected)) return fail(c, EMI_ERR_ARG, "unknown model %d", model);
     if (nparams != np_expected || (nparams > 0 && !params))
         return fail(c, EMI_ERR_ARG, "model %d takes %d parameters, got %d", model, np_expected, nparams);
+    if (c->rtc) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        emi::rtc_destroy(c->rtc);
+        c->rtc = nullptr;
+    }
     c->model = model;
     c->ns = ns;
     c->nc = nc;
@@ -361,6 +375,45 @@ int emi_set_model(emi_ctx_t c, int model, const double* params, int nparams, int
     memset(c->params, 0, sizeof c->params);
     for (int i = 0; i < nparams; ++i) c->params[i] = params[i];
     return EMI_OK;
+}
+
+int emi_set_model_source(emi_ctx_t c, const char* struct_name, const char* source, int ns, int nc,
+                         const double* params, int nparams, int maximize) {
+    if (!c) return EMI_ERR_ARG;
+    if (nparams < 0 || nparams > EMI_MAX_PARAMS || (nparams > 0 && !params))
+        return fail(c, EMI_ERR_ARG, "emi_set_model_source: at most %d parameters", EMI_MAX_PARAMS);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    emi::RtcModel* m = nullptr;
+    std::string log;
+    const int st = emi::rtc_build(c->f32, struct_name, source, ns, nc, &m, &log);
+    if (st) {
+        c->err = log;
+        return st;
+    }
+    emi::rtc_destroy(c->rtc);
+    c->rtc = m;
+    c->model = EMI_MODEL_SOURCE;
+    c->ns = ns;
+    c->nc = nc;
+    c->maximize = maximize ? 1 : 0;
+    memset(c->params, 0, sizeof c->params);
+    for (int i = 0; i < nparams; ++i) c->params[i] = params[i];
+    // path rows name states of the previous model
+    c->np = 0;
+    c->path_sets = 0;
+    return EMI_OK;
+}
+
+int emi_check_model_source(const char* struct_name, const char* source, int ns, int nc, int f32, char* log,
+                           size_t log_len) {
+    std::string l;
+    const int st = emi::rtc_check(f32 != 0, struct_name, source, ns, nc, &l);
+    if (log && log_len) {
+        strncpy(log, l.c_str(), log_len - 1);
+        log[log_len - 1] = '\0';
+    }
+    return st;
 }
 
 int emi_set_batch(emi_ctx_t c, int B) {
@@ -489,8 +542,7 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         HIP_TRY(c, emi::defect_f64_set_attr());
         c->attr_set = true;
     }
-    const bool fused = nodes && defect && !c->f32 && c->allow_fused && c->symmetric &&
-                       emi::fused_supported(c->model, c->M, c->sym_ct);
+    const bool fused = nodes && defect && overlapped_path(c);
     ProfEvents* pe = nullptr;
     if (c->profile) {
         if (c->prof_used == c->prof.size()) {
@@ -524,13 +576,18 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
             HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         }
         if (pe) HIP_TRY(c, hipEventRecord(pe->k[0], c->stream));
-        HIP_TRY(c, emi::launch_symdefect(c->model, sa, c->stream, !(c->fused_attr_mask & bit), c->sym_ct));
-        c->fused_attr_mask |= bit;
+        if (c->rtc) {
+            HIP_TRY(c, emi::rtc_launch_symdefect(c->rtc, sa, c->stream));
+        } else {
+            HIP_TRY(c, emi::launch_symdefect(c->model, sa, c->stream, !(c->fused_attr_mask & bit), c->sym_ct));
+            c->fused_attr_mask |= bit;
+        }
         if (pe) {
             HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
             HIP_TRY(c, hipEventRecord(pe->k[2], s2));
         }
-        HIP_TRY(c, emi::launch_nodes<double>(c->model, na, jac, false, s2));
+        if (c->rtc) HIP_TRY(c, emi::rtc_launch_nodes<double>(c->rtc, na, jac, false, s2));
+        else HIP_TRY(c, emi::launch_nodes<double>(c->model, na, jac, false, s2));
         if (pe) HIP_TRY(c, hipEventRecord(pe->k[3], s2));
         HIP_TRY(c, emi::launch_cost_finish<double>(na.cost_part, na.cost, c->B, emi::node_chunks(c->M),
                                                    na.sgn * na.h, s2));
@@ -548,13 +605,15 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         if (c->f32) {
             emi::NodeArgs<float> a;
             fill_node_args(c, a, dX, dU, dRES, dVALS, dCOST);
-            HIP_TRY(c, emi::launch_nodes<float>(c->model, a, jac, true, c->stream));
+            if (c->rtc) HIP_TRY(c, emi::rtc_launch_nodes<float>(c->rtc, a, jac, true, c->stream));
+            else HIP_TRY(c, emi::launch_nodes<float>(c->model, a, jac, true, c->stream));
             HIP_TRY(c, emi::launch_cost_finish<float>(a.cost_part, a.cost, c->B, emi::node_chunks(c->M), a.sgn * a.h,
                                                       c->stream));
         } else {
             emi::NodeArgs<double> a;
             fill_node_args(c, a, dX, dU, dRES, dVALS, dCOST);
-            HIP_TRY(c, emi::launch_nodes<double>(c->model, a, jac, true, c->stream));
+            if (c->rtc) HIP_TRY(c, emi::rtc_launch_nodes<double>(c->rtc, a, jac, true, c->stream));
+            else HIP_TRY(c, emi::launch_nodes<double>(c->model, a, jac, true, c->stream));
             HIP_TRY(c, emi::launch_cost_finish<double>(a.cost_part, a.cost, c->B, emi::node_chunks(c->M), a.sgn * a.h,
                                                        c->stream));
         }
@@ -625,11 +684,13 @@ int emi_hess_dev(emi_ctx_t c, const void* dX, const void* dU, const void* dLamF,
     if (c->f32) {
         emi::HessArgs<float> a;
         fill(a);
-        HIP_TRY(c, emi::launch_hess<float>(c->model, a, c->stream));
+        if (c->rtc) HIP_TRY(c, emi::rtc_launch_hess<float>(c->rtc, a, c->stream));
+        else HIP_TRY(c, emi::launch_hess<float>(c->model, a, c->stream));
     } else {
         emi::HessArgs<double> a;
         fill(a);
-        HIP_TRY(c, emi::launch_hess<double>(c->model, a, c->stream));
+        if (c->rtc) HIP_TRY(c, emi::rtc_launch_hess<double>(c->rtc, a, c->stream));
+        else HIP_TRY(c, emi::launch_hess<double>(c->model, a, c->stream));
     }
     return EMI_OK;
 }
@@ -736,8 +797,7 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
 
 int emi_last_path(emi_ctx_t c, int* fused) {
     if (!c || !fused) return EMI_ERR_ARG;
-    *fused = (!c->f32 && c->allow_fused && c->symmetric && c->M > 0 && c->model >= 0 &&
-              emi::fused_supported(c->model, c->M, c->sym_ct)) ? 1 : 0;
+    *fused = overlapped_path(c) ? 1 : 0;
     return EMI_OK;
 }
 

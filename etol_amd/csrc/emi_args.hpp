@@ -1,0 +1,93 @@
+// emi_args.hpp -- tile constants and kernel argument blocks.  Shared by the kernels built into
+// libemi355x.so and by the model programs compiled at run time (emi_rtc.hip), so it stays free of
+// host-only includes.
+#pragma once
+#ifdef __HIPCC_RTC__
+// values of include/emi355x.h (checked against it on the static side, emi_kernels.hpp)
+#define EMI_PATH_ELLIPSE 0
+#define EMI_PATH_DISC 1
+#define EMI_PATH_TRACK 2
+#define EMI_PATH_REC 8
+#else
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "emi355x.h"
+#endif
+
+#define EMI_NODE_THREADS 256
+
+// defect GEMM tile (fp64 MFMA path)
+#define DEF_TM 96
+#define DEF_TN 128
+#define DEF_BK 16
+
+// even/odd defect kernel (emi_symdefect.hip): 16 instances x 64*CT half-indices per workgroup, K tile 16
+#define FUSED_TI 16
+#define FUSED_BK 16
+
+#include "emi_models.hpp"
+
+namespace emi {
+
+template <typename T> struct NodeArgs {
+    const T* X;         // [B][ns][M]
+    const T* U;         // [B][nc][M]
+    T* RES;             // [B][nres][M]
+    T* VALS;            // [B][nvals][M]
+    T* cost_part;       // [B][nchunks]
+    T* cost;            // [B]
+    const T* w;         // [M]  LGL weights
+    const T* node_t;    // [M]  node times t0 + h (tau+1)
+    const T* Ddiag;     // [M]  D_kk
+    const T* path;      // [path_sets][np][EMI_PATH_REC]
+    const T* track_x;   // [track_sets][ntracks][M]
+    const T* track_y;
+    int M, B, np, nres, nvals;
+    int path_sets, track_sets, ntracks;
+    int px, py;
+    T h, sgn;
+    ModelParams<T> P;
+};
+
+template <typename T> struct HessArgs {
+    const T* X;
+    const T* U;
+    const T* lamF;      // [B][ns][M]
+    const T* lamC;      // [B][np][M]
+    T* H;               // [B][nhess][M]
+    const T* w;
+    const T* node_t;
+    const T* path;
+    int M, B, np, path_sets, px, py;
+    T h, sgn, sigma;
+    ModelParams<T> P;
+};
+
+struct SymDefectArgs {
+    const double* X;
+    const double* U;
+    double* RES;
+    const double* node_t;
+    const double* De;       // [M/2][M/2]  (D[i][j] + D[i][N-j]) / 2
+    const double* Do;       // [M/2][M/2]  (D[i][j] - D[i][N-j]) / 2
+    int M, B, nres;
+    int order;              // block -> tile order within an XCD (see emi_symdefect.hip)
+    int ablate;             // diagnostics (results invalid): 1 skip MFMAs, 2 skip operand DMA, 4 skip epilogue
+    double h;
+    ModelParams<double> P;
+};
+
+struct DefectArgs {
+    const double* X;    // [R][M], R = B*ns
+    const double* D;    // [M][M] row-major
+    double* RES;        // [B][nres][M]; defect rows are accumulated into
+    int R, M, ns, nres;
+};
+struct DefectArgsF32 {
+    const float* X;
+    const float* D;
+    float* RES;
+    int R, M, ns, nres;
+};
+
+}  // namespace emi

@@ -1,86 +1,19 @@
-// emi_kernels.hpp -- argument blocks and launcher prototypes shared by the
-// kernels (emi_kernels.hip) and the C-ABI implementation (emi_api.hip).
+// emi_kernels.hpp -- launcher prototypes shared by the kernel translation units and the C-ABI
+// implementation (emi_api.hip).  Argument blocks and tile constants: emi_args.hpp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include <string>
+
 #include "emi355x.h"
+#include "emi_args.hpp"
 
-#define EMI_NODE_THREADS 256
-
-// defect GEMM tile (fp64 MFMA path)
-#define DEF_TM 96
-#define DEF_TN 128
-#define DEF_BK 16
-
-// even/odd defect kernel (emi_symdefect.hip): 16 instances x 64*CT half-indices per workgroup, K tile 16
-#define FUSED_TI 16
-#define FUSED_BK 16
-
-#include "emi_models.hpp"
+// emi_args.hpp repeats these for run-time compiled model programs
+static_assert(EMI_PATH_ELLIPSE == 0 && EMI_PATH_DISC == 1 && EMI_PATH_TRACK == 2 && EMI_PATH_REC == 8,
+              "emi_args.hpp and emi355x.h disagree");
 
 namespace emi {
-
-template <typename T> struct NodeArgs {
-    const T* X;         // [B][ns][M]
-    const T* U;         // [B][nc][M]
-    T* RES;             // [B][nres][M]
-    T* VALS;            // [B][nvals][M]
-    T* cost_part;       // [B][nchunks]
-    T* cost;            // [B]
-    const T* w;         // [M]  LGL weights
-    const T* node_t;    // [M]  node times t0 + h (tau+1)
-    const T* Ddiag;     // [M]  D_kk
-    const T* path;      // [path_sets][np][EMI_PATH_REC]
-    const T* track_x;   // [track_sets][ntracks][M]
-    const T* track_y;
-    int M, B, np, nres, nvals;
-    int path_sets, track_sets, ntracks;
-    int px, py;
-    T h, sgn;
-    ModelParams<T> P;
-};
-
-template <typename T> struct HessArgs {
-    const T* X;
-    const T* U;
-    const T* lamF;      // [B][ns][M]
-    const T* lamC;      // [B][np][M]
-    T* H;               // [B][nhess][M]
-    const T* w;
-    const T* node_t;
-    const T* path;
-    int M, B, np, path_sets, px, py;
-    T h, sgn, sigma;
-    ModelParams<T> P;
-};
-
-struct SymDefectArgs {
-    const double* X;
-    const double* U;
-    double* RES;
-    const double* node_t;
-    const double* De;       // [M/2][M/2]  (D[i][j] + D[i][N-j]) / 2
-    const double* Do;       // [M/2][M/2]  (D[i][j] - D[i][N-j]) / 2
-    int M, B, nres;
-    int order;              // block -> tile order within an XCD (see emi_symdefect.hip)
-    int ablate;             // diagnostics (results invalid): 1 skip MFMAs, 2 skip operand DMA, 4 skip epilogue
-    double h;
-    ModelParams<double> P;
-};
-
-struct DefectArgs {
-    const double* X;    // [R][M], R = B*ns
-    const double* D;    // [M][M] row-major
-    double* RES;        // [B][nres][M]; defect rows are accumulated into
-    int R, M, ns, nres;
-};
-struct DefectArgsF32 {
-    const float* X;
-    const float* D;
-    float* RES;
-    int R, M, ns, nres;
-};
 
 int node_chunks(int M);
 template <typename T>
@@ -95,5 +28,16 @@ template <typename T>
 hipError_t launch_cost_finish(const T* part, T* cost, int B, int nchunks, T scale, hipStream_t s);
 bool fused_supported(int model, int M, int ct);
 hipError_t launch_symdefect(int model, const SymDefectArgs& a, hipStream_t s, bool set_attr, int ct);
+
+// model programs compiled at run time (emi_rtc.hip); the int results are EMI_* status codes
+struct RtcModel;
+int rtc_check(bool f32, const char* struct_name, const char* source, int ns, int nc, std::string* log);
+int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int nc, RtcModel** out, std::string* log);
+void rtc_destroy(RtcModel* m);
+bool rtc_has_symdefect(const RtcModel* m);
+template <typename T>
+hipError_t rtc_launch_nodes(RtcModel* m, const NodeArgs<T>& a, bool jac, bool defect_rows, hipStream_t s);
+template <typename T> hipError_t rtc_launch_hess(RtcModel* m, const HessArgs<T>& a, hipStream_t s);
+hipError_t rtc_launch_symdefect(RtcModel* m, const SymDefectArgs& a, hipStream_t s);
 
 }  // namespace emi

@@ -13,7 +13,9 @@
 //   hess() adds  cL*L_zz + sum_i cf[i]*f_i,zz  into the packed lower triangle
 //          H[v*(v+1)/2 + q], q<=v
 #pragma once
+#ifndef __HIPCC_RTC__   // hiprtc (models compiled at run time, emi_rtc.hip) predeclares the device runtime
 #include <hip/hip_runtime.h>
+#endif
 
 namespace emi {
 

@@ -1,0 +1,282 @@
+// emi_node_kernels.hpp -- the model-templated streaming kernels (K1+K2+K3+K5 node kernel, K3' cost
+// finish, KH Hessian blocks).  Instantiated for the built-in models in emi_kernels.hip and, through
+// hiprtc, for model structs generated from traced user callbacks (emi_rtc.hip).
+#pragma once
+#include "emi_args.hpp"
+
+namespace emi {
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+template <typename T, int VEC> struct Pack;
+template <> struct Pack<double, 1> { using type = double; };
+template <> struct Pack<double, 2> { using type = double2; };
+template <> struct Pack<float, 1> { using type = float; };
+template <> struct Pack<float, 2> { using type = float2; };
+template <> struct Pack<float, 4> { using type = float4; };
+
+template <typename T, int VEC>
+EMI_DEV void load_vec(const T* __restrict__ p, T (&r)[VEC]) {
+    using P = typename Pack<T, VEC>::type;
+    const P v = *reinterpret_cast<const P*>(p);
+    const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) r[i] = e[i];
+}
+template <typename T, int VEC>
+EMI_DEV void store_vec(T* __restrict__ p, const T (&r)[VEC]) {
+    using P = typename Pack<T, VEC>::type;
+    P v;
+    T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) e[i] = r[i];
+    *reinterpret_cast<P*>(p) = v;
+}
+
+// wave64 sum (all lanes end with lane 0 holding the total)
+template <typename T> EMI_DEV T wave_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// K1+K2+K3+K5: one thread = VEC consecutive nodes of one instance.
+//   grid.x = node chunks (EMI_NODE_THREADS*VEC nodes each), grid.y = instance
+// Reads  z = X[b][:][k], U[b][:][k]           (coalesced along k)
+// Writes RES defect rows  = -h f_i            (K4 adds D.X on top)
+//        RES path rows    = c_j
+//        VALS             = Jacobian values, cost gradient
+//        cost_part[b][chunk] = sum_k w_k L_k  over this block (wave DPP + LDS)
+// DEFROWS = false leaves the defect rows alone: the even/odd defect kernel
+// (emi_symdefect.hip) then produces them, concurrently, on another stream.
+// A thread issues all its loads first and only stores afterwards: vmcnt
+// retires in order, so a load behind the ~116 streaming stores would wait for
+// every one of them.  For the same reason the wave-uniform keep-out records
+// are read through the constant address space (scalar loads, lgkmcnt).
+// ---------------------------------------------------------------------------
+template <typename T, class Model, int VEC, bool JAC, bool DEFROWS>
+__global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T> a) {
+    constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
+    const int b = blockIdx.y;
+    const int M = a.M;
+    const int k0 = (blockIdx.x * EMI_NODE_THREADS + threadIdx.x) * VEC;
+    const bool active = k0 < M;  // M % VEC == 0 by dispatch, so the pack is whole
+
+    T lsum = T(0);
+    if (active) {
+        const T* __restrict__ Xb = a.X + (size_t)b * NS * M;
+        const T* __restrict__ Ub = a.U + (size_t)b * NC * M;
+        T* __restrict__ Rb = a.RES + (size_t)b * a.nres * M;
+        T* __restrict__ Vb = JAC ? a.VALS + (size_t)b * a.nvals * M : nullptr;
+
+        T z[NV][VEC];
+#pragma unroll
+        for (int v = 0; v < NS; ++v) load_vec<T, VEC>(Xb + (size_t)v * M + k0, z[v]);
+#pragma unroll
+        for (int v = 0; v < NC; ++v) load_vec<T, VEC>(Ub + (size_t)v * M + k0, z[NS + v]);
+        T wk[VEC], tk[VEC], dkk[VEC];
+        load_vec<T, VEC>(a.w + k0, wk);
+        load_vec<T, VEC>(a.node_t + k0, tk);
+        if (JAC) load_vec<T, VEC>(a.Ddiag + k0, dkk);
+
+        const T h = a.h;
+        // ---- K1 dynamics ------------------------------------------------
+        {
+            T fo[NS][VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                T ze[NV], fe[NS];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) ze[v] = z[v][e];
+                if (DEFROWS) {
+                    Model::f(a.P, ze, tk[e], fe);
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) fo[i][e] = -h * fe[i];
+                }
+                lsum += wk[e] * Model::cost(a.P, ze, tk[e]);
+            }
+            if (DEFROWS) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) store_vec<T, VEC>(Rb + (size_t)i * M + k0, fo[i]);
+            }
+        }
+        if (JAC) {
+            // ---- K1' dynamics Jacobian block + K5 placement ---------------
+            T Jv[NS][NV][VEC];
+            T gv[NV][VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                T ze[NV], Je[NS][NV], ge[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) ze[v] = z[v][e];
+                Model::jac(a.P, ze, tk[e], Je);
+                Model::grad(a.P, ze, tk[e], ge);
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v)
+                        Jv[i][v][e] = -h * Je[i][v] + (v == i ? dkk[e] : T(0));
+                const T cw = a.sgn * h * wk[e];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) gv[v][e] = cw * ge[v];
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    store_vec<T, VEC>(Vb + (size_t)(i * NV + v) * M + k0, Jv[i][v]);
+            T* __restrict__ Gb = Vb + (size_t)(NS * NV + 2 * a.np) * M;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) store_vec<T, VEC>(Gb + (size_t)v * M + k0, gv[v]);
+        }
+        // ---- K2 path constraints (records are wave-uniform: scalar loads) --
+        const int np = a.np;
+        if (np > 0) {
+            const int set = a.path_sets > 1 ? b : 0;
+            typedef const __attribute__((address_space(4))) T* cptr_t;   // read-only table: scalar loads
+            cptr_t rec = (cptr_t)(a.path + (size_t)set * np * EMI_PATH_REC);
+            T* __restrict__ Cb = Rb + (size_t)NS * M;
+            T* __restrict__ JCb = JAC ? Vb + (size_t)(NS * NV) * M : nullptr;
+            // the keep-outs act on two runtime-chosen states: select with
+            // compares, a runtime register index would go to scratch
+            T px[VEC], py[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                px[e] = z[0][e];
+                py[e] = z[0][e];
+#pragma unroll
+                for (int v = 1; v < NS; ++v) {
+                    px[e] = (v == a.px) ? z[v][e] : px[e];
+                    py[e] = (v == a.py) ? z[v][e] : py[e];
+                }
+            }
+            for (int j = 0; j < np; ++j) {
+                cptr_t r = rec + j * EMI_PATH_REC;
+                const int kind = (int)r[0];
+                T c[VEC], cx[VEC], cy[VEC];
+                if (kind == EMI_PATH_DISC) {
+                    // r^2 - ((x-xc)^2 + (y-yc)^2): etol_psopt_example1.cpp:243-247
+                    const T xc = r[1], yc = r[2], rsq = r[3];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const T dx = px[e] - xc, dy = py[e] - yc;
+                        c[e] = (dx * dx + dy * dy) * T(-1) + rsq;
+                        cx[e] = T(-2) * dx;
+                        cy[e] = T(-2) * dy;
+                    }
+                } else if (kind == EMI_PATH_ELLIPSE) {
+                    // etol_psopt_example1.cpp:174-182 (constants precomputed on host)
+                    const T xc = r[1], yc = r[2], ct = r[3], st = r[4], asq = r[5], bsq = r[6];
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const T dx = px[e] - xc, dy = py[e] - yc;
+                        const T delx = ct * dx - st * dy;
+                        const T dely = st * dx + ct * dy;
+                        c[e] = asq * bsq - (bsq * (delx * delx) + asq * (dely * dely));
+                        cx[e] = T(-2) * (bsq * delx * ct + asq * dely * st);
+                        cy[e] = T(-2) * (-bsq * delx * st + asq * dely * ct);
+                    }
+                } else {  // EMI_PATH_TRACK: centre tabulated at the node times
+                    const int trk = (int)r[1];
+                    const T rsq = r[2];
+                    const int tset = a.track_sets > 1 ? b : 0;
+                    const size_t off = ((size_t)tset * a.ntracks + trk) * M + k0;
+                    T xc[VEC], yc[VEC];
+                    load_vec<T, VEC>(a.track_x + off, xc);
+                    load_vec<T, VEC>(a.track_y + off, yc);
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        const T dx = px[e] - xc[e], dy = py[e] - yc[e];
+                        c[e] = (dx * dx + dy * dy) * T(-1) + rsq;
+                        cx[e] = T(-2) * dx;
+                        cy[e] = T(-2) * dy;
+                    }
+                }
+                store_vec<T, VEC>(Cb + (size_t)j * M + k0, c);
+                if (JAC) {
+                    store_vec<T, VEC>(JCb + (size_t)(2 * j) * M + k0, cx);
+                    store_vec<T, VEC>(JCb + (size_t)(2 * j + 1) * M + k0, cy);
+                }
+            }
+        }
+    }
+    // ---- K3 cost quadrature: wave reduction, then across the block's waves --
+    __shared__ T wsum[EMI_NODE_THREADS / 64];
+    const T ws = wave_sum(lsum);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) wsum[wid] = ws;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T s = T(0);
+#pragma unroll
+        for (int i = 0; i < EMI_NODE_THREADS / 64; ++i) s += wsum[i];
+        a.cost_part[(size_t)b * gridDim.x + blockIdx.x] = s;
+    }
+}
+
+template <typename T>
+__global__ void emi_cost_finish_kernel(const T* __restrict__ part, T* __restrict__ cost, int B,
+                                       int nchunks, T scale) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    T s = T(0);
+    for (int c = 0; c < nchunks; ++c) s += part[(size_t)b * nchunks + c];
+    cost[b] = scale * s;
+}
+
+// ---------------------------------------------------------------------------
+// KH: Lagrangian Hessian node blocks (packed lower triangle, (NV)(NV+1)/2).
+//   H = sigma*sgn*h*w_k L_zz  - h sum_i lamF[i][k] f_i,zz  + sum_j lamC[j][k] c_j,zz
+// ---------------------------------------------------------------------------
+template <typename T, class Model>
+__global__ __launch_bounds__(EMI_NODE_THREADS) void emi_hess_kernel(HessArgs<T> a) {
+    constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV, NH = NV * (NV + 1) / 2;
+    const int b = blockIdx.y;
+    const int M = a.M;
+    const int k = blockIdx.x * EMI_NODE_THREADS + threadIdx.x;
+    if (k >= M) return;
+    T z[NV], cf[NS], H[NH];
+#pragma unroll
+    for (int v = 0; v < NS; ++v) z[v] = a.X[((size_t)b * NS + v) * M + k];
+#pragma unroll
+    for (int v = 0; v < NC; ++v) z[NS + v] = a.U[((size_t)b * NC + v) * M + k];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) cf[i] = -a.h * a.lamF[((size_t)b * NS + i) * M + k];
+#pragma unroll
+    for (int q = 0; q < NH; ++q) H[q] = T(0);
+    const T cL = a.sigma * a.sgn * a.h * a.w[k];
+    Model::hess(a.P, z, a.node_t[k], cL, cf, H);
+    const int np = a.np;
+    if (np > 0) {
+        const int set = a.path_sets > 1 ? b : 0;
+        const T* __restrict__ rec = a.path + (size_t)set * np * EMI_PATH_REC;
+        T hxx = T(0), hxy = T(0), hyy = T(0);
+        for (int j = 0; j < np; ++j) {
+            const T* __restrict__ r = rec + j * EMI_PATH_REC;
+            const int kind = (int)r[0];
+            const T mu = a.lamC[((size_t)b * np + j) * M + k];
+            if (kind == EMI_PATH_ELLIPSE) {
+                const T ct = r[3], st = r[4], asq = r[5], bsq = r[6];
+                hxx += mu * T(-2) * (bsq * ct * ct + asq * st * st);
+                hyy += mu * T(-2) * (bsq * st * st + asq * ct * ct);
+                hxy += mu * T(-2) * ct * st * (asq - bsq);
+            } else {  // disc / track: -2 I
+                hxx += mu * T(-2);
+                hyy += mu * T(-2);
+            }
+        }
+        const int lo = a.px < a.py ? a.px : a.py, hi = a.px < a.py ? a.py : a.px;
+        const int qxx = a.px * (a.px + 1) / 2 + a.px, qyy = a.py * (a.py + 1) / 2 + a.py;
+        const int qxy = hi * (hi + 1) / 2 + lo;
+#pragma unroll
+        for (int q = 0; q < NH; ++q)
+            H[q] += (q == qxx ? hxx : T(0)) + (q == qyy ? hyy : T(0)) + (q == qxy ? hxy : T(0));
+    }
+    T* __restrict__ Hb = a.H + (size_t)b * NH * M;
+#pragma unroll
+    for (int q = 0; q < NH; ++q) Hb[(size_t)q * M + k] = H[q];
+}
+
+}  // namespace emi

@@ -1,0 +1,208 @@
+// emi_rtc.hip -- model programs compiled at run time.
+//
+// ePSOPT evaluates the user's callbacks and their derivatives by interpreting an ADOL-C tape on the
+// CPU at every NLP evaluation (reference src/ePSOPT/ePSOPT.cpp:64-65, 186-276).  Here a model
+// arrives as the text of a struct with the Model interface of emi_models.hpp (written by hand, or
+// generated from traced callbacks by etol_amd/host/emi_trace.cpp); it is compiled ONCE for gfx950
+// with hiprtc against the same kernel templates libemi355x.so was built from (their headers are
+// embedded as text, tools/embed_src.py), and the resulting code object is launched exactly like
+// the built-in instantiations: node kernel, Hessian kernel and the even/odd MFMA defect kernel.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "emi_kernels.hpp"
+#include "emi_rtc_sources.inc"
+
+namespace emi {
+
+struct RtcModel {
+    hipModule_t mod = nullptr;
+    hipFunction_t nodes[2][2][2] = {};   // [vec2][jac][defect rows]
+    hipFunction_t hess = nullptr;
+    hipFunction_t ring = nullptr;        // even/odd MFMA defect kernel (f64, LDS permitting)
+    bool f32 = false;
+    int ns = 0, nc = 0;
+    size_t ring_lds = 0;
+};
+
+namespace {
+
+bool valid_identifier(const char* s) {
+    if (!s || !*s || (*s >= '0' && *s <= '9')) return false;
+    for (; *s; ++s)
+        if (!((*s >= 'a' && *s <= 'z') || (*s >= 'A' && *s <= 'Z') || (*s >= '0' && *s <= '9') || *s == '_')) return false;
+    return true;
+}
+
+size_t ring_lds_bytes(int ns) { return (size_t)3 * (2 * ns * FUSED_TI + 2 * 64) * 16 * sizeof(double); }
+// the ring kernel holds 16 accumulator registers per state and needs three stages in 160 KB of LDS
+bool ring_fits(int ns) { return ns <= 8 && ring_lds_bytes(ns) <= 160 * 1024; }
+
+struct Names {
+    std::string nodes[2][2][2], hess, ring;
+};
+
+Names kernel_names(const char* sn, bool f32, bool with_ring) {
+    Names n;
+    const std::string T = f32 ? "float" : "double";
+    const std::string model = std::string("emi::") + sn + "<" + T + ">";
+    for (int v = 0; v < 2; ++v)
+        for (int j = 0; j < 2; ++j)
+            for (int d = 0; d < 2; ++d)
+                n.nodes[v][j][d] = "emi::emi_nodes_kernel<" + T + ", " + model + ", " + (v ? "2" : "1") + ", " +
+                                   (j ? "true" : "false") + ", " + (d ? "true" : "false") + ">";
+    n.hess = "emi::emi_hess_kernel<" + T + ", " + model + ">";
+    if (with_ring) n.ring = "emi::emi_symdefect_ring_f64_kernel<" + model + ">";
+    return n;
+}
+
+// compile; on success *code holds the gfx950 code object and *lowered the mangled kernel names in
+// the order nodes[0][0][0..1], nodes[0][1][..], nodes[1][..][..], hess, ring
+int compile(bool f32, const char* sn, const char* source, int ns, int nc, std::vector<char>* code,
+            std::vector<std::string>* lowered, bool* has_ring, std::string* log) {
+    if (!valid_identifier(sn) || !source || ns < 1 || nc < 0 || ns + nc > 64) {
+        if (log) *log = "emi_set_model_source: bad struct name, null source or dimensions out of range";
+        return EMI_ERR_ARG;
+    }
+    const bool with_ring = !f32 && ring_fits(ns);
+    std::string prog = "#include \"emi_args.hpp\"\n#include \"emi_node_kernels.hpp\"\n";
+    if (with_ring) prog += "#include \"emi_symdefect_kernels.hpp\"\n";
+    prog += "namespace emi {\n";
+    prog += source;
+    prog += "\n}  // namespace emi\n";
+    char chk[256];
+    snprintf(chk, sizeof chk, "static_assert(emi::%s<double>::NS == %d && emi::%s<double>::NC == %d && emi::%s<double>::NV == %d, "
+             "\"model struct dimensions differ from emi_set_model_source(ns, nc)\");\n", sn, ns, sn, nc, sn, ns + nc);
+    prog += chk;
+
+    hiprtcProgram p;
+    if (hiprtcCreateProgram(&p, prog.c_str(), "emi_model_program.hip", emi_rtc_nfiles, emi_rtc_texts, emi_rtc_names) !=
+        HIPRTC_SUCCESS) {
+        if (log) *log = "hiprtcCreateProgram failed";
+        return EMI_ERR_HIP;
+    }
+    const Names nm = kernel_names(sn, f32, with_ring);
+    std::vector<const std::string*> order;
+    for (int v = 0; v < 2; ++v)
+        for (int j = 0; j < 2; ++j)
+            for (int d = 0; d < 2; ++d) order.push_back(&nm.nodes[v][j][d]);
+    order.push_back(&nm.hess);
+    if (with_ring) order.push_back(&nm.ring);
+    for (const std::string* s : order) hiprtcAddNameExpression(p, s->c_str());
+
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function"};
+    const hiprtcResult r = hiprtcCompileProgram(p, 4, opts);
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(p, &ls);
+    std::string l(ls, '\0');
+    if (ls) hiprtcGetProgramLog(p, &l[0]);
+    while (!l.empty() && l.back() == '\0') l.pop_back();
+    if (r != HIPRTC_SUCCESS) {
+        if (log) *log = std::string("model program does not compile (") + hiprtcGetErrorString(r) + "):\n" + l;
+        hiprtcDestroyProgram(&p);
+        return EMI_ERR_ARG;
+    }
+    if (log) *log = l;
+    lowered->clear();
+    for (const std::string* s : order) {
+        const char* low = nullptr;
+        if (hiprtcGetLoweredName(p, s->c_str(), &low) != HIPRTC_SUCCESS || !low) {
+            if (log) *log = "no lowered name for " + *s;
+            hiprtcDestroyProgram(&p);
+            return EMI_ERR_HIP;
+        }
+        lowered->push_back(low);
+    }
+    size_t cs = 0;
+    hiprtcGetCodeSize(p, &cs);
+    code->resize(cs);
+    hiprtcGetCode(p, code->data());
+    hiprtcDestroyProgram(&p);
+    *has_ring = with_ring;
+    return EMI_OK;
+}
+
+hipError_t launch(hipFunction_t f, dim3 grid, dim3 block, size_t lds, hipStream_t s, const void* args, size_t bytes) {
+    if (!f) return hipErrorInvalidDeviceFunction;
+    // one by-value struct parameter: hand it over as the packed argument buffer
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, const_cast<void*>(args), HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes,
+                      HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(f, grid.x, grid.y, grid.z, block.x, block.y, block.z, (unsigned)lds, s, nullptr,
+                                 config);
+}
+
+}  // namespace
+
+int rtc_check(bool f32, const char* struct_name, const char* source, int ns, int nc, std::string* log) {
+    std::vector<char> code;
+    std::vector<std::string> low;
+    bool ring = false;
+    return compile(f32, struct_name, source, ns, nc, &code, &low, &ring, log);
+}
+
+int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int nc, RtcModel** out, std::string* log) {
+    *out = nullptr;
+    std::vector<char> code;
+    std::vector<std::string> low;
+    bool ring = false;
+    const int st = compile(f32, struct_name, source, ns, nc, &code, &low, &ring, log);
+    if (st) return st;
+    RtcModel* m = new RtcModel();
+    m->f32 = f32;
+    m->ns = ns;
+    m->nc = nc;
+    hipError_t e = hipModuleLoadData(&m->mod, code.data());
+    size_t i = 0;
+    for (int v = 0; v < 2 && e == hipSuccess; ++v)
+        for (int j = 0; j < 2 && e == hipSuccess; ++j)
+            for (int d = 0; d < 2 && e == hipSuccess; ++d) e = hipModuleGetFunction(&m->nodes[v][j][d], m->mod, low[i++].c_str());
+    if (e == hipSuccess) e = hipModuleGetFunction(&m->hess, m->mod, low[i++].c_str());
+    if (e == hipSuccess && ring) {
+        e = hipModuleGetFunction(&m->ring, m->mod, low[i++].c_str());
+        m->ring_lds = ring_lds_bytes(ns);
+    }
+    if (e != hipSuccess) {
+        if (log) *log = std::string("loading the model code object failed: ") + hipGetErrorString(e);
+        rtc_destroy(m);
+        return EMI_ERR_HIP;
+    }
+    *out = m;
+    return EMI_OK;
+}
+
+void rtc_destroy(RtcModel* m) {
+    if (!m) return;
+    if (m->mod) (void)hipModuleUnload(m->mod);
+    delete m;
+}
+
+bool rtc_has_symdefect(const RtcModel* m) { return m && m->ring; }
+
+template <typename T>
+hipError_t rtc_launch_nodes(RtcModel* m, const NodeArgs<T>& a, bool jac, bool defect_rows, hipStream_t s) {
+    const bool vec2 = a.M % 2 == 0;
+    const int per_block = EMI_NODE_THREADS * (vec2 ? 2 : 1);
+    dim3 grid((a.M + per_block - 1) / per_block, a.B), block(EMI_NODE_THREADS);
+    return launch(m->nodes[vec2][jac][defect_rows], grid, block, 0, s, &a, sizeof a);
+}
+template hipError_t rtc_launch_nodes<double>(RtcModel*, const NodeArgs<double>&, bool, bool, hipStream_t);
+template hipError_t rtc_launch_nodes<float>(RtcModel*, const NodeArgs<float>&, bool, bool, hipStream_t);
+
+template <typename T> hipError_t rtc_launch_hess(RtcModel* m, const HessArgs<T>& a, hipStream_t s) {
+    dim3 grid((a.M + EMI_NODE_THREADS - 1) / EMI_NODE_THREADS, a.B), block(EMI_NODE_THREADS);
+    return launch(m->hess, grid, block, 0, s, &a, sizeof a);
+}
+template hipError_t rtc_launch_hess<double>(RtcModel*, const HessArgs<double>&, hipStream_t);
+template hipError_t rtc_launch_hess<float>(RtcModel*, const HessArgs<float>&, hipStream_t);
+
+hipError_t rtc_launch_symdefect(RtcModel* m, const SymDefectArgs& a, hipStream_t s) {
+    const int mtiles = (a.B + FUSED_TI - 1) / FUSED_TI, ntiles = (a.M / 2) / 64;
+    return launch(m->ring, dim3(mtiles * ntiles), dim3(256), m->ring_lds, s, &a, sizeof a);
+}
+
+}  // namespace emi

@@ -32,332 +32,9 @@
 
 #include "emi_kernels.hpp"
 #include "emi_models.hpp"
+#include "emi_symdefect_kernels.hpp"
 
 namespace emi {
-
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-// CT = 16-column tiles per wave (4 waves side by side): tile = 16 instances x 64*CT half-indices.
-// CT = 1 keeps a wave at ~216 registers, so three 96-register waves of the node kernel fit on
-// the same SIMD; CT = 2 halves the re-reads of X but takes the whole register file.
-template <class Model, int CT>
-__global__ __launch_bounds__(256, CT == 1 ? 2 : 1) void emi_symdefect_f64_kernel(SymDefectArgs a) {
-    constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
-    constexpr int TI = FUSED_TI, TM = NS * TI, TN = 64 * CT, BK = FUSED_BK, LDK = BK + 2;
-    constexpr int A_PASS = TM * (BK / 2) / 256;   // double2 pieces per thread for E/O
-    constexpr int B_PASS = TN * (BK / 2) / 256;   // and for De / Do
-    static_assert(TM * (BK / 2) % 256 == 0 && TN * (BK / 2) % 256 == 0, "staging shape");
-    static_assert(TN % 64 == 0 && TI == 16, "wave layout below assumes 16 instances x 64*CT columns");
-    constexpr int STAGE = (2 * TM + 2 * TN) * LDK;   // doubles per LDS buffer
-
-    extern __shared__ __attribute__((aligned(16))) double smem[];   // [2][STAGE]: E, O, De, Do
-
-    const int M = a.M, Hh = M >> 1, B = a.B;
-    const int mtiles = (B + TI - 1) / TI;
-    int bid = blockIdx.x;
-    {   // XCD-aware bijective remap: workgroups that share a De/Do panel share blockIdx % 8
-        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    }
-    // a.order 0: an XCD walks a De/Do panel over all instance groups (panel stays in its L2, X is
-    // re-read once per panel from the Infinity Cache); 1: the ntiles workgroups of one instance
-    // group run together on one XCD (X tiles are shared in L2, De/Do cycles through it)
-    const int ntiles_ = gridDim.x / mtiles;
-    const int ntile = a.order ? bid % ntiles_ : bid / mtiles;
-    const int mtile = a.order ? bid / ntiles_ : bid - ntile * mtiles;
-    const int inst0 = mtile * TI, i0 = ntile * TN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int r16 = lane & 15, kq = lane >> 4;
-
-    d4 acc_a[NS][CT], acc_b[NS][CT];
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            acc_a[s][c] = d4{0.0, 0.0, 0.0, 0.0};
-            acc_b[s][c] = d4{0.0, 0.0, 0.0, 0.0};
-        }
-
-    // ---- staging: next K tile global -> registers (e/o formed on the fly) -> other LDS buffer
-    double2 pe[A_PASS], po[A_PASS], pde[B_PASS], pdo[B_PASS];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int p = 0; p < A_PASS; ++p) {
-            const int idx = tid + 256 * p, row = idx >> 3, c2 = idx & 7;
-            const int inst = inst0 + (row & 15), st = row >> 4;
-            double2 v = make_double2(0.0, 0.0), m = v;
-            if (inst < B) {
-                const double* xr = a.X + ((size_t)inst * NS + st) * M;
-                const int j = k0 + 2 * c2;
-                v = *reinterpret_cast<const double2*>(xr + j);            // x_j, x_{j+1}
-                m = *reinterpret_cast<const double2*>(xr + (M - 2 - j));  // x_{N-j-1}, x_{N-j}
-            }
-            pe[p] = make_double2(v.x + m.y, v.y + m.x);
-            po[p] = make_double2(v.x - m.y, v.y - m.x);
-        }
-#pragma unroll
-        for (int p = 0; p < B_PASS; ++p) {
-            const int idx = tid + 256 * p, row = idx >> 3, c2 = idx & 7;
-            const size_t off = (size_t)(i0 + row) * Hh + k0 + 2 * c2;
-            const double2 te = *reinterpret_cast<const double2*>(a.De + off);
-            const double2 to = *reinterpret_cast<const double2*>(a.Do + off);
-            pde[p] = make_double2(te.x, te.y);
-            pdo[p] = make_double2(to.x, to.y);
-        }
-    };
-    auto lstore = [&](int buf) {
-        double* Es = smem + (size_t)buf * STAGE;
-        double* Os = Es + TM * LDK;
-        double* Des = Os + TM * LDK;
-        double* Dos = Des + TN * LDK;
-#pragma unroll
-        for (int p = 0; p < A_PASS; ++p) {
-            const int idx = tid + 256 * p, row = idx >> 3, c2 = idx & 7;
-            *reinterpret_cast<double2*>(Es + row * LDK + 2 * c2) = pe[p];
-            *reinterpret_cast<double2*>(Os + row * LDK + 2 * c2) = po[p];
-        }
-#pragma unroll
-        for (int p = 0; p < B_PASS; ++p) {
-            const int idx = tid + 256 * p, row = idx >> 3, c2 = idx & 7;
-            *reinterpret_cast<double2*>(Des + row * LDK + 2 * c2) = pde[p];
-            *reinterpret_cast<double2*>(Dos + row * LDK + 2 * c2) = pdo[p];
-        }
-    };
-
-    const int nkt = Hh / BK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) gload((kt + 1) * BK);   // in flight under this tile's MFMAs
-        const double* Es = smem + (size_t)cur * STAGE;
-        const double* Os = Es + TM * LDK;
-        const double* Db = Os + TM * LDK + (wid * (16 * CT) + r16) * LDK + kq;
-        const double* Ob = Db + TN * LDK;
-#pragma unroll 2
-        for (int ks = 0; ks < BK / 4; ++ks) {
-            double bfe[CT], bfo[CT];
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                bfe[c] = Db[c * 16 * LDK + ks * 4];
-                bfo[c] = Ob[c * 16 * LDK + ks * 4];
-            }
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const double afe = Es[(s * 16 + r16) * LDK + ks * 4 + kq];
-                const double afo = Os[(s * 16 + r16) * LDK + ks * 4 + kq];
-#pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    acc_a[s][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(afe, bfe[c], acc_a[s][c], 0, 0, 0);
-                    acc_b[s][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(afo, bfo[c], acc_b[s][c], 0, 0, 0);
-                }
-            }
-        }
-        if (kt + 1 < nkt) {
-            lstore(cur ^ 1);               // the other buffer: nobody reads it during this tile
-            __syncthreads();
-            cur ^= 1;
-        }
-    }
-
-    // ---- epilogue: defect = D.X - h f, forward node i and mirrored node N-i ---------------
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        const int col = wid * (16 * CT) + c * 16 + r16;
-        const int node_f = i0 + col, node_m = M - 1 - node_f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int inst = inst0 + kq + 4 * i;
-            if (inst >= B) continue;
-            const double* __restrict__ Xb = a.X + (size_t)inst * NS * M;
-            const double* __restrict__ Ub = a.U + (size_t)inst * NC * M;
-            double* __restrict__ Rb = a.RES + (size_t)inst * a.nres * M;
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const int node = side == 0 ? node_f : node_m;
-                double z[NV], f[NS];
-#pragma unroll
-                for (int v = 0; v < NS; ++v) z[v] = Xb[(size_t)v * M + node];
-#pragma unroll
-                for (int v = 0; v < NC; ++v) z[NS + v] = Ub[(size_t)v * M + node];
-                Model::f(a.P, z, a.node_t[node], f);
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const double dx = side == 0 ? acc_a[s][c][i] + acc_b[s][c][i] : acc_b[s][c][i] - acc_a[s][c][i];
-                    Rb[(size_t)s * M + node] = dx - a.h * f[s];
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Ring variant (CT = 1): operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4, no
-// staging registers) into a 3-stage ring, two K tiles ahead of the MFMAs, with a COUNTED vmcnt so
-// that the loads stay in flight across the one barrier per K tile.  Raw X tiles are stored (the
-// forward range and the mirrored range); e = x_j + x_{N-j}, o = x_j - x_{N-j} are formed when the
-// fragments are read.  An LDS-DMA wave instruction writes 1 KB linearly (8 rows of 128 B), so the
-// rows cannot be padded: instead 16-byte chunk c of row r is stored at chunk position
-// c ^ ((r >> 1) & 7) (the swizzle is applied to the per-lane SOURCE address and again to the read
-// address), which keeps the ds_read_b64 fragment reads conflict-free.
-// With no staging registers a wave needs ~150 VGPRs, and two K tiles of look-ahead tolerate the
-// operand latency seen while the node kernel saturates HBM on the same CUs.
-// ---------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* emi_lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* emi_glb_ptr_t;
-
-template <class Model>
-__global__ __launch_bounds__(256, 2) void emi_symdefect_ring_f64_kernel(SymDefectArgs a) {
-    constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
-    constexpr int TI = FUSED_TI, TM = NS * TI, TN = 64, BK = 16, NST = 3;
-    constexpr int STAGE = (2 * TM + 2 * TN) * BK;        // doubles per ring stage
-    constexpr int NINSTR = (2 * TM + 2 * TN) * 8 / 64;   // LDS-DMA wave instructions per stage
-    constexpr int L = NINSTR / 4;                        // per wave (4 waves)
-    static_assert(NINSTR % 4 == 0, "stage does not split evenly over 4 waves");
-
-    extern __shared__ __attribute__((aligned(16))) double smem[];   // [NST][STAGE]: XF, XM, De, Do
-
-    const int M = a.M, Hh = M >> 1, B = a.B;
-    const int mtiles = (B + TI - 1) / TI;
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    }
-    // a.order 0: an XCD walks a De/Do panel over all instance groups (panel stays in its L2, X is
-    // re-read once per panel from the Infinity Cache); 1: the ntiles workgroups of one instance
-    // group run together on one XCD (X tiles are shared in L2, De/Do cycles through it)
-    const int ntiles_ = gridDim.x / mtiles;
-    const int ntile = a.order ? bid % ntiles_ : bid / mtiles;
-    const int mtile = a.order ? bid / ntiles_ : bid - ntile * mtiles;
-    const int inst0 = mtile * TI, i0 = ntile * TN;
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, kq = lane >> 4;
-
-    // ---- per-lane source pointers of this wave's L DMA instructions (tile 0), fixed per launch
-    const double* src[L];
-    int kdir[L];                                       // +1: advances with k0, -1: mirrored range
-#pragma unroll
-    for (int t = 0; t < L; ++t) {
-        const int q = (wid + 4 * t) * 64 + lane;       // 16-byte chunk id within the stage
-        int row, p;
-        if (q < 2 * TM * 8) {
-            const bool mir = q >= TM * 8;
-            const int qr = mir ? q - TM * 8 : q;
-            row = qr >> 3; p = qr & 7;
-            const int c = p ^ ((row >> 1) & 7);
-            int inst = inst0 + (row & 15);
-            inst = inst < B ? inst : B - 1;            // rows past the batch are never written out
-            const double* xr = a.X + ((size_t)inst * NS + (row >> 4)) * M;
-            src[t] = mir ? xr + (M - BK) + 2 * c : xr + 2 * c;
-            kdir[t] = mir ? -1 : 1;
-        } else {
-            const bool od = q >= (2 * TM + TN) * 8;
-            const int qr = q - (2 * TM + (od ? TN : 0)) * 8;
-            row = qr >> 3; p = qr & 7;
-            const int c = p ^ ((row >> 1) & 7);
-            src[t] = (od ? a.Do : a.De) + (size_t)(i0 + row) * Hh + 2 * c;
-            kdir[t] = 1;
-        }
-    }
-    auto issue = [&](int stage, int kt) {
-        double* base = smem + (size_t)stage * STAGE;
-#pragma unroll
-        for (int t = 0; t < L; ++t) {
-            double* dst = base + (size_t)(wid + 4 * t) * 128;      // wave-uniform: 1 KB per instruction
-            const double* g = src[t] + (ptrdiff_t)kdir[t] * kt * BK;
-            __builtin_amdgcn_global_load_lds((emi_glb_ptr_t)g, (emi_lds_ptr_t)dst, 16, 0, 0);
-        }
-    };
-
-    d4 acc_a[NS], acc_b[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        acc_a[s] = d4{0.0, 0.0, 0.0, 0.0};
-        acc_b[s] = d4{0.0, 0.0, 0.0, 0.0};
-    }
-
-    const int nkt = Hh / BK;
-    issue(0, 0);
-    if (nkt > 1) issue(1, 1);
-    for (int kt = 0; kt < nkt; ++kt) {
-        // tile kt has landed once all but this wave's L youngest DMA instructions are done
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");     // every wave's part landed; stage (kt-1)%3 is free
-        if (kt + 2 < nkt && !(a.ablate & 2)) issue((kt + 2) % NST, kt + 2);
-        if (a.ablate & 1) continue;
-        const double* XF = smem + (size_t)(kt % NST) * STAGE;
-        const double* XM = XF + TM * BK;
-        const double* DE = XM + TM * BK;
-        const double* DO = DE + TN * BK;
-        // Fragment reads are software-pipelined by hand: with one wave per SIMD nothing else
-        // hides the LDS latency, so the raw values of k-step ks+1 are requested before the
-        // MFMAs of k-step ks are issued (the compiler then waits with a counted lgkmcnt).
-        const int rb = wid * 16 + r16, swb = (rb >> 1) & 7;
-        double xf_c[NS], xm_c[NS], be_c, bo_c;
-        auto frag = [&](int ks, double (&xf)[NS], double (&xm)[NS], double& be, double& bo) {
-            const int kk = ks * 4 + kq, km = BK - 1 - kk;          // forward / mirrored position
-            const int pb = ((kk >> 1) ^ swb) * 2 + (kk & 1);
-            be = DE[rb * BK + pb];
-            bo = DO[rb * BK + pb];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int r = s * 16 + r16, sw = (r >> 1) & 7;
-                xf[s] = XF[r * BK + ((kk >> 1) ^ sw) * 2 + (kk & 1)];
-                xm[s] = XM[r * BK + ((km >> 1) ^ sw) * 2 + (km & 1)];
-            }
-        };
-        frag(0, xf_c, xm_c, be_c, bo_c);
-#pragma unroll
-        for (int ks = 0; ks < BK / 4; ++ks) {
-            double xf_n[NS], xm_n[NS], be_n = 0.0, bo_n = 0.0;
-            if (ks + 1 < BK / 4) frag(ks + 1, xf_n, xm_n, be_n, bo_n);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                acc_a[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf_c[s] + xm_c[s], be_c, acc_a[s], 0, 0, 0);
-                acc_b[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf_c[s] - xm_c[s], bo_c, acc_b[s], 0, 0, 0);
-            }
-            if (ks + 1 < BK / 4) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s) { xf_c[s] = xf_n[s]; xm_c[s] = xm_n[s]; }
-                be_c = be_n;
-                bo_c = bo_n;
-            }
-        }
-    }
-
-    // ---- epilogue: defect = D.X - h f, forward node i and mirrored node N-i ---------------
-    const int col = wid * 16 + r16;
-    const int node_f = i0 + col, node_m = M - 1 - node_f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int inst = inst0 + kq + 4 * i;
-        if (inst >= B || (a.ablate & 4)) continue;
-        const double* __restrict__ Xb = a.X + (size_t)inst * NS * M;
-        const double* __restrict__ Ub = a.U + (size_t)inst * NC * M;
-        double* __restrict__ Rb = a.RES + (size_t)inst * a.nres * M;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int node = side == 0 ? node_f : node_m;
-            double z[NV], f[NS];
-#pragma unroll
-            for (int v = 0; v < NS; ++v) z[v] = Xb[(size_t)v * M + node];
-#pragma unroll
-            for (int v = 0; v < NC; ++v) z[NS + v] = Ub[(size_t)v * M + node];
-            Model::f(a.P, z, a.node_t[node], f);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const double dx = side == 0 ? acc_a[s][i] + acc_b[s][i] : acc_b[s][i] - acc_a[s][i];
-                Rb[(size_t)s * M + node] = dx - a.h * f[s];
-            }
-        }
-    }
-}
 
 template <class Model>
 static hipError_t launch_symdefect_ring_model(const SymDefectArgs& a, hipStream_t s, bool set_attr) {

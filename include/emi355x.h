@@ -19,6 +19,13 @@
  *                      (integrand_cost :186-216, dae :218-276) -- the user's
  *                      f_t closures cannot run on the device, so a model id
  *                      + parameter block selects a hand-written kernel
+ *   emi_set_model_source  the same callbacks for a model the library has no
+ *                      kernel for: where ePSOPT records the user's closures on
+ *                      an ADOL-C tape and interprets it at every evaluation
+ *                      (derivatives = "automatic", ePSOPT.cpp:64), the host
+ *                      records them once, differentiates the trace and hands
+ *                      over the text of a model struct; it is compiled for
+ *                      gfx950 at this call and runs in the same kernels
  *   emi_set_path       the path rows counted at ePSOPT.cpp:58 and produced
  *                      at :261-270; row formulas follow
  *                      src/Examples/PSOPT/etol_psopt_example1.cpp:163-182
@@ -78,7 +85,8 @@ enum {
 enum {
     EMI_MODEL_POINTMASS2D = 0,  /* ns=2 nc=2: etol_psopt_example1.cpp:101-138 */
     EMI_MODEL_QUADROTOR2D = 1,  /* ns=6 nc=2: planar quadrotor (build-defined) */
-    EMI_MODEL_FIXEDWING12 = 2   /* ns=12 nc=4: rigid-body fixed wing (build-defined) */
+    EMI_MODEL_FIXEDWING12 = 2,  /* ns=12 nc=4: rigid-body fixed wing (build-defined) */
+    EMI_MODEL_SOURCE = 100      /* installed by emi_set_model_source (emi_layout_t.model)  */
 };
 
 /* path-row kinds; one record = EMI_PATH_REC reals: {kind, c0..c6} */
@@ -138,6 +146,21 @@ int emi_set_mesh(emi_ctx_t ctx, int M, const double* tau, const double* w,
                  const double* D, double t0, double tf);
 int emi_set_model(emi_ctx_t ctx, int model, const double* params, int nparams,
                   int maximize);
+/* Model given as C++ text: the definition of
+ *     template <typename T> struct <struct_name> { NS, NC, NV, f, jac, cost, grad, hess };
+ * with the interface of the built-in models (etol_amd/csrc/emi_models.hpp; the
+ * text may use EMI_DEV, ModelParams<T> and the emi_sin/cos/tan/exp/log/sqrt/pow
+ * helpers).  It is compiled for gfx950 here (hiprtc) together with the
+ * library's kernel templates; on a compile error the status is EMI_ERR_ARG and
+ * emi_last_error() holds the compiler log.  params (<= 16) reach the struct as
+ * ModelParams<T>.  Replaces a previous emi_set_model / emi_set_model_source.   */
+int emi_set_model_source(emi_ctx_t ctx, const char* struct_name, const char* source,
+                         int ns, int nc, const double* params, int nparams,
+                         int maximize);
+/* Compile-only check of such a text (no device needed): EMI_OK or EMI_ERR_ARG
+ * with up to log_len-1 characters of the compiler log in log (may be NULL).   */
+int emi_check_model_source(const char* struct_name, const char* source, int ns,
+                           int nc, int f32, char* log, size_t log_len);
 int emi_set_batch(emi_ctx_t ctx, int B);
 /* recs: [nsets][np][EMI_PATH_REC]; nsets is 1 (shared) or B (per instance) */
 int emi_set_path(emi_ctx_t ctx, int np, int nsets, const double* recs,

@@ -1,0 +1,186 @@
+"""Models compiled at run time (emi_set_model_source) on the GPU: a traced user model must give what
+the hand-written kernel of the same model gives, and what the equations give.  -m gpu
+
+ePSOPT evaluates such models by interpreting an ADOL-C tape per node on the CPU (reference
+src/ePSOPT/ePSOPT.cpp:64-65, 218-276); here the trace is differentiated once on the host and the
+generated struct runs in the library's node / Hessian / MFMA defect kernels."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import oracle_lib as O
+from test_gpu_parity import TOL_DEFECT, TOL_NODE, check
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def traced_source(which):
+    import torch  # noqa: F401
+    lib = C.CDLL(os.path.join(HERE, "harness", "libetol_harness.so"))
+    lib.harness_traced_model_source.restype = C.c_char_p
+    return lib.harness_traced_model_source(which).decode()
+
+
+def _quad_evaluators(name, f32=False):
+    import etol_amd as E
+    c = cases.case_inputs(name)
+    evs = []
+    for traced in (True, False):
+        ev = E.Evaluator(0, f32=f32)
+        ev.set_mesh(c["M"], c["t0"], c["tf"])
+        if traced:
+            ev.set_model_source("TracedModel", traced_source(0), 6, 2)
+        else:
+            ev.set_model(c["model"], c["params"])
+        ev.set_batch(c["B"])
+        if c.get("recs") is not None:
+            ev.set_path(c["recs"], 0, 1)
+        evs.append(ev)
+    return c, evs[0], evs[1]
+
+
+@pytest.mark.parametrize("name,ring", [("quad_256", True), ("quad_1024_obs", True), ("quad_ragged", False)])
+def test_traced_quadrotor_matches_oracle_and_builtin_kernel(built, name, ring):
+    import etol_amd as E
+    c, tr, bi = _quad_evaluators(name)
+    assert tr.layout.model == E.MODEL_SOURCE
+    assert tr.uses_fused_kernel == ring          # even/odd MFMA kernel instantiated for the traced struct
+    got = tr.eval_host(c["X"], c["U"])
+    ref = O.evaluate(c["model"], c["params"], c["M"], (tr.tau, tr.w, tr.D), c["t0"], c["tf"], c["X"], c["U"],
+                     c.get("recs"))
+    check(c, tr, got, ref)
+    # against the hand-written kernel: same arithmetic up to the order of a few products
+    hand = bi.eval_host(c["X"], c["U"])
+    for a, b in zip(got, hand):
+        assert np.abs(a - b).max() / (np.abs(b).max() + 1.0) < 1e-13
+    # sequential general path gives the same rows
+    tr.set_option("overlap", 0)
+    seq = tr.eval_host(c["X"], c["U"])
+    check(c, tr, seq, ref)
+    # Lagrangian Hessian blocks
+    rng = np.random.default_rng(5)
+    lay = tr.layout
+    lamF = rng.standard_normal((c["B"], lay.ns, c["M"]))
+    lamC = rng.standard_normal((c["B"], lay.np, c["M"]))
+    H = tr.hess_host(c["X"], c["U"], lamF, lamC, sigma=0.7)
+    Hb = bi.hess_host(c["X"], c["U"], lamF, lamC, sigma=0.7)
+    assert np.abs(H - Hb).max() / (np.abs(Hb).max() + 1.0) < 1e-13
+
+
+def _custom_reference(X, U, tn, D, w, h):
+    """numpy long-double restatement of the model of harness_traced_model_source(1)."""
+    ld = np.longdouble
+    a, b, c = X[:, 0].astype(ld), X[:, 1].astype(ld), U[:, 0].astype(ld)
+    t = tn.astype(ld)[None, :]
+    e3, q, sq = np.exp(a * ld(0.3)), 1 + b * b, np.sqrt(2 + a * a)
+    f0 = e3 / q + np.tan(c) * sq - t
+    lg, pw = np.log(3 + a * b + c * c), (2 + b) ** ld(1.5)
+    s1 = np.sin(1 + b * ld(0.1))
+    f1 = lg * pw - np.cos(a - c) / s1
+    L = c * c * np.exp(-a) + b * np.sin(a * c)
+    J = np.zeros((X.shape[0], 2, 3, X.shape[2]), dtype=ld)
+    J[:, 0, 0] = ld(0.3) * e3 / q + np.tan(c) * a / sq
+    J[:, 0, 1] = -e3 * 2 * b / q ** 2
+    J[:, 0, 2] = sq / np.cos(c) ** 2
+    inner = 3 + a * b + c * c
+    J[:, 1, 0] = b / inner * pw + np.sin(a - c) / s1
+    J[:, 1, 1] = a / inner * pw + lg * ld(1.5) * np.sqrt(2 + b) + np.cos(a - c) * np.cos(1 + b * ld(0.1)) * ld(0.1) / s1 ** 2
+    J[:, 1, 2] = 2 * c / inner * pw - np.sin(a - c) / s1
+    g = np.stack([-c * c * np.exp(-a) + b * c * np.cos(a * c), np.sin(a * c), 2 * c * np.exp(-a) + b * a * np.cos(a * c)], 1)
+    F = np.stack([f0, f1], 1)
+    DX = np.einsum("kj,bij->bik", D.astype(ld), X.astype(ld))
+    RES = DX - h * F
+    cost = h * np.einsum("k,bk->b", w.astype(ld), L)
+    return RES.astype(np.float64), J.astype(np.float64), g.astype(np.float64), cost.astype(np.float64)
+
+
+@pytest.mark.parametrize("M,B,ring", [(128, 20, True), (20, 3, False), (384, 33, True)])
+def test_custom_traced_model_against_numpy(built, M, B, ring):
+    """A model the library has no kernel for (2 states, 1 control, explicit time dependence, every
+    traced elementary function)."""
+    import etol_amd as E
+    rng = np.random.default_rng(100 + M)
+    X = rng.uniform(0.2, 1.2, (B, 2, M))
+    U = rng.uniform(0.2, 1.2, (B, 1, M))
+    t0, tf = 0.25, 3.0
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, t0, tf)
+    ev.set_model_source("TracedModel", traced_source(1), 2, 1)
+    ev.set_batch(B)
+    assert ev.uses_fused_kernel == ring
+    RES, VALS, COST = ev.eval_host(X, U)
+    h = (tf - t0) / 2
+    rRES, J, g, rcost = _custom_reference(X, U, ev.node_t, ev.D, ev.w, h)
+    scale = np.einsum("kj,bij->bik", np.abs(ev.D), np.abs(X)) + np.abs(rRES) + 1.0
+    assert (np.abs(RES - rRES) / scale).max() < TOL_DEFECT
+    dd = np.diag(ev.D)
+    for i in range(2):
+        for v in range(3):
+            ref = -h * J[:, i, v] + (dd[None, :] if v == i else 0.0)
+            got = VALS[:, i * 3 + v]
+            assert np.abs(got - ref).max() / (np.abs(ref).max() + 1.0) < 10 * TOL_NODE, (i, v)
+    for v in range(3):
+        ref = h * ev.w[None, :] * g[:, v]
+        assert np.abs(VALS[:, 6 + v] - ref).max() / (np.abs(ref).max() + 1.0) < 10 * TOL_NODE
+    assert np.abs(COST - rcost).max() / (np.abs(rcost).max() + 1.0) < 1e-13
+    # Hessian blocks: central differences of the device's own analytic Jacobian / gradient values
+    lamF = rng.standard_normal((B, 2, M))
+    H = ev.hess_host(X, U, lamF, None, sigma=0.9)
+    eps = 1e-6
+    Z = np.concatenate([X, U], 1)
+    for q in range(3):
+        Zp, Zm = Z.copy(), Z.copy()
+        Zp[:, q] += eps
+        Zm[:, q] -= eps
+        _, Vp, _ = ev.eval_host(Zp[:, :2], Zp[:, 2:])
+        _, Vm, _ = ev.eval_host(Zm[:, :2], Zm[:, 2:])
+        dV = (Vp - Vm) / (2 * eps)
+        for v in range(3):
+            # d/dz_q of  0.9 * cost gradient_v + sum_i lamF_i * (defect Jacobian (i,v) without the D_kk term)
+            ref = 0.9 * dV[:, 6 + v] + sum(lamF[:, i] * dV[:, i * 3 + v] for i in range(2))
+            hi, lo = max(v, q), min(v, q)
+            got = H[:, hi * (hi + 1) // 2 + lo]
+            # the (i,i) Jacobian entries carry D_kk (up to N(N+1)/4): differencing them loses its ulp / eps
+            tol = 1e-7 * (np.abs(ref).max() + 1.0) + 4 * np.finfo(float).eps * np.abs(dd)[None, :] / eps * np.abs(lamF).max()
+            assert (np.abs(got - ref) < tol).all(), (v, q)
+
+
+def test_traced_quadrotor_f32_context(built):
+    c, tr, bi = _quad_evaluators("quad_256", f32=True)
+    X = c["X"].astype(np.float32).astype(np.float64)
+    U = c["U"].astype(np.float32).astype(np.float64)
+    got = tr.eval_host(X, U)
+    hand = bi.eval_host(X, U)
+    for a, b in zip(got, hand):
+        assert np.abs(a - b).max() / (np.abs(b).max() + 1.0) < 2e-6
+
+
+def test_model_source_replaces_and_is_replaced(built):
+    """emi_set_model after emi_set_model_source (and back) switches kernels cleanly; a text that does
+    not compile leaves the previous model in place and reports the compiler log."""
+    import etol_amd as E
+    from etol_amd import _lib
+    c = cases.case_inputs("quad_256")
+    ev = E.Evaluator(0)
+    ev.set_mesh(c["M"], c["t0"], c["tf"])
+    ev.set_model(c["model"], c["params"])
+    ev.set_batch(c["B"])
+    a = ev.eval_host(c["X"], c["U"])
+    ev.set_model_source("TracedModel", traced_source(0), 6, 2)
+    b = ev.eval_host(c["X"], c["U"])
+    with pytest.raises(_lib.EmiError) as ei:
+        ev.set_model_source("TracedModel", "template <typename T> struct TracedModel { int x };", 6, 2)
+    assert "error" in str(ei.value)
+    b2 = ev.eval_host(c["X"], c["U"])
+    ev.set_model(c["model"], c["params"])
+    a2 = ev.eval_host(c["X"], c["U"])
+    for p, q in zip(a, a2):
+        assert np.array_equal(p, q)
+    for p, q in zip(b, b2):
+        assert np.array_equal(p, q)
+    for p, q in zip(a, b):
+        assert np.abs(p - q).max() / (np.abs(p).max() + 1.0) < 1e-13

@@ -106,3 +106,38 @@ def test_traced_every_operation_against_sympy(built, tmp_path):
         for got, ref in ((f, ref_f), (J, ref_J), (g, ref_g), (H, ref_H)):
             assert np.abs(got - ref).max() < 1e-12 * (np.abs(ref).max() + 1)
         assert abs(L - ev(Lc)) < 1e-13 * (abs(ev(Lc)) + 1)
+
+
+def _check_source(src, ns, nc, f32=0, name="TracedModel"):
+    import torch  # noqa: F401
+    from etol_amd import _lib
+    lib = _lib.load()
+    log = C.create_string_buffer(1 << 16)
+    st = lib.emi_check_model_source(name.encode(), src.encode(), ns, nc, f32, log, len(log))
+    return st, log.value.decode(errors="replace")
+
+
+@pytest.mark.parametrize("which,ns,nc", [(0, 6, 2), (1, 2, 1)])
+def test_generated_model_compiles_against_the_kernel_templates(built, which, ns, nc):
+    """hiprtc cross-compiles for gfx950 without a GPU: the generated struct must instantiate the node,
+    Hessian and even/odd MFMA defect kernels the library itself is built from."""
+    import torch  # noqa: F401
+    lib = C.CDLL(os.path.join(HERE, "harness", "libetol_harness.so"))
+    lib.harness_traced_model_source.restype = C.c_char_p
+    src = lib.harness_traced_model_source(which).decode()
+    for f32 in (0, 1):
+        st, log = _check_source(src, ns, nc, f32)
+        assert st == 0, log
+
+
+def test_model_source_errors_are_reported(built):
+    st, log = _check_source("template <typename T> struct TracedModel { static constexpr int NS = 2; };", 2, 1)
+    assert st == 1 and "error" in log
+    # dimension mismatch between the text and the call
+    lib = C.CDLL(os.path.join(HERE, "harness", "libetol_harness.so"))
+    lib.harness_traced_model_source.restype = C.c_char_p
+    src = lib.harness_traced_model_source(1).decode()
+    st, log = _check_source(src, 3, 1)
+    assert st == 1 and "dimensions differ" in log
+    st, log = _check_source(src, 2, 1, name="not a name")
+    assert st == 1
