@@ -15,6 +15,7 @@
 
 #include "emi_nlp.hpp"
 #include "emi_transcribe.hpp"
+#include "emi_trace.hpp"
 
 namespace ETOL {
 
@@ -90,6 +91,7 @@ PathBlock track_rows(const std::list<track_t>& tracks, const Symbol& sx, const S
 // ---------------------------------------------------------------------------------------------
 struct eMI355X::Device : public mi355x::NlpEvaluator {
     emi_ctx_t ctx = nullptr;
+    bool source_installed = false;       // the traced model's code object is loaded in ctx
     ~Device() override {
         if (ctx) emi_destroy(ctx);
     }
@@ -124,30 +126,56 @@ mi355x::Prob* eMI355X::getProblem() { return &_problem; }
 // One call per callback, with Symbols in the anys; collects the model and the path table.
 void eMI355X::traceCallbacks() {
     mi355x::Prob& P = _problem;
+    mi355x::Trace::active().clear();     // the handles below are the inputs of a fresh trace
     vector_t x, u;
     for (size_t i = 0; i < getNStates(); ++i) x.push_back(mi355x::Symbol{mi355x::Symbol::STATE, i});
     for (size_t j = 0; j < getNControls(); ++j) u.push_back(mi355x::Symbol{mi355x::Symbol::CONTROL, j});
     const std::any tsym = mi355x::Symbol{mi355x::Symbol::TIME, 0};
     if (_objective == NULL) die("no objective function set");
     if (_gradient.size() != getNStates()) die("setGradient needs one function per state");
+    P.model_source.clear();
     try {
+        bool traced = false;
+        int cost_node = -1;
+        std::vector<int> f_nodes;
         {
             vector_t params = {std::string()};
             std::vector<std::string> pnames = {std::string("")};
-            const mi355x::ModelTerm t =
-                std::any_cast<mi355x::ModelTerm>((*_objective)(x, u, params, pnames, tsym, getDt()));
-            if (t.row != -1) die("the objective callback must return mi355x::objective(...)");
-            P.model = t.model;
-            P.model_params = t.params;
+            const std::any out = (*_objective)(x, u, params, pnames, tsym, getDt());
+            if (out.type() == typeid(mi355x::Var)) {
+                // computed with the handles: a traced model (the ePSOPT way of writing callbacks)
+                traced = true;
+                cost_node = std::any_cast<mi355x::Var>(out).node;
+                if (cost_node < 0) die("the objective callback returned a Var that is not part of the trace");
+            } else {
+                const mi355x::ModelTerm t = std::any_cast<mi355x::ModelTerm>(out);
+                if (t.row != -1) die("the objective callback must return mi355x::objective(...) or a traced Var");
+                P.model = t.model;
+                P.model_params = t.params;
+            }
         }
         for (size_t i = 0; i < getNStates(); ++i) {
             vector_t params = {std::string()};
             std::vector<std::string> pnames = {std::string("")};
-            const mi355x::ModelTerm t =
-                std::any_cast<mi355x::ModelTerm>((*_gradient.at(i))(x, u, params, pnames, tsym, getDt()));
+            const std::any out = (*_gradient.at(i))(x, u, params, pnames, tsym, getDt());
+            if (traced) {
+                if (out.type() != typeid(mi355x::Var))
+                    die("gradient callback " + std::to_string(i) + " must return a traced Var like the objective");
+                f_nodes.push_back(std::any_cast<mi355x::Var>(out).node);
+                if (f_nodes.back() < 0) die("gradient callback " + std::to_string(i) + " returned a Var outside the trace");
+                continue;
+            }
+            const mi355x::ModelTerm t = std::any_cast<mi355x::ModelTerm>(out);
             if (t.row != (int)i || t.model != P.model || t.params != P.model_params)
                 die("gradient callback " + std::to_string(i) + " does not describe state derivative " +
                     std::to_string(i) + " of the objective's model");
+        }
+        if (traced) {
+            // derivatives and code for the device, once (ePSOPT: ADOL-C tape re-interpreted per evaluation)
+            P.model = EMI_MODEL_SOURCE;
+            P.model_params.clear();
+            P.model_source = mi355x::Trace::active().generate_model("TracedModel", (int)getNStates(),
+                                                                     (int)getNControls(), f_nodes, cost_node);
         }
         P.path_records.clear();
         P.tracks.clear();
@@ -225,8 +253,8 @@ void eMI355X::setup() {
 
     traceCallbacks();
     setMesh(P.nodes);
-    int ns = 0, nc = 0, npar = 0;
-    if (emi_model_dims(P.model, &ns, &nc, &npar) != EMI_OK) die("unknown device model");
+    int ns = (int)P.nstates, nc = (int)P.ncontrols, npar = 0;
+    if (P.model != EMI_MODEL_SOURCE && emi_model_dims(P.model, &ns, &nc, &npar) != EMI_OK) die("unknown device model");
     if ((size_t)ns != P.nstates || (size_t)nc != P.ncontrols)
         die("the device model has " + std::to_string(ns) + " states / " + std::to_string(nc) +
             " controls, the configuration has " + std::to_string(P.nstates) + " / " + std::to_string(P.ncontrols));
@@ -277,8 +305,15 @@ void eMI355X::configureDevice(Device* dev) {
     }
     emi_ctx_t c = dev->ctx;
     must(emi_set_mesh(c, (int)P.nodes, P.tau.data(), P.w.data(), P.D.data(), P.t0, P.tf), c, "emi_set_mesh");
-    must(emi_set_model(c, P.model, P.model_params.data(), (int)P.model_params.size(), isMaximized() ? 1 : 0), c,
-         "emi_set_model");
+    if (P.model == EMI_MODEL_SOURCE) {
+        if (!dev->source_installed)      // compiled for gfx950 once per context; meshes come and go
+            must(emi_set_model_source(c, "TracedModel", P.model_source.c_str(), (int)P.nstates, (int)P.ncontrols,
+                                      nullptr, 0, isMaximized() ? 1 : 0), c, "emi_set_model_source");
+        dev->source_installed = true;
+    } else {
+        must(emi_set_model(c, P.model, P.model_params.data(), (int)P.model_params.size(), isMaximized() ? 1 : 0), c,
+             "emi_set_model");
+    }
     must(emi_set_batch(c, 1), c, "emi_set_batch");
     if (P.ntracks)
         must(emi_set_tracks(c, (int)P.ntracks, 1, P.track_x.data(), P.track_y.data()), c, "emi_set_tracks");
@@ -320,11 +355,10 @@ double eMI355X::odeError(const std::vector<double>& z, std::vector<double>* z_fi
     for (size_t j = 0; j < nc; ++j)      // the interpolant of a bounded control may overshoot: clip
         for (size_t k = 0; k < M2; ++k)
             zf[(ns + j) * M2 + k] = std::min(std::max(zf[(ns + j) * M2 + k], P.control_lower[j]), P.control_upper[j]);
-    Device fine;
-    configureDevice(&fine);
+    configureDevice(_dev.get());         // the solve context, on the fine mesh for one evaluation
     std::vector<double> RES((ns + P.npath) * M2), cost(1);
-    must(emi_eval_host(fine.ctx, zf.data(), zf.data() + ns * M2, RES.data(), nullptr, cost.data(),
-                       EMI_EVAL_ALL | EMI_EVAL_NOJAC), fine.ctx, "emi_eval_host (ODE error)");
+    must(emi_eval_host(_dev->ctx, zf.data(), zf.data() + ns * M2, RES.data(), nullptr, cost.data(),
+                       EMI_EVAL_ALL | EMI_EVAL_NOJAC), _dev->ctx, "emi_eval_host (ODE error)");
     const double h = (P.tf - P.t0) / 2.0;
     double err = 0;
     for (size_t i = 0; i < ns; ++i) {
@@ -341,6 +375,7 @@ double eMI355X::odeError(const std::vector<double>& z, std::vector<double>* z_fi
     if (nodes_fine) *nodes_fine = M2;
     // back to the coarse mesh (the caller decides whether to adopt a finer one)
     P.nodes = M; P.tau = tau; P.w = w; P.D = D_keep; P.track_x = tx_keep; P.track_y = ty_keep;
+    configureDevice(_dev.get());
     return err;
 }
 

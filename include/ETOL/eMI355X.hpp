@@ -60,6 +60,7 @@ struct Prob {
     size_t nstates = 0, ncontrols = 0, nodes = 0, npath = 0;
     int model = -1;
     std::vector<double> model_params;
+    std::string model_source;                      // model == EMI_MODEL_SOURCE: struct generated from the traced callbacks
     double t0 = 0, tf = 0;
     std::vector<double> tau, w, D;                 // LGL mesh
     std::vector<double> path_records;              // [npath][EMI_PATH_REC]

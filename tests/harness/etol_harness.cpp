@@ -161,8 +161,26 @@ extern "C" int harness_solve_example1_oracle(const char* xml, const char* oracle
     return 0;
 }
 
+// ---- traced models: the quadrotor written with mi355x::Var arithmetic, as a user would -----------
+namespace {
+// x = (px, pz, theta, vx, vz, omega), u = (T, tau); same equations as EMI_MODEL_QUADROTOR2D
+mx::Var traced_quad_rhs(const std::vector<mx::Var>& x, const std::vector<mx::Var>& u, int i) {
+    const double m = 1.0, I = 0.01, g = 9.81;
+    switch (i) {
+        case 0: return x[3];
+        case 1: return x[4];
+        case 2: return x[5];
+        case 3: return -(u[0] / m) * mx::sin(x[2]);
+        case 4: return (u[0] / m) * mx::cos(x[2]) - g;
+        default: return u[1] / I;
+    }
+}
+mx::Var traced_quad_cost(const std::vector<mx::Var>& u) { return 1.0 * u[0] * u[0] + 1.0 * u[1] * u[1]; }
+}  // namespace
+
 // ---- quadrotor VGP (the headline model) as an ETOL problem set up through the public API --------
 namespace {
+int g_traced = 0;               // 1: callbacks compute with mx::Var handles (traced model) instead of naming a built-in
 double g_quad_tau_max = 1.0;   // torque bound of the quadrotor test problem (harness_set_quad_tau_max)
 struct QuadSetup {
     std::vector<std::array<double, 3>> discs;
@@ -179,12 +197,25 @@ void configure_quadrotor(ETOL::TrajectoryOptimizer* t, QuadSetup& q, int nsteps,
     const std::array<double, 3> all[3] = {{4.0, 3.2, 0.8}, {6.3, 4.4, 0.7}, {2.5, 1.2, 0.4}};
     for (int i = 0; i < ndiscs; ++i) q.discs.push_back(all[i]);
     auto mp = q.params;
-    q.obj = [mp](F_ARGS) -> ETOL::scalar_t { return mx::objective(EMI_MODEL_QUADROTOR2D, mp); };
+    const bool traced = g_traced != 0;
+    // traced: the way an ePSOPT user writes callbacks (arithmetic on the solver's own scalar type,
+    // reference etol_psopt_example1.cpp:101-138), here on mx::Var
+    q.obj = [mp, traced](F_ARGS) -> ETOL::scalar_t {
+        if (!traced) return mx::objective(EMI_MODEL_QUADROTOR2D, mp);
+        std::vector<mx::Var> uu = {std::any_cast<mx::Var>(u.at(0)), std::any_cast<mx::Var>(u.at(1))};
+        return traced_quad_cost(uu);
+    };
     t->setObjective(&q.obj);
     q.grad.resize(6);
     std::vector<ETOL::f_t*> gp;
     for (int i = 0; i < 6; ++i) {
-        q.grad[i] = [mp, i](F_ARGS) -> ETOL::scalar_t { return mx::derivative(EMI_MODEL_QUADROTOR2D, i, mp); };
+        q.grad[i] = [mp, i, traced](F_ARGS) -> ETOL::scalar_t {
+            if (!traced) return mx::derivative(EMI_MODEL_QUADROTOR2D, i, mp);
+            std::vector<mx::Var> xx, uu;
+            for (const auto& a : x) xx.push_back(std::any_cast<mx::Var>(a));
+            for (const auto& a : u) uu.push_back(std::any_cast<mx::Var>(a));
+            return traced_quad_rhs(xx, uu, i);
+        };
         gp.push_back(&q.grad[i]);
     }
     t->setGradient(gp);
@@ -201,6 +232,7 @@ void configure_quadrotor(ETOL::TrajectoryOptimizer* t, QuadSetup& q, int nsteps,
 }  // namespace
 
 extern "C" void harness_set_quad_tau_max(double v) { g_quad_tau_max = v; }
+extern "C" void harness_set_traced(int on) { g_traced = on; }
 
 // Solve the quadrotor VGP on the GPU through ETOL::eMI355X.  Outputs X[6][M], U[2][M].
 extern "C" int harness_solve_quadrotor(int nsteps, double dt, int ndiscs, double tol, int print_level, int refine,
@@ -276,23 +308,6 @@ extern "C" int harness_solve_quadrotor_oracle(const char* oracle_so, int nsteps,
     for (int i = 0; i < 2 * m; ++i) U[i] = r.z[6 * m + i];
     return 0;
 }
-
-// ---- traced models: the quadrotor written with mi355x::Var arithmetic, as a user would -----------
-namespace {
-// x = (px, pz, theta, vx, vz, omega), u = (T, tau); same equations as EMI_MODEL_QUADROTOR2D
-mx::Var traced_quad_rhs(const std::vector<mx::Var>& x, const std::vector<mx::Var>& u, int i) {
-    const double m = 1.0, I = 0.01, g = 9.81;
-    switch (i) {
-        case 0: return x[3];
-        case 1: return x[4];
-        case 2: return x[5];
-        case 3: return -(u[0] / m) * mx::sin(x[2]);
-        case 4: return (u[0] / m) * mx::cos(x[2]) - g;
-        default: return u[1] / I;
-    }
-}
-mx::Var traced_quad_cost(const std::vector<mx::Var>& u) { return 1.0 * u[0] * u[0] + 1.0 * u[1] * u[1]; }
-}  // namespace
 
 // Source of the generated model struct for the traced quadrotor (or, with which=1, a model that
 // exercises every traced operation).  Host-only: used to check trace + derivatives + code generation.
@@ -373,9 +388,19 @@ int harness_solve_example1(const char* xml, int with_obstacles, double tol, int 
     ETOL::TrajectoryOptimizer* t = &e.solver;
     t->loadConfigs(xml);
     t->setMaximize(false);
-    e.obj = [](F_ARGS) -> ETOL::scalar_t { return mx::objective(EMI_MODEL_POINTMASS2D); };
-    e.xdot = [](F_ARGS) -> ETOL::scalar_t { return mx::derivative(EMI_MODEL_POINTMASS2D, 0); };
-    e.ydot = [](F_ARGS) -> ETOL::scalar_t { return mx::derivative(EMI_MODEL_POINTMASS2D, 1); };
+    if (g_traced) {
+        // the reference's own callbacks (etol_psopt_example1.cpp:101-138), on mx::Var instead of adouble
+        e.obj = [](F_ARGS) -> ETOL::scalar_t {
+            const mx::Var u0 = std::any_cast<mx::Var>(u.at(0)), u1 = std::any_cast<mx::Var>(u.at(1));
+            return u0 * u0 + u1 * u1;
+        };
+        e.xdot = [](F_ARGS) -> ETOL::scalar_t { return std::any_cast<mx::Var>(u.at(0)); };
+        e.ydot = [](F_ARGS) -> ETOL::scalar_t { return std::any_cast<mx::Var>(u.at(1)); };
+    } else {
+        e.obj = [](F_ARGS) -> ETOL::scalar_t { return mx::objective(EMI_MODEL_POINTMASS2D); };
+        e.xdot = [](F_ARGS) -> ETOL::scalar_t { return mx::derivative(EMI_MODEL_POINTMASS2D, 0); };
+        e.ydot = [](F_ARGS) -> ETOL::scalar_t { return mx::derivative(EMI_MODEL_POINTMASS2D, 1); };
+    }
     t->setObjective(&e.obj);
     t->setGradient({&e.xdot, &e.ydot});
     if (with_obstacles) {

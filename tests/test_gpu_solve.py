@@ -131,3 +131,33 @@ def test_mesh_refinement_adds_nodes_until_the_ode_tolerance_is_met(H, xmls):
     # shipped problem: dynamics xdot = u are integrated exactly by the collocation scheme
     cost, X, U, T, iters = solve(H, xmls["ocp_2d_ex1.xml"], 0)
     assert X.shape[1] == 33
+
+
+def test_traced_callbacks_solve_like_the_builtin_models(H, xmls):
+    """Callbacks written as arithmetic on the solver's scalar type (the ePSOPT way, reference
+    etol_psopt_example1.cpp:101-138; here mi355x::Var): setup() traces them, differentiates the trace
+    and compiles the model for the device.  Same problems, same answers as the hand-written kernels,
+    including across mesh refinement (one compilation, several meshes)."""
+    base1 = solve(H, xmls["ocp_2d_ex1.xml"], 1)
+    baseq = _solve_quadrotor(H, 40, 0.1, 2, refine=0)
+    H.harness_set_quad_tau_max.argtypes = [C.c_double]
+    H.harness_set_traced.argtypes = [C.c_int]
+    H.harness_set_traced(1)
+    try:
+        tr1 = solve(H, xmls["ocp_2d_ex1.xml"], 1)
+        trq = _solve_quadrotor(H, 40, 0.1, 2, refine=0)
+        H.harness_set_quad_tau_max(20.0)
+        trr = _solve_quadrotor(H, 12, 4.0 / 12, 1, refine=1, ode_tol=1e-4)
+    finally:
+        H.harness_set_traced(0)
+        H.harness_set_quad_tau_max(1.0)
+    assert tr1[1].shape == base1[1].shape and abs(tr1[0] - base1[0]) < 1e-9 * base1[0]
+    assert np.abs(tr1[1] - base1[1]).max() < 1e-7 and np.abs(tr1[2] - base1[2]).max() < 1e-7
+    assert trq[1].shape == baseq[1].shape and abs(trq[0] - baseq[0]) < 1e-8 * baseq[0]
+    assert np.abs(trq[1] - baseq[1]).max() < 1e-6 and np.abs(trq[2] - baseq[2]).max() < 1e-5
+    # refinement with the traced model: converged, and feasible for the oracle's hand-written equations
+    m = trr[1].shape[1]
+    assert m > 13 and trr[4] > 1 and trr[5] <= 1e-4
+    RES, _, COST = O.evaluate(1, [1.0, 0.01, 9.81, 1.0, 1.0], m, O.lgl(m), 0.0, 4.0, trr[1][None], trr[2][None],
+                              np.array([[1, 4.0, 3.2, 0.64, 0, 0, 0, 0]], dtype=float))
+    assert np.abs(RES[0, :6]).max() < 1e-7 and RES[0, 6:].max() < 1e-7 and abs(COST[0] - trr[0]) < 1e-8
