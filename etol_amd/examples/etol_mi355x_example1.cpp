@@ -6,8 +6,12 @@
 //    subject to  dx/dt = u0,  dy/dt = u1
 //                (x,y) outside every exclusion zone (one ellipse per polygon edge)
 //                (x,y) outside every moving exclusion disc
-// Callbacks use the eMI355X datatypes (include/ETOL/eMI355X_Types.hpp): they are
-// called once at setup() and describe the problem to the device evaluator.
+// Callbacks use the eMI355X datatypes (include/ETOL/eMI355X_Types.hpp) and are called once, at
+// setup().  Objective and dynamics are written as in the reference example -- arithmetic on the
+// solver's scalar type (there adouble, here mi355x::Var): eMI355X records the expressions,
+// differentiates them and compiles the model for the GPU.  (A callback may instead name one of the
+// library's hand-written kernels: return mx::objective(EMI_MODEL_POINTMASS2D) /
+// mx::derivative(EMI_MODEL_POINTMASS2D, i).)
 #include <ETOL/eMI355X.hpp>
 
 #include <iostream>
@@ -71,9 +75,13 @@ void editAlgo(ETOL::TrajectoryOptimizer* t) {
     algo->max_cpu_time = 100;
 }
 
-ETOL::scalar_t objFunction(F_ARGS) { return mx::objective(EMI_MODEL_POINTMASS2D); }
-ETOL::scalar_t dxdt(F_ARGS) { return mx::derivative(EMI_MODEL_POINTMASS2D, 0); }
-ETOL::scalar_t dydt(F_ARGS) { return mx::derivative(EMI_MODEL_POINTMASS2D, 1); }
+// reference etol_psopt_example1.cpp:101-138, with mx::Var in place of adouble
+ETOL::scalar_t objFunction(F_ARGS) {
+    const mx::Var u0 = std::any_cast<mx::Var>(u.at(0)), u1 = std::any_cast<mx::Var>(u.at(1));
+    return u0 * u0 + u1 * u1;
+}
+ETOL::scalar_t dxdt(F_ARGS) { return std::any_cast<mx::Var>(u.at(0)); }
+ETOL::scalar_t dydt(F_ARGS) { return std::any_cast<mx::Var>(u.at(1)); }
 
 ETOL::f_t obsConstraint(ETOL::TrajectoryOptimizer* t) {
     const double tspan = t->getDt() * t->getNSteps();
