@@ -45,6 +45,8 @@ $(LIBDIR)/emi_defect_f32.o: $(CSRC)/emi_defect_f32.hip $(CSRC_HDR) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(LIBDIR)/emi_api.o: $(CSRC)/emi_api.hip $(CSRC_HDR) | $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(LIBDIR)/emi_kkt.o: $(CSRC)/emi_kkt.hip $(CSRC_HDR) | $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(LIBDIR)/emi_rtc_sources.inc: $(RTC_HDR) tools/embed_src.py | $(LIBDIR)
 	python3 tools/embed_src.py $@ $(RTC_HDR)
 $(LIBDIR)/emi_rtc.o: $(CSRC)/emi_rtc.hip $(LIBDIR)/emi_rtc_sources.inc $(CSRC_HDR) | $(LIBDIR)
@@ -52,8 +54,8 @@ $(LIBDIR)/emi_rtc.o: $(CSRC)/emi_rtc.hip $(LIBDIR)/emi_rtc_sources.inc $(CSRC_HD
 $(LIBDIR)/emi_host.o: $(CSRC)/emi_host.cpp include/emi355x.h | $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
 
-$(LIBDIR)/libemi355x.so: $(LIBDIR)/emi_kernels.o $(LIBDIR)/emi_symdefect.o $(LIBDIR)/emi_defect_f32.o $(LIBDIR)/emi_api.o $(LIBDIR)/emi_rtc.o $(LIBDIR)/emi_host.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lhiprtc
+$(LIBDIR)/libemi355x.so: $(LIBDIR)/emi_kernels.o $(LIBDIR)/emi_symdefect.o $(LIBDIR)/emi_defect_f32.o $(LIBDIR)/emi_api.o $(LIBDIR)/emi_rtc.o $(LIBDIR)/emi_kkt.o $(LIBDIR)/emi_host.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lhiprtc -lrocsolver -lrocblas
 
 HOST_SRC := $(HOST)/TrajectoryOptimizer.cpp $(HOST)/eMI355X.cpp $(HOST)/emi_nlp.cpp $(HOST)/emi_trace.cpp
 HOST_HDR := $(wildcard include/ETOL/*.hpp) $(wildcard $(HOST)/*.hpp) include/emi355x.h

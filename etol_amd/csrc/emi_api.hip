@@ -56,6 +56,7 @@ struct emi_ctx_s {
     // model
     int model = -1, ns = 0, nc = 0, maximize = 0;
     double params[EMI_MAX_PARAMS] = {0};
+    emi::KktWorkspace* kkt = nullptr;   // Newton-step workspace (emi_kkt_factor)
     emi::RtcModel* rtc = nullptr;   // model == EMI_MODEL_SOURCE: code object compiled at emi_set_model_source
     // batch / path
     int B = 0;
@@ -256,6 +257,7 @@ int emi_destroy(emi_ctx_t c) {
     if (c->t_stop) (void)hipEventDestroy(c->t_stop);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     emi::rtc_destroy(c->rtc);
+    emi::kkt_destroy(c->kkt);
     delete c;
     return EMI_OK;
 }
@@ -710,6 +712,29 @@ int emi_hess_host(emi_ctx_t c, const double* X, const double* U, const double* L
     if ((st = ensure(c, c->s_H, nH * rb))) return st;
     if ((st = emi_hess_dev(c, c->s_X.p, c->s_U.p, c->s_LF.p, c->s_LC.p, sigma, c->s_H.p))) return st;
     return download_real(c, H, c->s_H.p, nH);
+}
+
+int emi_kkt_factor(emi_ctx_t c, const double* Qblk, const double* Jblk, const unsigned char* fixed, double dc,
+                   int* info) {
+    if (!c) return EMI_ERR_ARG;
+    if (c->M <= 0 || c->model < 0) return fail(c, EMI_ERR_STATE, "emi_kkt_factor: mesh and model must be set");
+    if (c->f32) return fail(c, EMI_ERR_UNSUPPORTED, "emi_kkt_factor: f64 contexts only");
+    if (!Qblk || !Jblk || !fixed || !info || !(dc >= 0.0)) return fail(c, EMI_ERR_ARG, "emi_kkt_factor: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::string err;
+    const int st = emi::kkt_factor(&c->kkt, c->stream, (const double*)c->d_D.p, c->M, c->ns, c->ns + c->nc, Qblk, Jblk,
+                                   fixed, dc, info, &err);
+    if (st) c->err = err;
+    return st;
+}
+
+int emi_kkt_solve(emi_ctx_t c, double* rhs) {
+    if (!c || !rhs) return EMI_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    std::string err;
+    const int st = emi::kkt_solve(c->kkt, c->stream, (c->ns + c->nc) * c->M, rhs, &err);
+    if (st) c->err = err;
+    return st;
 }
 
 int emi_timer_start(emi_ctx_t c) {

@@ -40,4 +40,11 @@ hipError_t rtc_launch_nodes(RtcModel* m, const NodeArgs<T>& a, bool jac, bool de
 template <typename T> hipError_t rtc_launch_hess(RtcModel* m, const HessArgs<T>& a, hipStream_t s);
 hipError_t rtc_launch_symdefect(RtcModel* m, const SymDefectArgs& a, hipStream_t s);
 
+// Newton step on the device (emi_kkt.hip)
+struct KktWorkspace;
+int kkt_factor(KktWorkspace** w, hipStream_t stream, const double* dD, int M, int ns, int nv, const double* Qblk,
+               const double* Jblk, const unsigned char* fixed, double dc, int* info, std::string* err);
+int kkt_solve(KktWorkspace* w, hipStream_t stream, int nz, double* rhs, std::string* err);
+void kkt_destroy(KktWorkspace* w);
+
 }  // namespace emi

@@ -178,6 +178,25 @@ class Evaluator:
                                          float(sigma), _dp(H)), "emi_hess_host")
         return H
 
+    # ---- Newton step (KKT solve) on the device ----------------------------------
+    def kkt_factor(self, Qblk, Jblk, fixed, dc=0.0):
+        """Assemble and LU-factorise the KKT matrix of one instance; returns rocSOLVER's info (0 = ok)."""
+        lay = self.layout
+        nv = lay.ns + lay.nc
+        Qblk = np.ascontiguousarray(Qblk, dtype=np.float64)
+        Jblk = np.ascontiguousarray(Jblk, dtype=np.float64)
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+        assert Qblk.shape == (lay.nhess, lay.M) and Jblk.shape == (lay.ns * nv, lay.M) and fixed.shape == (nv * lay.M,)
+        info = C.c_int(-1)
+        self._ck(self.lib.emi_kkt_factor(self.ctx, _dp(Qblk), _dp(Jblk), fixed.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                                         float(dc), C.byref(info)), "emi_kkt_factor")
+        return info.value
+
+    def kkt_solve(self, rhs):
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64).copy()
+        self._ck(self.lib.emi_kkt_solve(self.ctx, _dp(rhs)), "emi_kkt_solve")
+        return rhs
+
     # ---- measurement -----------------------------------------------------------
     def timer_start(self):
         self._ck(self.lib.emi_timer_start(self.ctx), "emi_timer_start")

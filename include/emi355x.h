@@ -38,6 +38,10 @@
  *   emi_hess_*         what ADOL-C's sparse_hess returns for hessian="exact"
  *                      (ePSOPT.cpp:65) [PSOPT]
  *   emi_jac_structure  the sparsity pattern IPOPT is given [PSOPT]
+ *   emi_kkt_factor/_solve  the linear solve of IPOPT's Newton step, reached
+ *                      through ::psopt at ePSOPT.cpp:84 with nlp_method "IPOPT"
+ *                      (:62) [IPOPT]: the primal-dual KKT matrix is assembled
+ *                      and factorised on the device
  *
  * Threading: a context must be driven by one caller thread at a time
  * (the reference is single-threaded throughout).
@@ -169,6 +173,22 @@ int emi_set_path(emi_ctx_t ctx, int np, int nsets, const double* recs,
 int emi_set_tracks(emi_ctx_t ctx, int ntracks, int nsets, const double* xc,
                    const double* yc);
 int emi_get_layout(emi_ctx_t ctx, emi_layout_t* out);
+
+/* ---- Newton step of the NLP iteration (batch of one, f64 contexts) --------
+ * KKT matrix of one instance, N = (ns+nc+ns)*M rows:
+ *     [ Q    J^T ]   Q: node-block-diagonal, Qblk [nhess][M] packed lower
+ *     [ J  -dc I ]      triangles (layout of emi_hess_*: Hessian blocks plus
+ *                       whatever diagonal / path-row terms the caller adds)
+ *                    J: D (x) [I 0] off the node diagonal, Jblk [ns*(ns+nc)][M]
+ *                       on it (the defect entries of VALS, which hold D_kk)
+ * Unknown order: variables v*M+k, then defect multipliers i*M+k.  fixed
+ * [(ns+nc)*M]: 1 = the variable does not move (identity row/column, rhs 0).
+ * Host pointers.  *info = 0 factorised, > 0 a pivot was exactly zero.
+ * The factorisation is an LU (no inertia): the caller checks curvature.     */
+int emi_kkt_factor(emi_ctx_t ctx, const double* Qblk, const double* Jblk,
+                   const unsigned char* fixed, double dc, int* info);
+/* rhs [N] in, solution out; may be called repeatedly after one factor.     */
+int emi_kkt_solve(emi_ctx_t ctx, double* rhs);
 
 /* COO pattern of VALS in per-instance NLP numbering:
  * rows/cols have nvals*M entries ordered like VALS; cost-gradient entries

@@ -1,0 +1,88 @@
+"""Newton-step linear algebra on the device (emi_kkt_factor / emi_kkt_solve) against numpy.  -m gpu
+
+The reference reaches this step inside IPOPT (src/ePSOPT/ePSOPT.cpp:62, 84)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def dense_kkt(D, Qblk, Jblk, fixed, dc, M, ns, nv):
+    nz, N = nv * M, (nv + ns) * M
+    K = np.zeros((N, N))
+    for v in range(nv):
+        for q in range(v + 1):
+            blk = Qblk[v * (v + 1) // 2 + q]
+            for k in range(M):
+                K[v * M + k, q * M + k] = blk[k]
+                K[q * M + k, v * M + k] = blk[k]
+    for i in range(ns):
+        rows = nz + i * M + np.arange(M)
+        K[np.ix_(rows, i * M + np.arange(M))] = D
+        for v in range(nv):
+            K[rows, v * M + np.arange(M)] = Jblk[i * nv + v]
+        K[rows, rows] = -dc
+    K[nz:, :nz][:, :] = K[nz:, :nz]
+    K[:nz, nz:] = K[nz:, :nz].T
+    for q in np.nonzero(fixed)[0]:
+        K[q, :] = 0
+        K[:, q] = 0
+        K[q, q] = 1
+    return K
+
+
+@pytest.mark.parametrize("M,model", [(9, 0), (33, 1), (64, 1)])
+def test_kkt_factor_solve_matches_numpy(built, M, model):
+    import etol_amd as E
+    from etol_amd import workloads as W
+    ns, nc, _ = E.model_dims(model)
+    nv, nh = ns + nc, (ns + nc) * (ns + nc + 1) // 2
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 4.0)
+    ev.set_model(model, W.QUAD_PARAMS if model == 1 else [])
+    ev.set_batch(1)
+    rng = np.random.default_rng(M)
+    # SPD node blocks (as after inertia correction), arbitrary Jacobian node entries
+    Qblk = np.zeros((nh, M))
+    for k in range(M):
+        A = rng.standard_normal((nv, nv))
+        Qk = A @ A.T + nv * np.eye(nv)
+        for v in range(nv):
+            for q in range(v + 1):
+                Qblk[v * (v + 1) // 2 + q, k] = Qk[v, q]
+    Jblk = rng.standard_normal((ns * nv, M))
+    for i in range(ns):
+        Jblk[i * nv + i] += np.diag(ev.D)
+    fixed = np.zeros(nv * M, dtype=np.uint8)
+    fixed[np.arange(ns) * M] = 1            # initial state, as eMI355X::addBounds fixes it
+    dc = 1e-9
+    assert ev.kkt_factor(Qblk, Jblk, fixed, dc) == 0
+    K = dense_kkt(ev.D, Qblk, Jblk, fixed, dc, M, ns, nv)
+    assert np.allclose(K, K.T)
+    for _ in range(2):                       # one factorisation, several right-hand sides
+        rhs = rng.standard_normal((nv + ns) * M)
+        sol = ev.kkt_solve(rhs)
+        ref_rhs = rhs.copy()
+        ref_rhs[np.nonzero(fixed)[0]] = 0
+        ref = np.linalg.solve(K, ref_rhs)
+        assert np.all(sol[np.nonzero(fixed)[0]] == 0)
+        # backward error of the device solution in the numpy matrix
+        res = K @ sol - ref_rhs
+        assert np.abs(res).max() < 1e-10 * (np.abs(K).max() * np.abs(sol).max() + 1)
+        assert np.abs(sol - ref).max() < 1e-7 * (np.abs(ref).max() + 1)
+
+
+def test_kkt_reports_singular_matrix_and_state_errors(built):
+    import etol_amd as E
+    from etol_amd import _lib
+    ev = E.Evaluator(0)
+    ev.set_mesh(5, 0.0, 1.0)
+    ev.set_model(0, [])
+    ev.set_batch(1)
+    with pytest.raises(_lib.EmiError):
+        ev.kkt_solve(np.zeros(6 * 5))                         # nothing factorised yet
+    # Q = 0, J = 0 and every variable free: structurally singular
+    info = ev.kkt_factor(np.zeros((10, 5)), np.zeros((8, 5)), np.zeros(20, dtype=np.uint8), 0.0)
+    assert info > 0
+    with pytest.raises(_lib.EmiError):
+        ev.kkt_solve(np.zeros(6 * 5))
