@@ -728,11 +728,11 @@ int emi_kkt_factor(emi_ctx_t c, const double* Qblk, const double* Jblk, const un
     return st;
 }
 
-int emi_kkt_solve(emi_ctx_t c, double* rhs) {
-    if (!c || !rhs) return EMI_ERR_ARG;
+int emi_kkt_solve(emi_ctx_t c, double* rhs, int nrhs) {
+    if (!c || !rhs || nrhs < 1) return EMI_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     std::string err;
-    const int st = emi::kkt_solve(c->kkt, c->stream, (c->ns + c->nc) * c->M, rhs, &err);
+    const int st = emi::kkt_solve(c->kkt, c->stream, (c->ns + c->nc) * c->M, rhs, nrhs, &err);
     if (st) c->err = err;
     return st;
 }

@@ -31,7 +31,8 @@ struct KktWorkspace {
     rocblas_int* info = nullptr;
     double* Q = nullptr;        // [nh][M]
     double* J = nullptr;        // [ns*nv][M]
-    double* rhs = nullptr;      // [N]
+    double* rhs = nullptr;      // [N][nrhs] column-major
+    size_t rhs_elems = 0;
     unsigned char* fixed = nullptr;   // [nv*M]
     size_t cap_small = 0;       // elements the small buffers were sized for (N)
     int N = 0;
@@ -72,9 +73,9 @@ __global__ __launch_bounds__(256) void emi_kkt_assemble_kernel(double* __restric
     K[(size_t)r * N + c] = val;    // K symmetric: row-major position == column-major position of the transpose
 }
 
-__global__ void emi_kkt_mask_rhs_kernel(double* __restrict__ rhs, const unsigned char* __restrict__ fixed, int nz) {
+__global__ void emi_kkt_mask_rhs_kernel(double* __restrict__ rhs, const unsigned char* __restrict__ fixed, int nz, int N) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nz && fixed[q]) rhs[q] = 0.0;
+    if (q < nz && fixed[q]) rhs[(size_t)blockIdx.y * N + q] = 0.0;
 }
 
 const char* rb(rocblas_status s) { return rocblas_status_to_string(s); }
@@ -117,7 +118,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         w->K_elems = (size_t)N * N;
     }
     if (w->cap_small < (size_t)N) {
-        void** small[] = {(void**)&w->ipiv, (void**)&w->info, (void**)&w->Q, (void**)&w->J, (void**)&w->rhs, (void**)&w->fixed};
+        void** small[] = {(void**)&w->ipiv, (void**)&w->info, (void**)&w->Q, (void**)&w->J, (void**)&w->fixed};
         for (void** b : small)
             if (*b) { KKT_HIP(hipFree(*b)); *b = nullptr; }
         w->cap_small = 0;
@@ -125,7 +126,6 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         KKT_HIP(hipMalloc(&w->info, sizeof(rocblas_int)));
         KKT_HIP(hipMalloc(&w->Q, (size_t)nh * M * sizeof(double)));
         KKT_HIP(hipMalloc(&w->J, (size_t)ns * nv * M * sizeof(double)));
-        KKT_HIP(hipMalloc(&w->rhs, (size_t)N * sizeof(double)));
         KKT_HIP(hipMalloc(&w->fixed, (size_t)nz));
         w->cap_small = (size_t)N;
     }
@@ -145,15 +145,23 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
     return EMI_OK;
 }
 
-int kkt_solve(KktWorkspace* w, hipStream_t stream, int nz, double* rhs, std::string* err) {
+int kkt_solve(KktWorkspace* w, hipStream_t stream, int nz, double* rhs, int nrhs, std::string* err) {
     if (!w || !w->factored) { *err = "emi_kkt_solve: no factorisation (emi_kkt_factor must succeed first)"; return EMI_ERR_STATE; }
     const int N = w->N;
-    KKT_HIP(hipMemcpyAsync(w->rhs, rhs, (size_t)N * sizeof(double), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(emi_kkt_mask_rhs_kernel, dim3((nz + 255) / 256), dim3(256), 0, stream, w->rhs, w->fixed, nz);
+    const size_t elems = (size_t)N * nrhs;
+    if (w->rhs_elems < elems) {
+        if (w->rhs) KKT_HIP(hipFree(w->rhs));
+        w->rhs = nullptr;
+        w->rhs_elems = 0;
+        KKT_HIP(hipMalloc(&w->rhs, elems * sizeof(double)));
+        w->rhs_elems = elems;
+    }
+    KKT_HIP(hipMemcpyAsync(w->rhs, rhs, elems * sizeof(double), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(emi_kkt_mask_rhs_kernel, dim3((nz + 255) / 256, nrhs), dim3(256), 0, stream, w->rhs, w->fixed, nz, N);
     KKT_HIP(hipGetLastError());
     KKT_RB(rocblas_set_stream(w->handle, stream));
-    KKT_RB(rocsolver_dgetrs(w->handle, rocblas_operation_none, N, 1, w->K, N, w->ipiv, w->rhs, N));
-    KKT_HIP(hipMemcpyAsync(rhs, w->rhs, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, stream));
+    KKT_RB(rocsolver_dgetrs(w->handle, rocblas_operation_none, N, nrhs, w->K, N, w->ipiv, w->rhs, N));
+    KKT_HIP(hipMemcpyAsync(rhs, w->rhs, elems * sizeof(double), hipMemcpyDeviceToHost, stream));
     KKT_HIP(hipStreamSynchronize(stream));
     return EMI_OK;
 #undef KKT_HIP

@@ -193,8 +193,10 @@ class Evaluator:
         return info.value
 
     def kkt_solve(self, rhs):
+        """rhs: [N] or [nrhs][N]; returns the solution(s) in the same shape."""
         rhs = np.ascontiguousarray(rhs, dtype=np.float64).copy()
-        self._ck(self.lib.emi_kkt_solve(self.ctx, _dp(rhs)), "emi_kkt_solve")
+        nrhs = 1 if rhs.ndim == 1 else rhs.shape[0]
+        self._ck(self.lib.emi_kkt_solve(self.ctx, _dp(rhs), nrhs), "emi_kkt_solve")
         return rhs
 
     # ---- measurement -----------------------------------------------------------

@@ -89,7 +89,7 @@ PathBlock track_rows(const std::list<track_t>& tracks, const Symbol& sx, const S
 // ---------------------------------------------------------------------------------------------
 // device adapter: the only place that touches the C ABI
 // ---------------------------------------------------------------------------------------------
-struct eMI355X::Device : public mi355x::NlpEvaluator {
+struct eMI355X::Device : public mi355x::NlpEvaluator, public mi355x::KktBackend {
     emi_ctx_t ctx = nullptr;
     bool source_installed = false;       // the traced model's code object is loaded in ctx
     ~Device() override {
@@ -102,6 +102,13 @@ struct eMI355X::Device : public mi355x::NlpEvaluator {
              double* H) override {
         return emi_hess_host(ctx, X, U, lamF, lamC, sigma, H);
     }
+    // Newton step on the device (emi_kkt.hip)
+    int factor(const double* Qblk, const double* Jblk, const unsigned char* fixed, double dc) override {
+        int info = -1;
+        const int st = emi_kkt_factor(ctx, Qblk, Jblk, fixed, dc, &info);
+        return st == EMI_OK ? info : -1;
+    }
+    int solve(double* rhs, int nrhs) override { return emi_kkt_solve(ctx, rhs, nrhs) == EMI_OK ? 0 : -1; }
     std::string last_error() const override { return ctx ? emi_last_error(ctx) : "no device context"; }
 };
 
@@ -488,6 +495,12 @@ void eMI355X::solve() {
     _solution.ode_error = 0;
     for (int mr = 0;; ++mr) {
         mi355x::NlpProblem nlp = mi355x::make_nlp(P, _dev.get());
+        // Newton-step linear algebra: small KKT systems on the host (exact inertia), the rest on the device
+        const size_t kkt_rows = (2 * ns + nc) * P.nodes;
+        const bool dev_kkt = _algorithm.linear_solver == "device" ||
+                             (_algorithm.linear_solver == "auto" && kkt_rows > 1200);
+        nlp.kkt = dev_kkt ? static_cast<mi355x::KktBackend*>(_dev.get()) : nullptr;
+        _solution.linear_solver = dev_kkt ? "device LU (rocSOLVER) + curvature test" : "host LDL^T";
         r = mi355x::solve_nlp(nlp, opt, mi355x::initial_guess(P));
         ++_solution.mesh_iterations;
         if (!r.ok || !refine) break;

@@ -171,6 +171,150 @@ struct Eval {
     double cost = 0;
 };
 
+// Makes every node block of Q (packed lower triangles, Qblk[nh][M]) positive definite over its free
+// variables: cyclic Jacobi eigen-decomposition of the (at most 16 x 16) block; if an eigenvalue is
+// below eps * max|lambda|, the block is rebuilt from max(|lambda|, floor).  Returns the largest
+// shift applied to an eigenvalue (0: nothing was modified).
+struct BlockMod {          // one modified eigenpair of one node block:  Q~_k = Q_k + delta v v^T
+    int node;
+    double delta;
+    double v[16];
+};
+double convexify_node_blocks(double* Qblk, const unsigned char* fixed, int nv, int M, std::vector<BlockMod>* mods) {
+    constexpr int NMAX = 16;
+    mods->clear();
+    if (nv > NMAX) return 0.0;
+    double worst = 0.0;
+    double A[NMAX][NMAX], Vv[NMAX][NMAX], lam[NMAX];
+    for (int k = 0; k < M; ++k) {
+        // cheap screen: a block whose Cholesky runs through with comfortable pivots is left alone
+        for (int v = 0; v < nv; ++v)
+            for (int q = 0; q <= v; ++q) {
+                const bool fx = fixed[v * M + k] || fixed[q * M + k];
+                A[v][q] = A[q][v] = fx ? (v == q ? 1.0 : 0.0) : Qblk[(size_t)(v * (v + 1) / 2 + q) * M + k];
+            }
+        double amax = 0;
+        for (int v = 0; v < nv; ++v) amax = std::max(amax, std::fabs(A[v][v]));
+        const double floor_ = 1e-8 * std::max(1.0, amax);
+        {
+            double Lc[NMAX][NMAX];
+            bool pd = true;
+            for (int i = 0; i < nv && pd; ++i)
+                for (int j = 0; j <= i; ++j) {
+                    double sum = A[i][j];
+                    for (int t = 0; t < j; ++t) sum -= Lc[i][t] * Lc[j][t];
+                    if (i == j) {
+                        if (!(sum > floor_)) { pd = false; break; }
+                        Lc[i][i] = std::sqrt(sum);
+                    } else {
+                        Lc[i][j] = sum / Lc[j][j];
+                    }
+                }
+            if (pd) continue;
+        }
+        for (int i = 0; i < nv; ++i)
+            for (int j = 0; j < nv; ++j) Vv[i][j] = i == j ? 1.0 : 0.0;
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            double off = 0;
+            for (int i = 0; i < nv; ++i)
+                for (int j = 0; j < i; ++j) off += A[i][j] * A[i][j];
+            if (off < 1e-30 * std::max(1.0, amax * amax)) break;
+            for (int p = 0; p < nv; ++p)
+                for (int q = p + 1; q < nv; ++q) {
+                    if (A[p][q] == 0.0) continue;
+                    const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                    const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                    for (int r = 0; r < nv; ++r) {
+                        const double arp = A[r][p], arq = A[r][q];
+                        A[r][p] = c * arp - sn * arq;
+                        A[r][q] = sn * arp + c * arq;
+                    }
+                    for (int r = 0; r < nv; ++r) {
+                        const double apr = A[p][r], aqr = A[q][r];
+                        A[p][r] = c * apr - sn * aqr;
+                        A[q][r] = sn * apr + c * aqr;
+                    }
+                    for (int r = 0; r < nv; ++r) {
+                        const double vrp = Vv[r][p], vrq = Vv[r][q];
+                        Vv[r][p] = c * vrp - sn * vrq;
+                        Vv[r][q] = sn * vrp + c * vrq;
+                    }
+                }
+        }
+        double lmax = 0;
+        for (int i = 0; i < nv; ++i) { lam[i] = A[i][i]; lmax = std::max(lmax, std::fabs(lam[i])); }
+        const double fl = 1e-8 * std::max(1.0, lmax);
+        for (int i = 0; i < nv; ++i) {
+            const double nl = std::max(std::fabs(lam[i]), fl);
+            if (nl != lam[i]) {
+                BlockMod m;
+                m.node = k;
+                m.delta = nl - lam[i];
+                for (int r = 0; r < nv; ++r) m.v[r] = Vv[r][i];
+                mods->push_back(m);
+            }
+            worst = std::max(worst, nl - lam[i]);
+            lam[i] = nl;
+        }
+        for (int v = 0; v < nv; ++v)
+            for (int q = 0; q <= v; ++q) {
+                if (fixed[v * M + k] || fixed[q * M + k]) continue;
+                double sum = 0;
+                for (int e = 0; e < nv; ++e) sum += Vv[v][e] * lam[e] * Vv[q][e];
+                Qblk[(size_t)(v * (v + 1) / 2 + q) * M + k] = sum;
+            }
+    }
+    return worst;
+}
+
+// Host backend: the same matrix as etol_amd/csrc/emi_kkt.hip assembles, dense LDL^T (Bunch-Kaufman).
+class DenseHostKkt : public KktBackend {
+ public:
+    explicit DenseHostKkt(const NlpProblem& P) : _P(P) {}
+    int factor(const double* Qblk, const double* Jblk, const unsigned char* fx, double dc) override {
+        const int M = _P.M, ns = _P.ns, nv = ns + _P.nc, nz = nv * M, N = nz + ns * M;
+        _F.n = N;
+        _F.a.assign((size_t)N * N, 0.0);
+        _fixed.assign(fx, fx + nz);
+        double* a = _F.a.data();
+        for (int k = 0; k < M; ++k)
+            for (int v = 0; v < nv; ++v) {
+                if (_fixed[v * M + k]) { a[(size_t)(v * M + k) * N + v * M + k] = 1.0; continue; }
+                for (int q = 0; q <= v; ++q)
+                    if (!_fixed[q * M + k]) a[(size_t)(v * M + k) * N + q * M + k] = Qblk[(size_t)(v * (v + 1) / 2 + q) * M + k];
+            }
+        for (int i = 0; i < ns; ++i)
+            for (int k = 0; k < M; ++k) {
+                double* row = a + (size_t)(nz + i * M + k) * N;
+                for (int j = 0; j < M; ++j)
+                    if (!_fixed[i * M + j]) row[i * M + j] = _P.D[(size_t)k * M + j];
+                for (int v = 0; v < nv; ++v)
+                    if (!_fixed[v * M + k]) row[v * M + k] = Jblk[(size_t)(i * nv + v) * M + k];
+                row[nz + i * M + k] = -dc;
+            }
+        _ok = ldlt_factor(_F) && _F.nzero == 0;
+        return _ok ? 0 : 1;
+    }
+    int solve(double* rhs, int nrhs) override {
+        if (!_ok) return -1;
+        for (int c = 0; c < nrhs; ++c) {
+            double* b = rhs + (size_t)c * _F.n;
+            for (size_t q = 0; q < _fixed.size(); ++q)
+                if (_fixed[q]) b[q] = 0.0;
+            ldlt_solve(_F, b);
+        }
+        return 0;
+    }
+    std::string last_error() const override { return "dense host factorisation"; }
+
+ private:
+    const NlpProblem& _P;
+    LdltFactor _F;
+    std::vector<unsigned char> _fixed;
+    bool _ok = false;
+};
+
 }  // namespace
 
 NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vector<double>& z0) {
@@ -273,7 +417,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     for (int r = 0; r < mc; ++r) { if (shasL(r)) it.vL[r] = 1.0; if (shasU(r)) it.vU[r] = 1.0; }
 
     double mu = opt.mu_init, nu = 1.0;
-    double dw_last = 0.0;
+    double dw_used = 0.0;   // largest eigenvalue shift of the last step taken with modified blocks (log only)
     const double tau_min = 0.99, kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, kappa_sigma = 1e10;
     std::vector<double> y_unscaled(mc);
 
@@ -364,15 +508,104 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         return phi + nu_t * viol;
     };
 
-    const int N = nf + md;
-    LdltFactor F;
-    std::vector<double> rhs(N), dz(nz), ds(mc), de1(mc), de2(mc), dlam(md), dy(mc), dzL(nz), dzU(nz), dvL(mc), dvU(mc),
+    // Newton-step linear algebra: the caller's backend (eMI355X: the device) or the dense host one
+    DenseHostKkt host_kkt(P);
+    KktBackend* kkt = P.kkt ? P.kkt : &host_kkt;
+    std::vector<double> Qblk((size_t)nh * M), rhs_full((size_t)nz + md);
+    std::vector<unsigned char> fixed_mask(nz);
+    for (int q = 0; q < nz; ++q) fixed_mask[q] = fidx[q] < 0 ? 1 : 0;
+    std::vector<BlockMod> mods;
+    bool exact_step = false;
+    const int max_lowrank = 2048;        // more modified eigenpairs than this: take the modified step untested
+    std::vector<double> dz(nz), ds(mc), de1(mc), de2(mc), dlam(md), dy(mc), dzL(nz), dzU(nz), dvL(mc), dvU(mc),
         dw1(mc), dw2(mc);
     std::vector<double> sig_t(mc), r_t(mc), sig_s(mc), rhat_s(mc);
     Eval Et;
     Et.RES.resize(E.RES.size());
     Et.VALS.resize(E.VALS.size());
     std::vector<double> zt(nz), st(mc), e1t(mc), e2t(mc);
+
+    // ---- pieces of one Newton step, shared by the regular step and the second-order correction ----
+    const size_t NN = (size_t)nz + md;
+    std::vector<double> Cm;             // Cholesky factor of the r x r Woodbury matrix C (see below)
+    int r_mod = 0;
+    // r_t of the eliminated path rows for given row residuals  c - s - e1 + e2
+    auto fill_rt = [&](const std::vector<double>& rowres) {
+        for (int r = 0; r < mc; ++r) {
+            const double a1 = it.e1[r] / it.w1[r], a2 = it.e2[r] / it.w2[r];
+            r_t[r] = rowres[r] + rhat_s[r] / sig_s[r] - a1 * (it.y[r] - rho + mu / it.e1[r]) -
+                     a2 * (it.y[r] + rho - mu / it.e2[r]);
+        }
+    };
+    // right-hand side of the reduced KKT system in full indexing (fixed variables: 0), for defect residuals defres
+    auto build_rhs = [&](double* out, const double* defres) {
+        const double* V = E.VALS.data();
+        std::fill(out, out + NN, 0.0);
+        for (int q = 0; q < nz; ++q) {
+            if (fidx[q] < 0) continue;
+            double r = gradf[q] + jtl[q];
+            if (hasL(q)) r -= mu / (it.z[q] - P.zl[q]);
+            if (hasU(q)) r += mu / (P.zu[q] - it.z[q]);
+            out[q] = -r;
+        }
+        for (int j = 0; j < np; ++j)
+            for (int k = 0; k < M; ++k) {
+                const double t = sig_t[j * M + k] * r_t[j * M + k];
+                if (fidx[P.px * M + k] >= 0) out[P.px * M + k] -= V[(size_t)(ns * nv + 2 * j) * M + k] * t;
+                if (fidx[P.py * M + k] >= 0) out[P.py * M + k] -= V[(size_t)(ns * nv + 2 * j + 1) * M + k] * t;
+            }
+        for (int r = 0; r < md; ++r) out[nz + r] = -defres[r];
+    };
+    // y <- y + Y C^-1 (U^T y): turns a solve with the modified matrix K~ into one with the exact K
+    std::vector<double> tvec, soc_def(md), soc_row(mc), soc_rhs(NN);
+    auto woodbury = [&](double* y0) {
+        tvec.assign(r_mod, 0.0);
+        for (int a = 0; a < r_mod; ++a) {
+            double dot = 0;
+            for (int v = 0; v < nv; ++v) dot += mods[a].v[v] * y0[v * M + mods[a].node];
+            tvec[a] = dot;
+        }
+        for (int i = 0; i < r_mod; ++i) {
+            double sum = tvec[i];
+            for (int t = 0; t < i; ++t) sum -= Cm[(size_t)i * r_mod + t] * tvec[t];
+            tvec[i] = sum / Cm[(size_t)i * r_mod + i];
+        }
+        for (int i = r_mod - 1; i >= 0; --i) {
+            double sum = tvec[i];
+            for (int t = i + 1; t < r_mod; ++t) sum -= Cm[(size_t)t * r_mod + i] * tvec[t];
+            tvec[i] = sum / Cm[(size_t)i * r_mod + i];
+        }
+        for (int c = 0; c < r_mod; ++c) {
+            const double* y = &rhs_full[NN * (1 + c)];
+            const double tc = tvec[c];
+            for (size_t r = 0; r < NN; ++r) y0[r] += tc * y[r];
+        }
+    };
+    // everything that was eliminated from the system, from dz (uses r_t)
+    auto expand_step = [&]() {
+        const double* V = E.VALS.data();
+        for (int j = 0; j < np; ++j)
+            for (int k = 0; k < M; ++k) {
+                const int r = j * M + k;
+                const double jcdz = V[(size_t)(ns * nv + 2 * j) * M + k] * dz[P.px * M + k] +
+                                    V[(size_t)(ns * nv + 2 * j + 1) * M + k] * dz[P.py * M + k];
+                dy[r] = sig_t[r] * (jcdz + r_t[r]);
+                ds[r] = (dy[r] - rhat_s[r]) / sig_s[r];
+                de1[r] = it.e1[r] / it.w1[r] * (dy[r] + it.y[r] - rho + mu / it.e1[r]);
+                de2[r] = it.e2[r] / it.w2[r] * (-dy[r] - it.y[r] - rho + mu / it.e2[r]);
+                dvL[r] = dvU[r] = 0;
+                if (shasL(r)) { const double g = it.s[r] - cL(r); dvL[r] = mu / g - it.vL[r] - it.vL[r] / g * ds[r]; }
+                if (shasU(r)) { const double g = cU(r) - it.s[r]; dvU[r] = mu / g - it.vU[r] + it.vU[r] / g * ds[r]; }
+                dw1[r] = mu / it.e1[r] - it.w1[r] - it.w1[r] / it.e1[r] * de1[r];
+                dw2[r] = mu / it.e2[r] - it.w2[r] - it.w2[r] / it.e2[r] * de2[r];
+            }
+        for (int q = 0; q < nz; ++q) {
+            dzL[q] = dzU[q] = 0;
+            if (fidx[q] < 0) continue;
+            if (hasL(q)) { const double g = it.z[q] - P.zl[q]; dzL[q] = mu / g - it.zL[q] - it.zL[q] / g * dz[q]; }
+            if (hasU(q)) { const double g = P.zu[q] - it.z[q]; dzU[q] = mu / g - it.zU[q] + it.zU[q] / g * dz[q]; }
+        }
+    };
 
     grad_and_jt(it);
     for (int iter = 0;; ++iter) {
@@ -383,7 +616,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         R.constr_viol = viol;
         if (opt.print_level >= 5)
             printf("iter %3d  cost %.10e  inf_pr %.2e  kkt %.2e  mu %.1e  dw %.1e  nu %.1e  emax %.1e  rho %.0e\n", iter,
-                   E.cost, viol, err0, mu, dw_last, nu, emax, rho);
+                   E.cost, viol, err0, mu, dw_used, nu, emax, rho);
         if (err0 <= opt.tol) {
             if (emax <= std::max(opt.tol, 1e-9) * 10.0 || mc == 0) { R.ok = true; R.msg = "converged"; break; }
             // a path row is still relaxed: the penalty was too small for it
@@ -424,124 +657,126 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         // factor with inertia correction
         bool factored = false;
         double dw = 0.0, dc = 0.0;
-        for (int attempt = 0; attempt < 40; ++attempt) {
-            F.n = N;
-            F.a.assign((size_t)N * N, 0.0);
-            auto K = [&](int i, int j) -> double& { return i >= j ? F.a[(size_t)i * N + j] : F.a[(size_t)j * N + i]; };
+        for (int attempt = 0; attempt < 12; ++attempt) {
+            // The device factorisation is an LU and reports no inertia, so the matrix handed to the
+            // backend has its inertia by construction: every node block
+            //     Q_k = H_k + Sigma_k + sum_j sig_t g_j g_j^T
+            // is made positive definite (negative eigenvalues reflected, Q~_k = Q_k + sum delta v v^T),
+            // which makes K~ quasi-definite: exactly nz positive and md negative eigenvalues.  With
+            // U = [v; 0] (r columns, one per modified eigenpair) the true matrix is K = K~ - U Delta U^T and
+            //     inertia(K) = (nz - r, md, 0) + inertia(C),   C = Delta^-1 - U^T K~^-1 U   (r x r)
+            // (both Schur complements of [[K~, U], [U^T, Delta^-1]]).  So r extra solves with the same
+            // factors decide EXACTLY whether the unmodified K has the right inertia; if it has, the
+            // Woodbury identity turns the solve with K~ into the exact Newton step (quadratic
+            // convergence is kept); if not, the step of K~ is the inertia-corrected one.
             const double* V = E.VALS.data();
-            for (int k = 0; k < M; ++k) {
-                for (int v = 0; v < nv; ++v) {
-                    const int fv = fidx[v * M + k];
-                    if (fv < 0) continue;
-                    for (int q = 0; q <= v; ++q) {
-                        const int fq = fidx[q * M + k];
-                        if (fq < 0) continue;
-                        K(fv, fq) += E.H[(size_t)(v * (v + 1) / 2 + q) * M + k];
-                    }
+            std::copy(E.H.begin(), E.H.end(), Qblk.begin());
+            for (int v = 0; v < nv; ++v)
+                for (int k = 0; k < M; ++k) {
                     const int qq = v * M + k;
-                    double sg = dw;
-                    if (hasL(qq)) sg += it.zL[qq] / (it.z[qq] - P.zl[qq]);
-                    if (hasU(qq)) sg += it.zU[qq] / (P.zu[qq] - it.z[qq]);
-                    K(fv, fv) += sg;
+                    double sg = 0.0;
+                    if (fidx[qq] >= 0) {
+                        if (hasL(qq)) sg += it.zL[qq] / (it.z[qq] - P.zl[qq]);
+                        if (hasU(qq)) sg += it.zU[qq] / (P.zu[qq] - it.z[qq]);
+                    }
+                    Qblk[(size_t)(v * (v + 1) / 2 + v) * M + k] += sg;
                 }
-                const int fx = fidx[P.px * M + k], fy = fidx[P.py * M + k];
-                for (int j = 0; j < np; ++j) {
-                    const double gx = V[(size_t)(ns * nv + 2 * j) * M + k], gy = V[(size_t)(ns * nv + 2 * j + 1) * M + k];
-                    const double sg = sig_t[j * M + k];
-                    if (fx >= 0) K(fx, fx) += sg * gx * gx;
-                    if (fy >= 0) K(fy, fy) += sg * gy * gy;
-                    if (fx >= 0 && fy >= 0) K(std::max(fx, fy), std::min(fx, fy)) += sg * gx * gy;
+            {
+                const int hi = std::max(P.px, P.py), lo = std::min(P.px, P.py);
+                double* qxx = &Qblk[(size_t)(P.px * (P.px + 1) / 2 + P.px) * M];
+                double* qyy = &Qblk[(size_t)(P.py * (P.py + 1) / 2 + P.py) * M];
+                double* qxy = &Qblk[(size_t)(hi * (hi + 1) / 2 + lo) * M];
+                for (int j = 0; j < np; ++j)
+                    for (int k = 0; k < M; ++k) {
+                        const double gx = V[(size_t)(ns * nv + 2 * j) * M + k], gy = V[(size_t)(ns * nv + 2 * j + 1) * M + k];
+                        const double sg = sig_t[j * M + k];
+                        qxx[k] += sg * gx * gx;
+                        qyy[k] += sg * gy * gy;
+                        qxy[k] += sg * gx * gy;
+                    }
+            }
+            dw = convexify_node_blocks(Qblk.data(), fixed_mask.data(), nv, M, &mods);
+            const int info = kkt->factor(Qblk.data(), V, fixed_mask.data(), dc);
+            if (info < 0) { R.msg = "KKT factorisation failed: " + kkt->last_error(); return R; }
+            if (info > 0) {   // exactly singular: the defect Jacobian lost rank; regularise the dual block
+                dc = dc == 0.0 ? 1e-8 * std::pow(mu, 0.25) : dc * 100.0;
+                continue;
+            }
+            // right-hand sides: column 0 the Newton system, then one column per modified eigenpair
+            r_mod = (int)mods.size() <= max_lowrank ? (int)mods.size() : 0;
+            rhs_full.assign(NN * (1 + r_mod), 0.0);
+            build_rhs(rhs_full.data(), E.RES.data());
+            for (int c = 0; c < r_mod; ++c)
+                for (int v = 0; v < nv; ++v) rhs_full[NN * (1 + c) + v * M + mods[c].node] = mods[c].v[v];
+            if (kkt->solve(rhs_full.data(), 1 + r_mod) != 0) { R.msg = "KKT solve failed: " + kkt->last_error(); return R; }
+            bool finite = true;
+            for (size_t r = 0; r < NN && finite; ++r) finite = std::isfinite(rhs_full[r]);
+            if (!finite) { dc = dc == 0.0 ? 1e-8 * std::pow(mu, 0.25) : dc * 100.0; continue; }
+            exact_step = mods.empty();
+            if (r_mod > 0) {
+                // C = Delta^-1 - U^T Y,  Y = K~^-1 U  (columns 1.. of rhs_full);  Cholesky <=> right inertia
+                Cm.assign((size_t)r_mod * r_mod, 0.0);
+                for (int a = 0; a < r_mod; ++a) {
+                    for (int c = 0; c <= a; ++c) {
+                        double dot = 0;
+                        const double* y = &rhs_full[NN * (1 + c)];
+                        for (int v = 0; v < nv; ++v) dot += mods[a].v[v] * y[v * M + mods[a].node];
+                        Cm[(size_t)a * r_mod + c] = -dot;
+                    }
+                    Cm[(size_t)a * r_mod + a] += 1.0 / mods[a].delta;
+                }
+                bool pd = true;
+                for (int i = 0; i < r_mod && pd; ++i)
+                    for (int j = 0; j <= i; ++j) {
+                        double sum = Cm[(size_t)i * r_mod + j];
+                        for (int t = 0; t < j; ++t) sum -= Cm[(size_t)i * r_mod + t] * Cm[(size_t)j * r_mod + t];
+                        if (i == j) {
+                            if (!(sum > 1e-14 * (1.0 / mods[i].delta))) { pd = false; break; }
+                            Cm[(size_t)i * r_mod + i] = std::sqrt(sum);
+                        } else {
+                            Cm[(size_t)i * r_mod + j] = sum / Cm[(size_t)j * r_mod + j];
+                        }
+                    }
+                if (pd) {
+                    exact_step = true;
+                    woodbury(rhs_full.data());      // x = y0 + Y C^-1 (U^T y0)
                 }
             }
-            for (int i = 0; i < ns; ++i)
-                for (int k = 0; k < M; ++k) {
-                    const int row = nf + i * M + k;
-                    for (int j = 0; j < M; ++j) {
-                        if (j == k) continue;
-                        const int f = fidx[i * M + j];
-                        if (f >= 0) F.a[(size_t)row * N + f] += P.D[(size_t)k * M + j];
-                    }
-                    for (int v = 0; v < nv; ++v) {
-                        const int f = fidx[v * M + k];
-                        if (f >= 0) F.a[(size_t)row * N + f] += V[(size_t)(i * nv + v) * M + k];
-                    }
-                    F.a[(size_t)row * N + row] = -dc;
-                }
-            const bool nonsing = ldlt_factor(F);
-            if (nonsing && F.npos == nf && F.nneg == md && F.nzero == 0) { factored = true; break; }
-            if (!nonsing || F.nzero > 0) dc = 1e-8 * std::pow(mu, 0.25);
-            if (dw == 0.0) dw = dw_last == 0.0 ? 1e-4 : std::max(1e-20, dw_last / 3.0);
-            else dw *= (dw_last == 0.0 ? 100.0 : 8.0);
-            if (dw > 1e40) break;
+            if (exact_step) dw = 0.0;     // the log shows the shift only when the modified step was taken
+            factored = true;
+            break;
         }
         if (!factored) { R.msg = "KKT matrix could not be regularised to the right inertia"; break; }
-        if (dw > 0) dw_last = dw;
+        dw_used = dw;
 
-        // right-hand side and solve
-        {
-            const double* V = E.VALS.data();
-            std::fill(rhs.begin(), rhs.end(), 0.0);
-            for (int q = 0; q < nz; ++q) {
-                const int f = fidx[q];
-                if (f < 0) continue;
-                double r = gradf[q] + jtl[q];
-                if (hasL(q)) r -= mu / (it.z[q] - P.zl[q]);
-                if (hasU(q)) r += mu / (P.zu[q] - it.z[q]);
-                rhs[f] = -r;
-            }
-            for (int j = 0; j < np; ++j)
-                for (int k = 0; k < M; ++k) {
-                    const int r = j * M + k;
-                    const double t = sig_t[r] * r_t[r];
-                    const int fx = fidx[P.px * M + k], fy = fidx[P.py * M + k];
-                    if (fx >= 0) rhs[fx] -= V[(size_t)(ns * nv + 2 * j) * M + k] * t;
-                    if (fy >= 0) rhs[fy] -= V[(size_t)(ns * nv + 2 * j + 1) * M + k] * t;
-                }
-            for (int r = 0; r < md; ++r) rhs[nf + r] = -E.RES[r];
-            ldlt_solve(F, rhs.data());
-            for (int q = 0; q < nz; ++q) dz[q] = fidx[q] >= 0 ? rhs[fidx[q]] : 0.0;
-            for (int r = 0; r < md; ++r) dlam[r] = rhs[nf + r];
-            for (int j = 0; j < np; ++j)
-                for (int k = 0; k < M; ++k) {
-                    const int r = j * M + k;
-                    const double jcdz = V[(size_t)(ns * nv + 2 * j) * M + k] * dz[P.px * M + k] +
-                                        V[(size_t)(ns * nv + 2 * j + 1) * M + k] * dz[P.py * M + k];
-                    dy[r] = sig_t[r] * (jcdz + r_t[r]);
-                    ds[r] = (dy[r] - rhat_s[r]) / sig_s[r];
-                    de1[r] = it.e1[r] / it.w1[r] * (dy[r] + it.y[r] - rho + mu / it.e1[r]);
-                    de2[r] = it.e2[r] / it.w2[r] * (-dy[r] - it.y[r] - rho + mu / it.e2[r]);
-                    dvL[r] = dvU[r] = 0;
-                    if (shasL(r)) { const double g = it.s[r] - cL(r); dvL[r] = mu / g - it.vL[r] - it.vL[r] / g * ds[r]; }
-                    if (shasU(r)) { const double g = cU(r) - it.s[r]; dvU[r] = mu / g - it.vU[r] + it.vU[r] / g * ds[r]; }
-                    dw1[r] = mu / it.e1[r] - it.w1[r] - it.w1[r] / it.e1[r] * de1[r];
-                    dw2[r] = mu / it.e2[r] - it.w2[r] - it.w2[r] / it.e2[r] * de2[r];
-                }
-            for (int q = 0; q < nz; ++q) {
-                dzL[q] = dzU[q] = 0;
-                if (fidx[q] < 0) continue;
-                if (hasL(q)) { const double g = it.z[q] - P.zl[q]; dzL[q] = mu / g - it.zL[q] - it.zL[q] / g * dz[q]; }
-                if (hasU(q)) { const double g = P.zu[q] - it.z[q]; dzU[q] = mu / g - it.zU[q] + it.zU[q] / g * dz[q]; }
-            }
-        }
+        // the step in the eliminated quantities
+        for (int q = 0; q < nz; ++q) dz[q] = fidx[q] >= 0 ? rhs_full[q] : 0.0;
+        for (int r = 0; r < md; ++r) dlam[r] = rhs_full[nz + r];
+        expand_step();
         // fraction to the boundary
         double apr = 1.0, adu = 1.0;
-        for (int q = 0; q < nz; ++q) {
-            if (fidx[q] < 0) continue;
-            if (hasL(q) && dz[q] < 0) apr = std::min(apr, -tau * (it.z[q] - P.zl[q]) / dz[q]);
-            if (hasU(q) && dz[q] > 0) apr = std::min(apr, tau * (P.zu[q] - it.z[q]) / dz[q]);
-            if (dzL[q] < 0) adu = std::min(adu, -tau * it.zL[q] / dzL[q]);
-            if (dzU[q] < 0) adu = std::min(adu, -tau * it.zU[q] / dzU[q]);
-        }
-        for (int r = 0; r < mc; ++r) {
-            if (shasL(r) && ds[r] < 0) apr = std::min(apr, -tau * (it.s[r] - cL(r)) / ds[r]);
-            if (shasU(r) && ds[r] > 0) apr = std::min(apr, tau * (cU(r) - it.s[r]) / ds[r]);
-            if (de1[r] < 0) apr = std::min(apr, -tau * it.e1[r] / de1[r]);
-            if (de2[r] < 0) apr = std::min(apr, -tau * it.e2[r] / de2[r]);
-            if (dvL[r] < 0) adu = std::min(adu, -tau * it.vL[r] / dvL[r]);
-            if (dvU[r] < 0) adu = std::min(adu, -tau * it.vU[r] / dvU[r]);
-            if (dw1[r] < 0) adu = std::min(adu, -tau * it.w1[r] / dw1[r]);
-            if (dw2[r] < 0) adu = std::min(adu, -tau * it.w2[r] / dw2[r]);
-        }
+        auto step_lengths = [&]() {
+            apr = 1.0;
+            adu = 1.0;
+            for (int q = 0; q < nz; ++q) {
+                if (fidx[q] < 0) continue;
+                if (hasL(q) && dz[q] < 0) apr = std::min(apr, -tau * (it.z[q] - P.zl[q]) / dz[q]);
+                if (hasU(q) && dz[q] > 0) apr = std::min(apr, tau * (P.zu[q] - it.z[q]) / dz[q]);
+                if (dzL[q] < 0) adu = std::min(adu, -tau * it.zL[q] / dzL[q]);
+                if (dzU[q] < 0) adu = std::min(adu, -tau * it.zU[q] / dzU[q]);
+            }
+            for (int r = 0; r < mc; ++r) {
+                if (shasL(r) && ds[r] < 0) apr = std::min(apr, -tau * (it.s[r] - cL(r)) / ds[r]);
+                if (shasU(r) && ds[r] > 0) apr = std::min(apr, tau * (cU(r) - it.s[r]) / ds[r]);
+                if (de1[r] < 0) apr = std::min(apr, -tau * it.e1[r] / de1[r]);
+                if (de2[r] < 0) apr = std::min(apr, -tau * it.e2[r] / de2[r]);
+                if (dvL[r] < 0) adu = std::min(adu, -tau * it.vL[r] / dvL[r]);
+                if (dvU[r] < 0) adu = std::min(adu, -tau * it.vU[r] / dvU[r]);
+                if (dw1[r] < 0) adu = std::min(adu, -tau * it.w1[r] / dw1[r]);
+                if (dw2[r] < 0) adu = std::min(adu, -tau * it.w2[r] / dw2[r]);
+            }
+        };
+        step_lengths();
         // l1 merit: directional derivative of the barrier function and the penalty weight
         double dphi = 0, infeas0 = 0;
         for (int q = 0; q < nz; ++q) {
@@ -568,17 +803,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         nu = std::max(nu, std::min(1.1 * mmax, 1e8));
         const double phi0 = phi0_base + nu * infeas0;
         const double slope = dphi - nu * infeas0;
-        // backtracking
-        double alpha = apr;
-        bool accepted = false;
-        for (int ls = 0; ls < 40; ++ls) {
-            for (int q = 0; q < nz; ++q) zt[q] = it.z[q] + alpha * dz[q];
-            for (int r = 0; r < mc; ++r) {
-                st[r] = it.s[r] + alpha * ds[r];
-                e1t[r] = it.e1[r] + alpha * de1[r];
-                e2t[r] = it.e2[r] + alpha * de2[r];
-            }
-            if (!evaluate(zt, Et, false)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
+        auto slack_reset = [&]() {
             // slack reset: a row's slack may jump to the value that closes its residual whenever
             // that lowers the merit function (the keep-out rows are strongly curved, and a step
             // along a keep-out boundary otherwise shows up as an equality residual c - s)
@@ -591,10 +816,80 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 if (shasU(r)) { keep -= mu * std::log(hi - st[r]); take -= mu * std::log(hi - target); }
                 if (take < keep) st[r] = target;
             }
+        };
+        // backtracking
+        double alpha = apr;
+        bool accepted = false;
+        for (int ls = 0; ls < 40; ++ls) {
+            for (int q = 0; q < nz; ++q) zt[q] = it.z[q] + alpha * dz[q];
+            for (int r = 0; r < mc; ++r) {
+                st[r] = it.s[r] + alpha * ds[r];
+                e1t[r] = it.e1[r] + alpha * de1[r];
+                e2t[r] = it.e2[r] + alpha * de2[r];
+            }
+            if (!evaluate(zt, Et, false)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
+            slack_reset();
             const double phit = barrier_merit(zt, st, e1t, e2t, Et, mu, nu, nullptr);
             if (std::isfinite(phit) && phit <= phi0 + 1e-4 * alpha * std::min(slope, 0.0) + 1e-13 * std::fabs(phi0)) {
                 accepted = true;
                 break;
+            }
+            // Second-order correction (as in IPOPT's line search): the first trial point was rejected
+            // and is less feasible than the current one -- the curvature of the constraints, not the
+            // direction, is to blame (Maratos effect; without this the l1 merit function lets the
+            // iteration crawl along the strongly curved defect / keep-out rows with steps of 2^-8).
+            // Re-solve with the SAME factorisation for the constraint values seen at the trial point.
+            if (ls == 0) {
+                double infeas_t = 0;
+                barrier_merit(zt, st, e1t, e2t, Et, mu, 0.0, &infeas_t);
+                if (std::isfinite(infeas_t) && infeas_t >= infeas0) {
+                    const std::vector<double> b_dz = dz, b_ds = ds, b_de1 = de1, b_de2 = de2, b_dlam = dlam, b_dy = dy,
+                                              b_dzL = dzL, b_dzU = dzU, b_dvL = dvL, b_dvU = dvU, b_dw1 = dw1, b_dw2 = dw2,
+                                              b_rt = r_t;
+                    const double b_apr = apr, b_adu = adu;
+                    for (int r = 0; r < md; ++r) soc_def[r] = alpha * E.RES[r] + Et.RES[r];
+                    for (int r = 0; r < mc; ++r)
+                        soc_row[r] = alpha * row_res(E, it.s, it.e1, it.e2, r) + row_res(Et, st, e1t, e2t, r);
+                    double infeas_old = infeas_t;
+                    for (int pc = 0; pc < 4 && !accepted; ++pc) {
+                        fill_rt(soc_row);
+                        build_rhs(soc_rhs.data(), soc_def.data());
+                        if (kkt->solve(soc_rhs.data(), 1) != 0) break;
+                        if (exact_step && r_mod > 0) woodbury(soc_rhs.data());
+                        bool fin = true;
+                        for (size_t r = 0; r < NN && fin; ++r) fin = std::isfinite(soc_rhs[r]);
+                        if (!fin) break;
+                        for (int q = 0; q < nz; ++q) dz[q] = fidx[q] >= 0 ? soc_rhs[q] : 0.0;
+                        for (int r = 0; r < md; ++r) dlam[r] = soc_rhs[nz + r];
+                        expand_step();
+                        step_lengths();
+                        const double asoc = apr;
+                        for (int q = 0; q < nz; ++q) zt[q] = it.z[q] + asoc * dz[q];
+                        for (int r = 0; r < mc; ++r) {
+                            st[r] = it.s[r] + asoc * ds[r];
+                            e1t[r] = it.e1[r] + asoc * de1[r];
+                            e2t[r] = it.e2[r] + asoc * de2[r];
+                        }
+                        if (!evaluate(zt, Et, false)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
+                        slack_reset();
+                        double infeas_s = 0;
+                        const double phis = barrier_merit(zt, st, e1t, e2t, Et, mu, nu, &infeas_s);
+                        if (std::isfinite(phis) && phis <= phi0 + 1e-4 * asoc * std::min(slope, 0.0) + 1e-13 * std::fabs(phi0)) {
+                            accepted = true;
+                            alpha = asoc;
+                            ++R.soc_steps;
+                            break;
+                        }
+                        if (!std::isfinite(infeas_s) || infeas_s > 0.99 * infeas_old) break;
+                        infeas_old = infeas_s;
+                        for (int r = 0; r < md; ++r) soc_def[r] = asoc * soc_def[r] + Et.RES[r];
+                        for (int r = 0; r < mc; ++r) soc_row[r] = asoc * soc_row[r] + row_res(Et, st, e1t, e2t, r);
+                    }
+                    if (accepted) break;
+                    dz = b_dz; ds = b_ds; de1 = b_de1; de2 = b_de2; dlam = b_dlam; dy = b_dy; dzL = b_dzL; dzU = b_dzU;
+                    dvL = b_dvL; dvU = b_dvU; dw1 = b_dw1; dw2 = b_dw2; r_t = b_rt;
+                    apr = b_apr; adu = b_adu;
+                }
             }
             alpha *= 0.5;
         }

@@ -7,10 +7,13 @@
 // KKT system with inertia-correcting regularisation, l1-merit backtracking line
 // search, Fiacco-McCormick barrier schedule).  Every function/Jacobian/Hessian
 // value comes from the device through an NlpEvaluator; the linear algebra of
-// the step (a dense symmetric-indefinite factorisation of the reduced KKT
-// matrix) runs on the host and is sized for the shipped resource/configs
-// problems.  SURVEY.md section 8f ranks a structured device-side KKT solve as
-// the next component.
+// the step is either a dense symmetric-indefinite LDL^T on the host (small
+// problems such as the shipped resource/configs ones: exact inertia) or a
+// KktBackend -- the device assembly + LU of etol_amd/csrc/emi_kkt.hip (SURVEY.md
+// section 8f rank 1).  An LU reports no inertia, so that branch factorises a
+// quasi-definite matrix (node blocks of Q made positive definite: inertia known
+// by construction) and recovers the exact Newton step, together with an exact
+// inertia test of the unmodified matrix, from a low-rank Woodbury correction.
 #ifndef ETOL_MI355X_EMI_NLP_HPP_
 #define ETOL_MI355X_EMI_NLP_HPP_
 
@@ -32,6 +35,19 @@ class NlpEvaluator {
     virtual std::string last_error() const { return std::string(); }
 };
 
+// Linear algebra of the Newton step somewhere else than the host (eMI355X: emi_kkt_factor /
+// emi_kkt_solve on the device).  KKT matrix [[Q, J^T], [J, -dc I]] in the layout of
+// include/emi355x.h: Qblk [nh][M] packed node blocks, Jblk [ns*nv][M] defect Jacobian node
+// entries, unknowns ordered variables v*M+k then defect multipliers i*M+k.
+class KktBackend {
+ public:
+    virtual ~KktBackend() {}
+    // 0: factorised; > 0: singular; < 0: failure (see last_error)
+    virtual int factor(const double* Qblk, const double* Jblk, const unsigned char* fixed, double dc) = 0;
+    virtual int solve(double* rhs, int nrhs) = 0;   // rhs [nrhs][nz+md], in place; 0 on success
+    virtual std::string last_error() const { return std::string(); }
+};
+
 struct NlpProblem {
     int ns = 0, nc = 0, np = 0, M = 0;
     int px = 0, py = 1;                 // states the path rows depend on
@@ -40,6 +56,7 @@ struct NlpProblem {
     std::vector<double> cl, cu;         // np path-row bounds (same at every node)
     std::vector<double> cscale;         // np positive row scalings applied inside the iteration (empty = 1)
     NlpEvaluator* ev = nullptr;
+    KktBackend* kkt = nullptr;          // null: dense LDL^T on the host (with inertia); else e.g. the device LU
 };
 
 struct NlpOptions {
@@ -56,6 +73,7 @@ struct NlpResult {
     std::string msg;
     int iterations = 0;
     int evaluations = 0;
+    int soc_steps = 0;                  // iterations accepted through a second-order correction
     double cost = 0, kkt_error = 0, constr_viol = 0;
     std::vector<double> z;              // (ns+nc)*M solution
     std::vector<double> lamF, lamC;     // multipliers of the defect and path rows

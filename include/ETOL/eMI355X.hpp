@@ -31,7 +31,9 @@ struct Alg {
     std::string mesh_refinement = "automatic";     // "automatic" or "none" (ePSOPT.cpp:69)
     int mr_max_iterations = 10;                    // ePSOPT.cpp:70
     double ode_tolerance = 1.e-4;                  // ePSOPT.cpp:71
-    int mr_max_nodes = 129;                        // the host KKT factorisation is dense: keep it small
+    int mr_max_nodes = 513;                        // refinement stops adding nodes here
+    std::string linear_solver = "auto";            // Newton step: "host" (dense LDL^T), "device" (KKT assembled and
+                                                   // LU-factorised in HBM), "auto" = device above 1200 KKT rows
     int nlp_iter_max = 200;
     double nlp_tolerance = 1.e-6;
     double max_cpu_time = 1.e9;
@@ -46,6 +48,7 @@ struct Sol {
     int nlp_iterations = 0;
     int evaluations = 0;
     double kkt_error = 0, constraint_violation = 0;
+    std::string linear_solver;      // what the last solve used for the Newton step
     int mesh_iterations = 0;        // NLP solves performed (1 = no refinement happened)
     double ode_error = 0;           // relative ODE error estimate on the doubled grid
     size_t nstates = 0, ncontrols = 0, nodes = 0;

@@ -184,11 +184,14 @@ int emi_get_layout(emi_ctx_t ctx, emi_layout_t* out);
  * Unknown order: variables v*M+k, then defect multipliers i*M+k.  fixed
  * [(ns+nc)*M]: 1 = the variable does not move (identity row/column, rhs 0).
  * Host pointers.  *info = 0 factorised, > 0 a pivot was exactly zero.
- * The factorisation is an LU (no inertia): the caller checks curvature.     */
+ * The factorisation is an LU and reports no inertia: the caller passes a
+ * quasi-definite matrix (every Q block positive definite), whose inertia is
+ * known, and recovers the exact matrix by a low-rank update (emi_nlp.cpp).  */
 int emi_kkt_factor(emi_ctx_t ctx, const double* Qblk, const double* Jblk,
                    const unsigned char* fixed, double dc, int* info);
-/* rhs [N] in, solution out; may be called repeatedly after one factor.     */
-int emi_kkt_solve(emi_ctx_t ctx, double* rhs);
+/* rhs [nrhs][N] (one right-hand side after the other) in, solutions out;
+ * may be called repeatedly after one factor.                               */
+int emi_kkt_solve(emi_ctx_t ctx, double* rhs, int nrhs);
 
 /* COO pattern of VALS in per-instance NLP numbering:
  * rows/cols have nvals*M entries ordered like VALS; cost-gradient entries

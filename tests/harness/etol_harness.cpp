@@ -16,7 +16,8 @@ namespace mx = ETOL::mi355x;
 
 namespace {
 
-std::string g_out;
+std::string g_out, g_out2;
+std::string g_linear_solver = "auto";   // mx::Alg::linear_solver for the harness solves
 
 // a TrajectoryOptimizer that can be instantiated without a GPU (for the loader tests)
 class Plain : public ETOL::TrajectoryOptimizer {
@@ -101,7 +102,57 @@ struct OracleEval : public mx::NlpEvaluator {
                   P->track_y.data(), X, U, lamF, lamC, sigma, H);
     }
 };
+
+// CPU stand-in for the device Newton step (emi_kkt.hip): same matrix, same unknown order, dense
+// factorisation on the host.  Lets the CPU tests drive the KktBackend branch of solve_nlp.
+struct HostKkt : public mx::KktBackend {
+    const mx::Prob* P = nullptr;
+    mx::LdltFactor F;
+    std::vector<unsigned char> fixed;
+    bool ok = false;
+    int factor(const double* Qblk, const double* Jblk, const unsigned char* fx, double dc) override {
+        const int M = (int)P->nodes, ns = (int)P->nstates, nv = ns + (int)P->ncontrols, nz = nv * M, N = nz + ns * M;
+        F.n = N;
+        F.a.assign((size_t)N * N, 0.0);
+        fixed.assign(fx, fx + nz);
+        auto put = [&](int r, int c, double v) { (r >= c ? F.a[(size_t)r * N + c] : F.a[(size_t)c * N + r]) = v; };
+        for (int k = 0; k < M; ++k)
+            for (int v = 0; v < nv; ++v)
+                for (int q = 0; q <= v; ++q) put(v * M + k, q * M + k, Qblk[(size_t)(v * (v + 1) / 2 + q) * M + k]);
+        for (int i = 0; i < ns; ++i)
+            for (int k = 0; k < M; ++k) {
+                const int R = nz + i * M + k;
+                for (int j = 0; j < M; ++j) put(R, i * M + j, P->D[(size_t)k * M + j]);
+                for (int v = 0; v < nv; ++v) put(R, v * M + k, Jblk[(size_t)(i * nv + v) * M + k]);
+                put(R, R, -dc);
+            }
+        for (int q = 0; q < nz; ++q) {
+            if (!fixed[q]) continue;
+            for (int r = 0; r < N; ++r) put(r, q, 0.0);
+            put(q, q, 1.0);
+        }
+        ok = mx::ldlt_factor(F) && F.nzero == 0;
+        inertia_ok = ok && F.npos == nz && F.nneg == ns * M;
+        if (ok && !inertia_ok) ++wrong_inertia;   // must never happen: Q is convexified by the caller
+        return ok ? 0 : 1;
+    }
+    int solve(double* rhs, int nrhs) override {
+        if (!ok) return -1;
+        for (int c = 0; c < nrhs; ++c) {
+            double* b = rhs + (size_t)c * F.n;
+            for (size_t q = 0; q < fixed.size(); ++q)
+                if (fixed[q]) b[q] = 0.0;
+            mx::ldlt_solve(F, b);
+        }
+        return 0;
+    }
+    bool inertia_ok = false;
+    int wrong_inertia = 0;
+};
+HostKkt g_host_kkt;
 }  // namespace
+
+extern "C" int harness_kkt_standin_wrong_inertia(void) { return g_host_kkt.wrong_inertia; }
 
 extern "C" int harness_solve_example1_oracle(const char* xml, const char* oracle_so, int with_obstacles, double tol,
                                              int print_level, int max_iter, double* cost, int* M, double* X, double* U,
@@ -147,6 +198,11 @@ extern "C" int harness_solve_example1_oracle(const char* xml, const char* oracle
     P.path_lower.assign(P.npath, -1000.0); P.path_upper.assign(P.npath, 0.0);
     oe.P = &P;
     mx::NlpProblem nlp = mx::make_nlp(P, &oe);
+    if (g_linear_solver == "device") {   // CPU tests: the KktBackend branch with the host stand-in
+        g_host_kkt.P = &P;
+        g_host_kkt.wrong_inertia = 0;
+        nlp.kkt = &g_host_kkt;
+    }
     mx::NlpOptions opt;
     opt.tol = tol; opt.print_level = print_level; opt.max_iter = max_iter;
     mx::NlpResult r = mx::solve_nlp(nlp, opt, mx::initial_guess(P));
@@ -233,6 +289,8 @@ void configure_quadrotor(ETOL::TrajectoryOptimizer* t, QuadSetup& q, int nsteps,
 
 extern "C" void harness_set_quad_tau_max(double v) { g_quad_tau_max = v; }
 extern "C" void harness_set_traced(int on) { g_traced = on; }
+extern "C" void harness_set_linear_solver(const char* name) { g_linear_solver = name; }
+extern "C" const char* harness_last_linear_solver(void) { return g_out2.c_str(); }
 
 // Solve the quadrotor VGP on the GPU through ETOL::eMI355X.  Outputs X[6][M], U[2][M].
 extern "C" int harness_solve_quadrotor(int nsteps, double dt, int ndiscs, double tol, int print_level, int refine,
@@ -247,7 +305,9 @@ extern "C" int harness_solve_quadrotor(int nsteps, double dt, int ndiscs, double
     solver.getAlgorithm()->nlp_iter_max = 400;
     solver.getAlgorithm()->mesh_refinement = refine ? "automatic" : "none";
     solver.getAlgorithm()->ode_tolerance = ode_tol;
+    solver.getAlgorithm()->linear_solver = g_linear_solver;
     solver.solve();
+    g_out2 = solver.getSolution()->linear_solver;
     const mx::Sol* s = solver.getSolution();
     *iters = s->nlp_iterations;
     *mesh_iters = s->mesh_iterations;
@@ -294,6 +354,11 @@ extern "C" int harness_solve_quadrotor_oracle(const char* oracle_so, int nsteps,
     P.path_lower.assign(P.npath, -1000.0); P.path_upper.assign(P.npath, 0.0);
     oe.P = &P;
     mx::NlpProblem nlp = mx::make_nlp(P, &oe);
+    if (g_linear_solver == "device") {   // CPU tests: the KktBackend branch with the host stand-in
+        g_host_kkt.P = &P;
+        g_host_kkt.wrong_inertia = 0;
+        nlp.kkt = &g_host_kkt;
+    }
     mx::NlpOptions opt;
     opt.tol = tol; opt.print_level = print_level; opt.max_iter = 400;
     mx::NlpResult r = mx::solve_nlp(nlp, opt, mx::initial_guess(P));
@@ -428,7 +493,9 @@ int harness_solve_example1(const char* xml, int with_obstacles, double tol, int 
     t->setup();
     e.solver.getAlgorithm()->nlp_tolerance = tol;
     e.solver.getAlgorithm()->print_level = print_level;
+    e.solver.getAlgorithm()->linear_solver = g_linear_solver;
     t->solve();
+    g_out2 = e.solver.getSolution()->linear_solver;
     const mx::Sol* s = e.solver.getSolution();
     *iters = s->nlp_iterations;
     if (s->error_flag) { g_out = s->error_msg; return 1; }

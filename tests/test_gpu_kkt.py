@@ -59,7 +59,13 @@ def test_kkt_factor_solve_matches_numpy(built, M, model):
     assert ev.kkt_factor(Qblk, Jblk, fixed, dc) == 0
     K = dense_kkt(ev.D, Qblk, Jblk, fixed, dc, M, ns, nv)
     assert np.allclose(K, K.T)
-    for _ in range(2):                       # one factorisation, several right-hand sides
+    many = rng.standard_normal((5, (nv + ns) * M))          # several right-hand sides in one call
+    sols = ev.kkt_solve(many)
+    for b, x in zip(many, sols):
+        b = b.copy()
+        b[np.nonzero(fixed)[0]] = 0
+        assert np.abs(K @ x - b).max() < 1e-10 * (np.abs(K).max() * np.abs(x).max() + 1)
+    for _ in range(2):                       # one factorisation, several calls
         rhs = rng.standard_normal((nv + ns) * M)
         sol = ev.kkt_solve(rhs)
         ref_rhs = rhs.copy()

@@ -161,3 +161,57 @@ def test_traced_callbacks_solve_like_the_builtin_models(H, xmls):
     RES, _, COST = O.evaluate(1, [1.0, 0.01, 9.81, 1.0, 1.0], m, O.lgl(m), 0.0, 4.0, trr[1][None], trr[2][None],
                               np.array([[1, 4.0, 3.2, 0.64, 0, 0, 0, 0]], dtype=float))
     assert np.abs(RES[0, :6]).max() < 1e-7 and RES[0, 6:].max() < 1e-7 and abs(COST[0] - trr[0]) < 1e-8
+
+
+def _set_linear_solver(H, name):
+    H.harness_set_linear_solver.argtypes = [C.c_char_p]
+    H.harness_last_linear_solver.restype = C.c_char_p
+    H.harness_set_linear_solver(name.encode())
+
+
+def test_device_newton_step_gives_the_host_solution(H, xmls):
+    """Same NLP iteration, Newton step once through the host LDL^T (inertia) and once through the
+    device KKT assembly + LU with the curvature test: same solutions."""
+    try:
+        _set_linear_solver(H, "host")
+        h1 = solve(H, xmls["ocp_2d_ex1.xml"], 1)
+        hq = _solve_quadrotor(H, 40, 0.1, 2, refine=0)
+        assert H.harness_last_linear_solver().decode().startswith("host")
+        _set_linear_solver(H, "device")
+        d1 = solve(H, xmls["ocp_2d_ex1.xml"], 1)
+        dq = _solve_quadrotor(H, 40, 0.1, 2, refine=0)
+        assert H.harness_last_linear_solver().decode().startswith("device")
+    finally:
+        _set_linear_solver(H, "auto")
+    assert abs(d1[0] - h1[0]) < 1e-8 * h1[0] and np.abs(d1[1] - h1[1]).max() < 1e-6
+    assert abs(dq[0] - hq[0]) < 1e-8 * hq[0] and np.abs(dq[1] - hq[1]).max() < 1e-5 and np.abs(dq[2] - hq[2]).max() < 1e-4
+
+
+def test_quadrotor_256_nodes_end_to_end_on_the_device(H):
+    """Config-2 mesh (256 LGL nodes, 6 states): evaluation, derivatives AND the Newton step on the GPU
+    ("auto" picks the device above 1200 KKT rows: here 3584).  Feasibility by the CPU oracle."""
+    import time
+    t0 = time.time()
+    cost, X, U, iters, mesh_iters, _ = _solve_quadrotor_cap(H, 255, 4.0 / 255, 2, cap=300)
+    dt = time.time() - t0
+    assert H.harness_last_linear_solver().decode().startswith("device")
+    m = X.shape[1]
+    assert m == 256 and iters < 400
+    recs = np.array([[1, 4.0, 3.2, 0.64, 0, 0, 0, 0], [1, 6.3, 4.4, 0.49, 0, 0, 0, 0]], dtype=float)
+    RES, _, COST = O.evaluate(1, [1.0, 0.01, 9.81, 1.0, 1.0], m, O.lgl(m), 0.0, 4.0, X[None], U[None], recs)
+    assert np.abs(RES[0, :6]).max() < 1e-7 and RES[0, 6:].max() < 1e-7 and abs(COST[0] - cost) < 1e-8
+    assert 380 < cost < 450
+    print(f"quadrotor M=256: {iters} iterations, {dt:.2f} s wall")
+
+
+def _solve_quadrotor_cap(H, nsteps, dt, ndiscs, cap):
+    D = C.POINTER(C.c_double)
+    H.harness_solve_quadrotor.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, D,
+                                          C.POINTER(C.c_int), D, D, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), D]
+    X, U = np.zeros(6 * cap), np.zeros(2 * cap)
+    cost, M, it, mit, oerr = C.c_double(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
+    rc = H.harness_solve_quadrotor(nsteps, dt, ndiscs, 1e-8, 0, 0, 1e-4, C.byref(cost), C.byref(M),
+                                   X.ctypes.data_as(D), U.ctypes.data_as(D), cap, C.byref(it), C.byref(mit), C.byref(oerr))
+    assert rc == 0, H.harness_last_message().decode()
+    m = M.value
+    return cost.value, X[:6 * m].reshape(6, m), U[:2 * m].reshape(2, m), it.value, mit.value, oerr.value
