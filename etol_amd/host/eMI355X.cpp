@@ -487,33 +487,20 @@ void eMI355X::solve() {
     opt.print_level = _algorithm.print_level;
     opt.max_cpu_time = _algorithm.max_cpu_time;
 
-    // PSOPT's mesh refinement ("automatic", ePSOPT.cpp:69-71): solve, estimate the ODE error,
-    // add nodes and re-solve from the interpolated solution until the tolerance is met.
     mi355x::NlpResult r;
-    const bool refine = _algorithm.mesh_refinement == "automatic";
-    _solution.mesh_iterations = 0;
-    _solution.ode_error = 0;
-    for (int mr = 0;; ++mr) {
+    auto solve_current_mesh = [&](const mi355x::NlpOptions& o) {
         mi355x::NlpProblem nlp = mi355x::make_nlp(P, _dev.get());
-        // Newton-step linear algebra: small KKT systems on the host (exact inertia), the rest on the device
+        // Newton-step linear algebra: small KKT systems on the host, the rest on the device
         const size_t kkt_rows = (2 * ns + nc) * P.nodes;
         const bool dev_kkt = _algorithm.linear_solver == "device" ||
                              (_algorithm.linear_solver == "auto" && kkt_rows > 1200);
         nlp.kkt = dev_kkt ? static_cast<mi355x::KktBackend*>(_dev.get()) : nullptr;
-        _solution.linear_solver = dev_kkt ? "device LU (rocSOLVER) + curvature test" : "host LDL^T";
-        r = mi355x::solve_nlp(nlp, opt, mi355x::initial_guess(P));
-        ++_solution.mesh_iterations;
-        if (!r.ok || !refine) break;
-        std::vector<double> zf;
-        size_t M2 = 0;
-        _solution.ode_error = odeError(r.z, &zf, &M2);
-        if (_algorithm.print_level >= 5)
-            printf("mesh iteration %d: %zu nodes, cost %.10e, relative ODE error %.3e\n", mr, P.nodes, r.cost,
-                   _solution.ode_error);
-        if (_solution.ode_error <= _algorithm.ode_tolerance || mr + 1 >= _algorithm.mr_max_iterations) break;
-        const size_t Mnew = std::min((size_t)_algorithm.mr_max_nodes, P.nodes + std::max<size_t>(4, (P.nodes - 1) / 2));
-        if (Mnew <= P.nodes) break;
-        // warm start: the solution interpolated to the new nodes
+        _solution.linear_solver = dev_kkt ? "device: KKT assembly + LU (rocSOLVER), Woodbury-corrected" : "host LDL^T";
+        r = mi355x::solve_nlp(nlp, o, mi355x::initial_guess(P));
+        _solution.nlp_iterations_total += r.iterations;
+    };
+    // the solution on the current mesh, interpolated to Mnew LGL nodes, becomes the guess there
+    auto remesh_with_guess = [&](size_t Mnew) {
         const std::vector<double> tau = P.tau, w = P.w;
         const size_t M = P.nodes;
         setMesh(Mnew);
@@ -527,6 +514,68 @@ void eMI355X::solve() {
                 P.guess_controls[j * Mnew + k] =
                     std::min(std::max(P.guess_controls[j * Mnew + k], P.control_lower[j]), P.control_upper[j]);
         }
+    };
+    mi355x::NlpOptions warm = opt;      // started from an interpolated solution: stay close to it
+    warm.mu_init = 1e-3;
+    warm.bound_push = 1e-4;
+    warm.bound_frac = 1e-4;
+    _solution.mesh_iterations = 0;
+    _solution.nlp_iterations_total = 0;
+    _solution.ode_error = 0;
+    bool sequenced = false;             // the requested mesh is started from the sequencing ladder's solution
+
+    // Mesh sequencing: a fine global mesh is reached through coarse ones (33, 65, 129, ... nodes), each
+    // solve started from the interpolated previous solution.  An interior-point iteration from a cold
+    // straight-line guess needs hundreds of Newton steps on a 1000-node mesh; from the interpolant of the
+    // next-coarser solution it needs a few dozen, and the coarse solves cost next to nothing.
+    // (PSOPT's own remedy is the same idea driven by the error estimate: start coarse, refine.)
+    if (_algorithm.mesh_sequencing && P.nodes > 80 && P.guess_states.empty()) {
+        const size_t target = P.nodes;
+        std::vector<size_t> ladder;
+        for (size_t m = 33; m < target; m = 2 * m - 1) ladder.push_back(m);
+        bool chain_ok = true;
+        for (size_t li = 0; li < ladder.size() && chain_ok; ++li) {
+            if (li == 0) { setMesh(ladder[0]); configureDevice(_dev.get()); }
+            mi355x::NlpOptions o = li == 0 ? opt : warm;
+            o.tol = std::max(opt.tol, 1e-6);          // intermediate meshes only feed the next guess
+            solve_current_mesh(o);
+            ++_solution.mesh_iterations;
+            if (_algorithm.print_level >= 5)
+                printf("mesh sequencing: %zu nodes, %d iterations, cost %.10e (%s)\n", P.nodes, r.iterations, r.cost,
+                       r.msg.c_str());
+            chain_ok = r.ok;
+            warm.rho_init = std::max(warm.rho_init, r.rho);     // a penalty weight found too small stays raised
+            if (chain_ok) remesh_with_guess(li + 1 < ladder.size() ? ladder[li + 1] : target);
+        }
+        if (chain_ok) {
+            sequenced = true;
+        } else {                                       // fall back to the cold start on the requested mesh
+            setMesh(target);
+            configureDevice(_dev.get());
+            P.guess_states.clear();
+            P.guess_controls.clear();
+        }
+    }
+
+    // PSOPT's mesh refinement ("automatic", ePSOPT.cpp:69-71): solve, estimate the ODE error,
+    // add nodes and re-solve from the interpolated solution until the tolerance is met.
+    const bool refine = _algorithm.mesh_refinement == "automatic";
+    for (int mr = 0;; ++mr) {
+        solve_current_mesh(sequenced && mr == 0 ? warm : opt);
+        ++_solution.mesh_iterations;
+        if (!r.ok || !refine) break;
+        std::vector<double> zf;
+        size_t M2 = 0;
+        _solution.ode_error = odeError(r.z, &zf, &M2);
+        if (_algorithm.print_level >= 5)
+            printf("mesh iteration %d: %zu nodes, cost %.10e, relative ODE error %.3e\n", mr, P.nodes, r.cost,
+                   _solution.ode_error);
+        if (_solution.ode_error <= _algorithm.ode_tolerance || mr + 1 >= _algorithm.mr_max_iterations) break;
+        const size_t Mnew = std::min((size_t)_algorithm.mr_max_nodes, P.nodes + std::max<size_t>(4, (P.nodes - 1) / 2));
+        if (Mnew <= P.nodes) break;
+        // refined meshes start from the interpolated solution but with the cold-start barrier settings: the
+        // interpolant may cut through keep-outs between the old nodes, and the elastic rows need room to move
+        remesh_with_guess(Mnew);
     }
     const size_t M = P.nodes;
 

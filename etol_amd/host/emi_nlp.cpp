@@ -185,9 +185,11 @@ double convexify_node_blocks(double* Qblk, const unsigned char* fixed, int nv, i
     mods->clear();
     if (nv > NMAX) return 0.0;
     double worst = 0.0;
-    double A[NMAX][NMAX], Vv[NMAX][NMAX], lam[NMAX];
+    double A[NMAX][NMAX], Vv[NMAX][NMAX], lam[NMAX], d[NMAX];
+    // thresholds in the diagonally scaled block (unit diagonal): a block mixes barrier terms of 1e10 with
+    // curvatures of 1e-2, and only after scaling is "zero" distinguishable from "negative"
+    const double fl = 1e-9;
     for (int k = 0; k < M; ++k) {
-        // cheap screen: a block whose Cholesky runs through with comfortable pivots is left alone
         for (int v = 0; v < nv; ++v)
             for (int q = 0; q <= v; ++q) {
                 const bool fx = fixed[v * M + k] || fixed[q * M + k];
@@ -195,7 +197,13 @@ double convexify_node_blocks(double* Qblk, const unsigned char* fixed, int nv, i
             }
         double amax = 0;
         for (int v = 0; v < nv; ++v) amax = std::max(amax, std::fabs(A[v][v]));
-        const double floor_ = 1e-8 * std::max(1.0, amax);
+        for (int v = 0; v < nv; ++v)
+            for (int q = 0; q < v; ++q) amax = std::max(amax, std::fabs(A[v][q]));
+        if (amax == 0.0) amax = 1.0;
+        for (int v = 0; v < nv; ++v) d[v] = std::sqrt(std::max(std::fabs(A[v][v]), 1e-12 * amax));
+        for (int v = 0; v < nv; ++v)
+            for (int q = 0; q < nv; ++q) A[v][q] /= d[v] * d[q];          // congruence: inertia unchanged
+        // cheap screen: a block whose Cholesky runs through with comfortable pivots is left alone
         {
             double Lc[NMAX][NMAX];
             bool pd = true;
@@ -204,7 +212,7 @@ double convexify_node_blocks(double* Qblk, const unsigned char* fixed, int nv, i
                     double sum = A[i][j];
                     for (int t = 0; t < j; ++t) sum -= Lc[i][t] * Lc[j][t];
                     if (i == j) {
-                        if (!(sum > floor_)) { pd = false; break; }
+                        if (!(sum > 10.0 * fl)) { pd = false; break; }
                         Lc[i][i] = std::sqrt(sum);
                     } else {
                         Lc[i][j] = sum / Lc[j][j];
@@ -215,10 +223,12 @@ double convexify_node_blocks(double* Qblk, const unsigned char* fixed, int nv, i
         for (int i = 0; i < nv; ++i)
             for (int j = 0; j < nv; ++j) Vv[i][j] = i == j ? 1.0 : 0.0;
         for (int sweep = 0; sweep < 30; ++sweep) {
-            double off = 0;
-            for (int i = 0; i < nv; ++i)
+            double off = 0, dia = 0;
+            for (int i = 0; i < nv; ++i) {
+                dia += A[i][i] * A[i][i];
                 for (int j = 0; j < i; ++j) off += A[i][j] * A[i][j];
-            if (off < 1e-30 * std::max(1.0, amax * amax)) break;
+            }
+            if (off < 1e-32 * std::max(1.0, dia)) break;
             for (int p = 0; p < nv; ++p)
                 for (int q = p + 1; q < nv; ++q) {
                     if (A[p][q] == 0.0) continue;
@@ -242,19 +252,19 @@ double convexify_node_blocks(double* Qblk, const unsigned char* fixed, int nv, i
                     }
                 }
         }
-        double lmax = 0;
-        for (int i = 0; i < nv; ++i) { lam[i] = A[i][i]; lmax = std::max(lmax, std::fabs(lam[i])); }
-        const double fl = 1e-8 * std::max(1.0, lmax);
         for (int i = 0; i < nv; ++i) {
+            lam[i] = A[i][i];
             const double nl = std::max(std::fabs(lam[i]), fl);
-            if (nl != lam[i]) {
+            // a (numerically) zero eigenvalue is floored without bookkeeping -- a perturbation of 1e-9 of
+            // the diagonal; reflected, genuinely negative ones become columns of the low-rank correction
+            if (lam[i] < -fl) {
                 BlockMod m;
                 m.node = k;
                 m.delta = nl - lam[i];
-                for (int r = 0; r < nv; ++r) m.v[r] = Vv[r][i];
+                for (int r = 0; r < nv; ++r) m.v[r] = d[r] * Vv[r][i];
                 mods->push_back(m);
+                worst = std::max(worst, m.delta * d[0] * d[0]);
             }
-            worst = std::max(worst, nl - lam[i]);
             lam[i] = nl;
         }
         for (int v = 0; v < nv; ++v)
@@ -262,7 +272,7 @@ double convexify_node_blocks(double* Qblk, const unsigned char* fixed, int nv, i
                 if (fixed[v * M + k] || fixed[q * M + k]) continue;
                 double sum = 0;
                 for (int e = 0; e < nv; ++e) sum += Vv[v][e] * lam[e] * Vv[q][e];
-                Qblk[(size_t)(v * (v + 1) / 2 + q) * M + k] = sum;
+                Qblk[(size_t)(v * (v + 1) / 2 + q) * M + k] = d[v] * d[q] * sum;
             }
     }
     return worst;
@@ -390,7 +400,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     };
     if (!evaluate(it.z, E, true)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
 
-    double rho = 10.0;
+    double rho = opt.rho_init > 0 ? opt.rho_init : 10.0;
     it.s.assign(mc, 0.0);
     it.e1.assign(mc, 0.0);
     it.e2.assign(mc, 0.0);
@@ -509,14 +519,16 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     };
 
     // Newton-step linear algebra: the caller's backend (eMI355X: the device) or the dense host one
+    const size_t NN0 = (size_t)nz + md;
     DenseHostKkt host_kkt(P);
     KktBackend* kkt = P.kkt ? P.kkt : &host_kkt;
     std::vector<double> Qblk((size_t)nh * M), rhs_full((size_t)nz + md);
     std::vector<unsigned char> fixed_mask(nz);
     for (int q = 0; q < nz; ++q) fixed_mask[q] = fidx[q] < 0 ? 1 : 0;
     std::vector<BlockMod> mods;
+    std::vector<double> Qexact, rhs_keep(NN0), resid(NN0);
     bool exact_step = false;
-    const int max_lowrank = 2048;        // more modified eigenpairs than this: take the modified step untested
+    const int max_lowrank = 4096;        // more modified eigenpairs than this: take the modified step untested
     std::vector<double> dz(nz), ds(mc), de1(mc), de2(mc), dlam(md), dy(mc), dzL(nz), dzU(nz), dvL(mc), dvU(mc),
         dw1(mc), dw2(mc);
     std::vector<double> sig_t(mc), r_t(mc), sig_s(mc), rhat_s(mc);
@@ -581,6 +593,43 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             for (size_t r = 0; r < NN; ++r) y0[r] += tc * y[r];
         }
     };
+    // y = [[Q, J^T], [J, -dc I]] x  with the node blocks Qb (fixed variables: identity rows/columns)
+    auto kkt_matvec = [&](const double* Qb, const double* x, double* y, double dcv) {
+        const double* V = E.VALS.data();
+        std::fill(y, y + NN, 0.0);
+        for (int k = 0; k < M; ++k)
+            for (int v = 0; v < nv; ++v) {
+                if (fixed_mask[v * M + k]) continue;
+                double acc = 0;
+                for (int q = 0; q < nv; ++q) {
+                    if (fixed_mask[q * M + k]) continue;
+                    const int hi = std::max(v, q), lo = std::min(v, q);
+                    acc += Qb[(size_t)(hi * (hi + 1) / 2 + lo) * M + k] * x[q * M + k];
+                }
+                y[v * M + k] = acc;
+            }
+        for (int i = 0; i < ns; ++i)
+            for (int k = 0; k < M; ++k) {
+                const int R = nz + i * M + k;
+                const double* Dk = &P.D[(size_t)k * M];
+                const double xr = x[R];
+                double acc = 0;
+                for (int j = 0; j < M; ++j) {
+                    if (j == k || fixed_mask[i * M + j]) continue;
+                    acc += Dk[j] * x[i * M + j];
+                    y[i * M + j] += Dk[j] * xr;
+                }
+                for (int v = 0; v < nv; ++v) {
+                    if (fixed_mask[v * M + k]) continue;
+                    const double jv = V[(size_t)(i * nv + v) * M + k];
+                    acc += jv * x[v * M + k];
+                    y[v * M + k] += jv * xr;
+                }
+                y[R] = acc - dcv * xr;
+            }
+        for (int q = 0; q < nz; ++q)
+            if (fixed_mask[q]) y[q] = x[q];
+    };
     // everything that was eliminated from the system, from dz (uses r_t)
     auto expand_step = [&]() {
         const double* V = E.VALS.data();
@@ -608,6 +657,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     };
 
     grad_and_jt(it);
+    int n_acceptable = 0;
     for (int iter = 0;; ++iter) {
         R.iterations = iter;
         double viol = 0, emax = 0;
@@ -615,8 +665,8 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         R.kkt_error = err0;
         R.constr_viol = viol;
         if (opt.print_level >= 5)
-            printf("iter %3d  cost %.10e  inf_pr %.2e  kkt %.2e  mu %.1e  dw %.1e  nu %.1e  emax %.1e  rho %.0e\n", iter,
-                   E.cost, viol, err0, mu, dw_used, nu, emax, rho);
+            printf("iter %3d  cost %.10e  inf_pr %.2e  kkt %.2e  mu %.1e  dw %.1e  nu %.1e  emax %.1e  rho %.0e  r %d%s\n", iter,
+                   E.cost, viol, err0, mu, dw_used, nu, emax, rho, (int)mods.size(), exact_step ? " exact" : "");
         if (err0 <= opt.tol) {
             if (emax <= std::max(opt.tol, 1e-9) * 10.0 || mc == 0) { R.ok = true; R.msg = "converged"; break; }
             // a path row is still relaxed: the penalty was too small for it
@@ -625,14 +675,34 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             mu = std::max(mu, 1e-2);
             for (int r = 0; r < mc; ++r) { it.w1[r] = std::max(1e-8, rho - it.y[r]); it.w2[r] = std::max(1e-8, rho + it.y[r]); }
         }
+        // stagnation at round-off above the tolerance (large meshes): accept like IPOPT's acceptable level
+        if (err0 <= opt.acceptable_factor * opt.tol && (mc == 0 || emax <= 1e-6)) {
+            if (++n_acceptable >= opt.acceptable_iter) { R.ok = true; R.msg = "converged to acceptable level"; break; }
+        } else {
+            n_acceptable = 0;
+        }
         if (iter >= opt.max_iter) { R.msg = "maximum number of iterations exceeded"; break; }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count() > opt.max_cpu_time) {
             R.msg = "time limit exceeded";
             break;
         }
         // barrier update (may fire several times in a row)
-        while (mu > opt.tol / 10.0 && kkt_error(it, mu, nullptr, nullptr) <= kappa_eps * mu)
+        while (mu > opt.tol / 10.0 && kkt_error(it, mu, nullptr, nullptr) <= kappa_eps * mu) {
+            // this barrier problem is solved.  A row multiplier at the penalty weight (or, equivalently, an
+            // elastic still far above mu / rho) means the weight is too small for that row: raise it now
+            // instead of converging to a relaxed point first
+            double ymax = 0;
+            for (int r = 0; r < mc; ++r) ymax = std::max(ymax, std::fabs(it.y[r]));
+            if (mc > 0 && (emax > std::max(1e-6, 100.0 * mu) || ymax > 0.9 * rho) && rho < 1e12) {
+                rho *= 10.0;
+                mu = std::max(mu, 1e-2);
+                for (int r = 0; r < mc; ++r) { it.w1[r] = std::max(1e-8, rho - it.y[r]); it.w2[r] = std::max(1e-8, rho + it.y[r]); }
+                nu = 1.0;
+                break;
+            }
             mu = std::max(opt.tol / 10.0, std::min(kappa_mu * mu, std::pow(mu, theta_mu)));
+            nu = 1.0;    // a new barrier problem: the penalty weight is rebuilt from its multipliers, not inherited
+        }
         const double tau = std::max(tau_min, 1.0 - mu);
 
         // exact Lagrangian Hessian blocks from the device
@@ -695,6 +765,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                         qxy[k] += sg * gx * gy;
                     }
             }
+            Qexact = Qblk;
             dw = convexify_node_blocks(Qblk.data(), fixed_mask.data(), nv, M, &mods);
             const int info = kkt->factor(Qblk.data(), V, fixed_mask.data(), dc);
             if (info < 0) { R.msg = "KKT factorisation failed: " + kkt->last_error(); return R; }
@@ -706,6 +777,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             r_mod = (int)mods.size() <= max_lowrank ? (int)mods.size() : 0;
             rhs_full.assign(NN * (1 + r_mod), 0.0);
             build_rhs(rhs_full.data(), E.RES.data());
+            std::copy(rhs_full.begin(), rhs_full.begin() + NN, rhs_keep.begin());
             for (int c = 0; c < r_mod; ++c)
                 for (int v = 0; v < nv; ++v) rhs_full[NN * (1 + c) + v * M + mods[c].node] = mods[c].v[v];
             if (kkt->solve(rhs_full.data(), 1 + r_mod) != 0) { R.msg = "KKT solve failed: " + kkt->last_error(); return R; }
@@ -740,6 +812,28 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 if (pd) {
                     exact_step = true;
                     woodbury(rhs_full.data());      // x = y0 + Y C^-1 (U^T y0)
+                }
+            }
+            // iterative refinement against the matrix the step belongs to (K if exact, K~ otherwise): the
+            // factorisation of a 1000-node KKT matrix leaves residuals that would stall the Newton
+            // iteration some orders above the requested tolerance
+            {
+                const std::vector<double>& Qm = exact_step ? Qexact : Qblk;
+                double bmax = 0;
+                for (size_t r = 0; r < NN; ++r) bmax = std::max(bmax, std::fabs(rhs_keep[r]));
+                double prev = 1e300;
+                for (int ir = 0; ir < 3; ++ir) {
+                    kkt_matvec(Qm.data(), rhs_full.data(), resid.data(), dc);
+                    double rmax = 0;
+                    for (size_t r = 0; r < NN; ++r) { resid[r] = rhs_keep[r] - resid[r]; rmax = std::max(rmax, std::fabs(resid[r])); }
+                    if (!(rmax > 1e-14 * std::max(1.0, bmax)) || !(rmax < 0.5 * prev)) break;
+                    prev = rmax;
+                    if (kkt->solve(resid.data(), 1) != 0) break;
+                    if (exact_step && r_mod > 0) woodbury(resid.data());
+                    bool fin = true;
+                    for (size_t r = 0; r < NN && fin; ++r) fin = std::isfinite(resid[r]);
+                    if (!fin) break;
+                    for (size_t r = 0; r < NN; ++r) rhs_full[r] += resid[r];
                 }
             }
             if (exact_step) dw = 0.0;     // the log shows the shift only when the modified step was taken
@@ -793,14 +887,16 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             dphi += g * ds[r] + (rho - mu / it.e1[r]) * de1[r] + (rho - mu / it.e2[r]) * de2[r];
         }
         const double phi0_base = barrier_merit(it.z, it.s, it.e1, it.e2, E, mu, 0.0, &infeas0);
-        if (infeas0 > 0) {
-            const double need = dphi / (0.9 * infeas0);
-            if (nu < need) nu = need + 1.0;
-        }
+        // penalty weight of the l1 merit function: what the current multipliers and the descent condition
+        // ask for.  It may come down again (at most halving per iteration): the multipliers of the first,
+        // far-from-feasible iterations are orders of magnitude above those near the solution, and a weight
+        // frozen at that level rejects every step whose constraint curvature shows at all.
         double mmax = 0;
         for (int r = 0; r < md; ++r) mmax = std::max(mmax, std::fabs(it.lam[r] + dlam[r]));
         for (int r = 0; r < mc; ++r) mmax = std::max(mmax, std::fabs(it.y[r] + dy[r]));
-        nu = std::max(nu, std::min(1.1 * mmax, 1e8));
+        double nu_want = std::max(1.0, std::min(1.1 * mmax, 1e8));
+        if (infeas0 > 0) nu_want = std::max(nu_want, dphi / (0.9 * infeas0) + 1.0);
+        nu = std::max(nu_want, 0.5 * nu);
         const double phi0 = phi0_base + nu * infeas0;
         const double slope = dphi - nu * infeas0;
         auto slack_reset = [&]() {
@@ -930,6 +1026,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         grad_and_jt(it);
     }
     R.cost = E.cost;
+    R.rho = rho;
     R.z = it.z;
     R.lamF = it.lam;
     R.lamC.resize(mc);

@@ -66,6 +66,9 @@ struct NlpOptions {
     double mu_init = 0.1;
     double bound_push = 1e-2, bound_frac = 1e-2;
     double max_cpu_time = 1e9;          // seconds
+    double rho_init = 10.0;             // exact-penalty weight of the elastic path rows (escalated x10 as needed)
+    double acceptable_factor = 100.0;   // "acceptable": KKT error <= acceptable_factor * tol ...
+    int acceptable_iter = 10;           // ... over this many consecutive iterations (as IPOPT's acceptable_*)
 };
 
 struct NlpResult {
@@ -77,6 +80,7 @@ struct NlpResult {
     double cost = 0, kkt_error = 0, constr_viol = 0;
     std::vector<double> z;              // (ns+nc)*M solution
     std::vector<double> lamF, lamC;     // multipliers of the defect and path rows
+    double rho = 0;                     // penalty weight the solve ended with (warm start of the next mesh)
 };
 
 NlpResult solve_nlp(const NlpProblem& prob, const NlpOptions& opt, const std::vector<double>& z0);

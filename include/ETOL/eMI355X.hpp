@@ -32,6 +32,7 @@ struct Alg {
     int mr_max_iterations = 10;                    // ePSOPT.cpp:70
     double ode_tolerance = 1.e-4;                  // ePSOPT.cpp:71
     int mr_max_nodes = 513;                        // refinement stops adding nodes here
+    bool mesh_sequencing = true;                   // meshes above 80 nodes are reached through 33, 65, 129, ... nodes
     std::string linear_solver = "auto";            // Newton step: "host" (dense LDL^T), "device" (KKT assembled and
                                                    // LU-factorised in HBM), "auto" = device above 1200 KKT rows
     int nlp_iter_max = 200;
@@ -45,7 +46,8 @@ struct Sol {
     int error_flag = 0;
     std::string error_msg;
     double cost = 0;
-    int nlp_iterations = 0;
+    int nlp_iterations = 0;         // of the last NLP solve
+    int nlp_iterations_total = 0;   // over all meshes (sequencing + refinement)
     int evaluations = 0;
     double kkt_error = 0, constraint_violation = 0;
     std::string linear_solver;      // what the last solve used for the Newton step

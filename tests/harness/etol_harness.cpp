@@ -250,7 +250,12 @@ void configure_quadrotor(ETOL::TrajectoryOptimizer* t, QuadSetup& q, int nsteps,
     t->setXlower({0, 0, -1.2, -6, -6, -4}); t->setXupper({10, 10, 1.2, 6, 6, 4});
     t->setUlower({0, -g_quad_tau_max}); t->setUupper({25, g_quad_tau_max});
     t->setMaximize(false);
-    const std::array<double, 3> all[3] = {{4.0, 3.2, 0.8}, {6.3, 4.4, 0.7}, {2.5, 1.2, 0.4}};
+    // up to 20 keep-out discs (config 3 has 20): three large ones near the straight line, the rest scattered
+    const std::array<double, 3> all[20] = {{4.0, 3.2, 0.8}, {6.3, 4.4, 0.7}, {2.5, 1.2, 0.4}, {1.6, 3.4, 0.35}, {3.1, 5.2, 0.30},
+                                           {5.2, 1.4, 0.35}, {7.4, 2.6, 0.30}, {8.6, 4.2, 0.25}, {5.0, 6.3, 0.35}, {2.2, 7.1, 0.30},
+                                           {6.9, 7.4, 0.35}, {8.9, 7.9, 0.30}, {0.9, 5.6, 0.25}, {3.9, 8.4, 0.30}, {9.2, 1.3, 0.30},
+                                           {7.0, 0.8, 0.25}, {4.6, 4.9, 0.20}, {2.9, 2.9, 0.20}, {5.6, 3.0, 0.20}, {7.6, 5.4, 0.20}};
+    if (ndiscs > 20) ndiscs = 20;
     for (int i = 0; i < ndiscs; ++i) q.discs.push_back(all[i]);
     auto mp = q.params;
     const bool traced = g_traced != 0;

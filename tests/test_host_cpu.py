@@ -175,3 +175,33 @@ def test_nlp_iteration_quadrotor_vgp(H):
     assert np.abs(RES[0, :6]).max() < 1e-7 and RES[0, 6:].max() < 1e-7 and abs(COST[0] - cost.value) < 1e-8
     assert np.allclose(X[:, 0], [1, 1, 0, 0, 0, 0]) and np.all(np.abs(X[:3, -1] - [8, 6, 0]) <= 0.01 + 1e-9)
     assert U[0].min() >= -1e-9 and U[0].max() <= 25 + 1e-9 and np.abs(U[1]).max() <= 1 + 1e-9
+
+
+def test_newton_step_backend_interface_keeps_the_inertia_right(H):
+    """solve_nlp hands a quasi-definite matrix (node blocks convexified) to its KktBackend and recovers
+    the exact step by a Woodbury correction.  Driven here with a host stand-in for the device backend
+    (same matrix as etol_amd/csrc/emi_kkt.hip, dense LDL^T so that the inertia can be counted): the
+    factorised matrix must have exactly nz positive / md negative eigenvalues at EVERY iteration, and
+    the iteration must end where the built-in host backend ends."""
+    D = C.POINTER(C.c_double)
+    H.harness_solve_quadrotor_oracle.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, D,
+                                                 C.POINTER(C.c_int), D, D, C.c_int, C.POINTER(C.c_int)]
+    H.harness_set_linear_solver.argtypes = [C.c_char_p]
+    H.harness_last_message.restype = C.c_char_p
+    out = {}
+    try:
+        for name in ("host", "device"):
+            H.harness_set_linear_solver(name.encode())
+            X, U = np.zeros(6 * 64), np.zeros(2 * 64)
+            cost, M, it = C.c_double(), C.c_int(), C.c_int()
+            rc = H.harness_solve_quadrotor_oracle(os.path.join(ROOT, "oracle", "liboracle.so").encode(), 24, 0.16, 2, 1e-8,
+                                                  0, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D),
+                                                  64, C.byref(it))
+            assert rc == 0, H.harness_last_message().decode()
+            out[name] = (cost.value, X.copy(), it.value)
+        assert H.harness_kkt_standin_wrong_inertia() == 0
+    finally:
+        H.harness_set_linear_solver(b"auto")
+    assert out["host"][2] < 150 and out["device"][2] < 150
+    assert abs(out["host"][0] - out["device"][0]) < 1e-8 * out["host"][0]
+    assert np.abs(out["host"][1] - out["device"][1]).max() < 1e-6

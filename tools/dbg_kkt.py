@@ -14,7 +14,11 @@ H.harness_set_linear_solver(sys.argv[1].encode())
 cap = nsteps + 10
 X, U = np.zeros(6 * cap), np.zeros(2 * cap)
 cost, M, it, mit, oerr = C.c_double(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
-rc = H.harness_solve_quadrotor(nsteps, 4.0 / nsteps, 2, 1e-8, int(sys.argv[3]) if len(sys.argv) > 3 else 5, 0, 1e-4, C.byref(cost), C.byref(M), X.ctypes.data_as(D),
+ndiscs = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+import time
+t0 = time.time()
+rc = H.harness_solve_quadrotor(nsteps, 4.0 / nsteps, ndiscs, 1e-8, int(sys.argv[3]) if len(sys.argv) > 3 else 5, 0, 1e-4, C.byref(cost), C.byref(M), X.ctypes.data_as(D),
                                U.ctypes.data_as(D), cap, C.byref(it), C.byref(mit), C.byref(oerr))
 sys.stdout.flush()
+print("wall %.2f s" % (time.time() - t0))
 print("rc", rc, H.harness_last_message().decode(), "cost", cost.value, "iters", it.value)
