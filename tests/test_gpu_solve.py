@@ -23,6 +23,8 @@ def H(built):
     lib.harness_solve_example1.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, D, C.POINTER(C.c_int), D, D, D,
                                            C.c_int, C.POINTER(C.c_int)]
     lib.harness_last_message.restype = C.c_char_p
+    lib.harness_last_linear_solver.restype = C.c_char_p
+    lib.harness_set_linear_solver.argtypes = [C.c_char_p]
     return lib
 
 
@@ -215,3 +217,26 @@ def _solve_quadrotor_cap(H, nsteps, dt, ndiscs, cap):
     assert rc == 0, H.harness_last_message().decode()
     m = M.value
     return cost.value, X[:6 * m].reshape(6, m), U[:2 * m].reshape(2, m), it.value, mit.value, oerr.value
+
+
+def test_config3_sized_problem_end_to_end(H):
+    """Config 3 of the scope table as ONE optimisation: 6-state quadrotor, 1024 LGL nodes, 20 disc
+    keep-outs (8192 variables, 6144 defect + 20480 path rows).  Mesh sequencing 33 -> ... -> 513 -> 1024,
+    every evaluation, derivative and Newton step (KKT matrix of 14336 rows) on the GPU."""
+    import time
+    t0 = time.time()
+    cost, X, U, iters, mesh_iters, _ = _solve_quadrotor_cap(H, 1023, 4.0 / 1023, 20, cap=1100)
+    dt = time.time() - t0
+    assert H.harness_last_linear_solver().decode().startswith("device")
+    m = X.shape[1]
+    assert m == 1024 and mesh_iters >= 6 and iters < 200
+    discs = [(4.0, 3.2, 0.8), (6.3, 4.4, 0.7), (2.5, 1.2, 0.4), (1.6, 3.4, 0.35), (3.1, 5.2, 0.30), (5.2, 1.4, 0.35),
+             (7.4, 2.6, 0.30), (8.6, 4.2, 0.25), (5.0, 6.3, 0.35), (2.2, 7.1, 0.30), (6.9, 7.4, 0.35), (8.9, 7.9, 0.30),
+             (0.9, 5.6, 0.25), (3.9, 8.4, 0.30), (9.2, 1.3, 0.30), (7.0, 0.8, 0.25), (4.6, 4.9, 0.20), (2.9, 2.9, 0.20),
+             (5.6, 3.0, 0.20), (7.6, 5.4, 0.20)]
+    recs = np.array([[1, x, y, r * r, 0, 0, 0, 0] for x, y, r in discs], dtype=float)
+    RES, _, COST = O.evaluate(1, [1.0, 0.01, 9.81, 1.0, 1.0], m, O.lgl(m), 0.0, 4.0, X[None], U[None], recs)
+    assert np.abs(RES[0, :6]).max() < 1e-6 and RES[0, 6:].max() < 1e-6 and abs(COST[0] - cost) < 1e-7
+    assert np.allclose(X[:, 0], [1, 1, 0, 0, 0, 0]) and np.all(np.abs(X[:3, -1] - [8, 6, 0]) <= 0.01 + 1e-9)
+    assert 380 < cost < 460
+    print(f"quadrotor M=1024, 20 keep-outs: {mesh_iters} meshes, last solve {iters} iterations, {dt:.1f} s wall")
