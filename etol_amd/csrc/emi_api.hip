@@ -57,6 +57,7 @@ struct emi_ctx_s {
     int model = -1, ns = 0, nc = 0, maximize = 0;
     double params[EMI_MAX_PARAMS] = {0};
     emi::KktWorkspace* kkt = nullptr;   // Newton-step workspace (emi_kkt_factor)
+    int kkt_method = 1;                 // 1: Schur complement + Cholesky (falls back to 0 if not quasi-definite); 0: LU of K
     emi::RtcModel* rtc = nullptr;   // model == EMI_MODEL_SOURCE: code object compiled at emi_set_model_source
     // batch / path
     int B = 0;
@@ -723,7 +724,7 @@ int emi_kkt_factor(emi_ctx_t c, const double* Qblk, const double* Jblk, const un
     HIP_TRY(c, hipSetDevice(c->device));
     std::string err;
     const int st = emi::kkt_factor(&c->kkt, c->stream, (const double*)c->d_D.p, c->M, c->ns, c->ns + c->nc, Qblk, Jblk,
-                                   fixed, dc, info, &err);
+                                   fixed, dc, c->kkt_method, info, &err);
     if (st) c->err = err;
     return st;
 }
@@ -808,6 +809,11 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
     if (strcmp(name, "sym_ct") == 0) {
         if (value < 1 || value > 3) return fail(c, EMI_ERR_ARG, "sym_ct must be 1, 2 or 3 (3 = LDS-DMA ring)");
         c->sym_ct = value;
+        return EMI_OK;
+    }
+    if (strcmp(name, "kkt_method") == 0) {
+        if (value != 0 && value != 1) return fail(c, EMI_ERR_ARG, "kkt_method must be 0 (LU) or 1 (Schur complement + Cholesky)");
+        c->kkt_method = value;
         return EMI_OK;
     }
     if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }

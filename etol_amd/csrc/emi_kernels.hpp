@@ -43,7 +43,7 @@ hipError_t rtc_launch_symdefect(RtcModel* m, const SymDefectArgs& a, hipStream_t
 // Newton step on the device (emi_kkt.hip)
 struct KktWorkspace;
 int kkt_factor(KktWorkspace** w, hipStream_t stream, const double* dD, int M, int ns, int nv, const double* Qblk,
-               const double* Jblk, const unsigned char* fixed, double dc, int* info, std::string* err);
+               const double* Jblk, const unsigned char* fixed, double dc, int method, int* info, std::string* err);
 int kkt_solve(KktWorkspace* w, hipStream_t stream, int nz, double* rhs, int nrhs, std::string* err);
 void kkt_destroy(KktWorkspace* w);
 
