@@ -729,6 +729,18 @@ int emi_kkt_factor(emi_ctx_t c, const double* Qblk, const double* Jblk, const un
     return st;
 }
 
+int emi_kkt_lowrank(emi_ctx_t c, int r, const int* node, const double* vec, const double* delta, int* exact) {
+    if (!c || r < 0 || !exact || (r > 0 && (!node || !vec || !delta))) return fail(c, EMI_ERR_ARG, "emi_kkt_lowrank: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (int a = 0; a < r; ++a)
+        if (node[a] < 0 || node[a] >= c->M || !(delta[a] > 0.0))
+            return fail(c, EMI_ERR_ARG, "emi_kkt_lowrank: column %d has node %d / delta %g", a, node[a], delta[a]);
+    std::string err;
+    const int st = emi::kkt_lowrank(c->kkt, c->stream, (c->ns + c->nc) * c->M, r, node, vec, delta, exact, &err);
+    if (st) c->err = err;
+    return st;
+}
+
 int emi_kkt_solve(emi_ctx_t c, double* rhs, int nrhs) {
     if (!c || !rhs || nrhs < 1) return EMI_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));

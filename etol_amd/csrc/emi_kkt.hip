@@ -61,6 +61,15 @@ struct KktWorkspace {
     size_t T_elems = 0, Cb_elems = 0;
     size_t cap_schur = 0;
     int* flag = nullptr;        // node kernel: a block was not positive definite
+    // low-rank correction (kkt_lowrank)
+    bool lr_active = false;
+    int lr_r = 0, lr_cap = 0, lr_n = 0;
+    double* lrY = nullptr;      // [N][r]  K~^-1 U
+    double* lrC = nullptr;      // [r][r]  Cholesky factor of Delta^-1 - U^T Y
+    double* lrT = nullptr;      // [r][<=64] work
+    int* lr_node = nullptr;
+    double* lr_vec = nullptr;   // [r][nv]
+    double* lr_delta = nullptr;
 };
 
 namespace {
@@ -243,6 +252,37 @@ __global__ void emi_kkt_copy_lambda_kernel(const double* __restrict__ lam, size_
     if (r < md) rhs[(size_t)c * ld_r + nz + r] = lam[(size_t)c * ld_l + r];
 }
 
+// ---- low-rank correction kernels ---------------------------------------------------------------
+// U[(v, node_c), c] = vec_c[v]
+__global__ void emi_kkt_lr_scatter_kernel(double* __restrict__ U, const int* __restrict__ node, const double* __restrict__ vec,
+                                          int r, int N, int M, int nv) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= r) return;
+    for (int v = 0; v < nv; ++v) U[(size_t)c * N + (size_t)v * M + node[c]] = vec[(size_t)c * nv + v];
+}
+// C[a][c] = (a == c) / delta_a - sum_v vec_a[v] Y[(v, node_a), c]      (column-major r x r, lower triangle used)
+__global__ void emi_kkt_lr_c_kernel(double* __restrict__ Cm, const double* __restrict__ Y, const int* __restrict__ node,
+                                    const double* __restrict__ vec, const double* __restrict__ delta, int r, int N, int M, int nv) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y * blockDim.y + threadIdx.y;
+    if (a >= r || c >= r) return;
+    double dot = 0;
+    const double* y = Y + (size_t)c * N + node[a];
+    for (int v = 0; v < nv; ++v) dot += vec[(size_t)a * nv + v] * y[(size_t)v * M];
+    Cm[(size_t)c * r + a] = (a == c ? 1.0 / delta[a] : 0.0) - dot;
+}
+// T[a, c] = sum_v vec_a[v] X[(v, node_a), c]
+__global__ void emi_kkt_lr_utx_kernel(double* __restrict__ T, const double* __restrict__ X, const int* __restrict__ node,
+                                      const double* __restrict__ vec, int r, int N, int M, int nv) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
+    if (a >= r) return;
+    double dot = 0;
+    const double* x = X + (size_t)c * N + node[a];
+    for (int v = 0; v < nv; ++v) dot += vec[(size_t)a * nv + v] * x[(size_t)v * M];
+    T[(size_t)c * r + a] = dot;
+}
+
 const char* rb(rocblas_status s) { return rocblas_status_to_string(s); }
 
 }  // namespace
@@ -251,7 +291,7 @@ void kkt_destroy(KktWorkspace* w) {
     if (!w) return;
     if (w->handle) (void)rocblas_destroy_handle(w->handle);
     void* bufs[] = {w->K, w->ipiv, w->info, w->Q, w->J, w->rhs, w->fixed, w->S, w->Pinv, w->G, w->Rk, w->Doff, w->W, w->T,
-                    w->Cb, w->flag};
+                    w->Cb, w->flag, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete w;
@@ -264,6 +304,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
     if (!*pw) *pw = new KktWorkspace();
     KktWorkspace* w = *pw;
     w->factored = false;
+    w->lr_active = false;
 #define KKT_HIP(call)                                                                      \
     do {                                                                                   \
         hipError_t e_ = (call);                                                            \
@@ -365,19 +406,10 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
     return EMI_OK;
 }
 
-int kkt_solve(KktWorkspace* w, hipStream_t stream, int nz, double* rhs, int nrhs, std::string* err) {
-    if (!w || !w->factored) { *err = "emi_kkt_solve: no factorisation (emi_kkt_factor must succeed first)"; return EMI_ERR_STATE; }
+// X [N][nrhs] on the device, in place: X <- K~^-1 X with the current factorisation
+static int solve_dev(KktWorkspace* w, hipStream_t stream, int nz, double* X, int nrhs, std::string* err) {
     const int N = w->N;
-    const size_t elems = (size_t)N * nrhs;
-    if (w->rhs_elems < elems) {
-        if (w->rhs) KKT_HIP(hipFree(w->rhs));
-        w->rhs = nullptr;
-        w->rhs_elems = 0;
-        KKT_HIP(hipMalloc(&w->rhs, elems * sizeof(double)));
-        w->rhs_elems = elems;
-    }
-    KKT_HIP(hipMemcpyAsync(w->rhs, rhs, elems * sizeof(double), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(emi_kkt_mask_rhs_kernel, dim3((nz + 255) / 256, nrhs), dim3(256), 0, stream, w->rhs, w->fixed, nz, N);
+    hipLaunchKernelGGL(emi_kkt_mask_rhs_kernel, dim3((nz + 255) / 256, nrhs), dim3(256), 0, stream, X, w->fixed, nz, N);
     KKT_HIP(hipGetLastError());
     KKT_RB(rocblas_set_stream(w->handle, stream));
     if (w->method_used == 1) {
@@ -397,30 +429,116 @@ int kkt_solve(KktWorkspace* w, hipStream_t stream, int nz, double* rhs, int nrhs
         const double one = 1.0, zero = 0.0, mone = -1.0;
         dim3 gk((M + 127) / 128, nrhs), bk(128);
         // t = P a
-        hipLaunchKernelGGL(emi_kkt_apply_p_kernel, gk, bk, 0, stream, w->Pinv, w->rhs, (size_t)N, w->T, (size_t)nz, M, nv);
+        hipLaunchKernelGGL(emi_kkt_apply_p_kernel, gk, bk, 0, stream, w->Pinv, X, (size_t)N, w->T, (size_t)nz, M, nv);
         // Cb = Doff t_states            (Doff = Dc^T in column-major terms), one M x ns panel per right-hand side
         KKT_RB(rocblas_dgemm_strided_batched(w->handle, rocblas_operation_transpose, rocblas_operation_none, M, ns, M, &one,
                                              w->Doff, M, 0, w->T, M, (rocblas_stride)nz, &zero, w->Cb, M, (rocblas_stride)md,
                                              nrhs));
         // Cb += J_node t - b
-        hipLaunchKernelGGL(emi_kkt_jnode_minus_b_kernel, gk, bk, 0, stream, w->J, w->T, (size_t)nz, w->rhs + nz, (size_t)N, w->Cb,
+        hipLaunchKernelGGL(emi_kkt_jnode_minus_b_kernel, gk, bk, 0, stream, w->J, w->T, (size_t)nz, X + nz, (size_t)N, w->Cb,
                            (size_t)md, M, ns, nv);
         KKT_HIP(hipGetLastError());
         // lambda = S^-1 Cb
         KKT_RB(rocsolver_dpotrs(w->handle, rocblas_fill_lower, md, nrhs, w->S, md, w->Cb, md));
-        // y = a - J^T lambda  (in place in the primal part of rhs), then x = P y
+        // y = a - J^T lambda  (in place in the primal part of X), then x = P y
         KKT_RB(rocblas_dgemm_strided_batched(w->handle, rocblas_operation_none, rocblas_operation_none, M, ns, M, &mone, w->Doff,
-                                             M, 0, w->Cb, M, (rocblas_stride)md, &one, w->rhs, M, (rocblas_stride)N, nrhs));
-        hipLaunchKernelGGL(emi_kkt_jnode_t_kernel, gk, bk, 0, stream, w->J, w->Cb, (size_t)md, w->rhs, (size_t)N, M, ns, nv);
-        hipLaunchKernelGGL(emi_kkt_apply_p_kernel, gk, bk, 0, stream, w->Pinv, w->rhs, (size_t)N, w->T, (size_t)nz, M, nv);
+                                             M, 0, w->Cb, M, (rocblas_stride)md, &one, X, M, (rocblas_stride)N, nrhs));
+        hipLaunchKernelGGL(emi_kkt_jnode_t_kernel, gk, bk, 0, stream, w->J, w->Cb, (size_t)md, X, (size_t)N, M, ns, nv);
+        hipLaunchKernelGGL(emi_kkt_apply_p_kernel, gk, bk, 0, stream, w->Pinv, X, (size_t)N, w->T, (size_t)nz, M, nv);
         KKT_HIP(hipGetLastError());
-        KKT_HIP(hipMemcpy2DAsync(w->rhs, (size_t)N * sizeof(double), w->T, (size_t)nz * sizeof(double), (size_t)nz * sizeof(double),
+        KKT_HIP(hipMemcpy2DAsync(X, (size_t)N * sizeof(double), w->T, (size_t)nz * sizeof(double), (size_t)nz * sizeof(double),
                                  nrhs, hipMemcpyDeviceToDevice, stream));
-        hipLaunchKernelGGL(emi_kkt_copy_lambda_kernel, dim3((md + 255) / 256, nrhs), dim3(256), 0, stream, w->Cb, (size_t)md, w->rhs,
+        hipLaunchKernelGGL(emi_kkt_copy_lambda_kernel, dim3((md + 255) / 256, nrhs), dim3(256), 0, stream, w->Cb, (size_t)md, X,
                            (size_t)N, nz, md);
         KKT_HIP(hipGetLastError());
     } else {
-        KKT_RB(rocsolver_dgetrs(w->handle, rocblas_operation_none, N, nrhs, w->K, N, w->ipiv, w->rhs, N));
+        KKT_RB(rocsolver_dgetrs(w->handle, rocblas_operation_none, N, nrhs, w->K, N, w->ipiv, X, N));
+    }
+    return EMI_OK;
+}
+
+// Low-rank correction K = K~ - U Delta U^T (U = [u; 0], one column per reflected eigenpair of a node block):
+// Y = K~^-1 U and the Cholesky factor of C = Delta^-1 - U^T Y stay on the device; *exact = 1 iff C is positive
+// definite, i.e. iff the unmodified K has the inertia of K~ (emi_nlp.cpp has the argument).  While exact,
+// kkt_solve returns solutions of K (Woodbury), otherwise of K~.
+int kkt_lowrank(KktWorkspace* w, hipStream_t stream, int nz, int r, const int* node, const double* vec, const double* delta,
+                int* exact, std::string* err) {
+    if (!w || !w->factored) { *err = "emi_kkt_lowrank: no factorisation"; return EMI_ERR_STATE; }
+    w->lr_active = false;
+    w->lr_r = 0;
+    *exact = r == 0 ? 1 : 0;
+    if (r == 0) return EMI_OK;
+    const int N = w->N, nv = w->nv, M = w->M;
+    if (w->lr_cap < r) {
+        void** bufs[] = {(void**)&w->lrY, (void**)&w->lrC, (void**)&w->lr_node, (void**)&w->lr_vec, (void**)&w->lr_delta,
+                         (void**)&w->lrT};
+        for (void** b : bufs)
+            if (*b) { KKT_HIP(hipFree(*b)); *b = nullptr; }
+        w->lr_cap = 0;
+        const int cap = r + r / 4 + 16;
+        KKT_HIP(hipMalloc(&w->lrY, (size_t)N * cap * sizeof(double)));
+        KKT_HIP(hipMalloc(&w->lrC, (size_t)cap * cap * sizeof(double)));
+        KKT_HIP(hipMalloc(&w->lr_node, (size_t)cap * sizeof(int)));
+        KKT_HIP(hipMalloc(&w->lr_vec, (size_t)cap * KKT_NV_MAX * sizeof(double)));
+        KKT_HIP(hipMalloc(&w->lr_delta, (size_t)cap * sizeof(double)));
+        KKT_HIP(hipMalloc(&w->lrT, (size_t)cap * 64 * sizeof(double)));
+        w->lr_cap = cap;
+        w->lr_n = N;
+    } else if (w->lr_n < N) {
+        if (w->lrY) KKT_HIP(hipFree(w->lrY));
+        w->lrY = nullptr;
+        KKT_HIP(hipMalloc(&w->lrY, (size_t)N * w->lr_cap * sizeof(double)));
+        w->lr_n = N;
+    }
+    KKT_HIP(hipMemcpyAsync(w->lr_node, node, (size_t)r * sizeof(int), hipMemcpyHostToDevice, stream));
+    KKT_HIP(hipMemcpyAsync(w->lr_vec, vec, (size_t)r * nv * sizeof(double), hipMemcpyHostToDevice, stream));
+    KKT_HIP(hipMemcpyAsync(w->lr_delta, delta, (size_t)r * sizeof(double), hipMemcpyHostToDevice, stream));
+    KKT_HIP(hipMemsetAsync(w->lrY, 0, (size_t)N * r * sizeof(double), stream));
+    hipLaunchKernelGGL(emi_kkt_lr_scatter_kernel, dim3((r + 63) / 64), dim3(64), 0, stream, w->lrY, w->lr_node, w->lr_vec, r, N, M,
+                       nv);
+    KKT_HIP(hipGetLastError());
+    int st = solve_dev(w, stream, nz, w->lrY, r, err);
+    if (st) return st;
+    hipLaunchKernelGGL(emi_kkt_lr_c_kernel, dim3((r + 15) / 16, (r + 15) / 16), dim3(16, 16), 0, stream, w->lrC, w->lrY, w->lr_node,
+                       w->lr_vec, w->lr_delta, r, N, M, nv);
+    KKT_HIP(hipGetLastError());
+    KKT_RB(rocsolver_dpotrf(w->handle, rocblas_fill_lower, r, w->lrC, r, w->info));
+    rocblas_int hinfo = 0;
+    KKT_HIP(hipMemcpyAsync(&hinfo, w->info, sizeof hinfo, hipMemcpyDeviceToHost, stream));
+    KKT_HIP(hipStreamSynchronize(stream));
+    if (hinfo == 0) {
+        w->lr_active = true;
+        w->lr_r = r;
+        *exact = 1;
+    }
+    return EMI_OK;
+}
+
+int kkt_solve(KktWorkspace* w, hipStream_t stream, int nz, double* rhs, int nrhs, std::string* err) {
+    if (!w || !w->factored) { *err = "emi_kkt_solve: no factorisation (emi_kkt_factor must succeed first)"; return EMI_ERR_STATE; }
+    const int N = w->N;
+    const size_t elems = (size_t)N * nrhs;
+    if (w->rhs_elems < elems) {
+        if (w->rhs) KKT_HIP(hipFree(w->rhs));
+        w->rhs = nullptr;
+        w->rhs_elems = 0;
+        KKT_HIP(hipMalloc(&w->rhs, elems * sizeof(double)));
+        w->rhs_elems = elems;
+    }
+    KKT_HIP(hipMemcpyAsync(w->rhs, rhs, elems * sizeof(double), hipMemcpyHostToDevice, stream));
+    int st = solve_dev(w, stream, nz, w->rhs, nrhs, err);
+    if (st) return st;
+    if (w->lr_active) {
+        // x <- x + Y C^-1 (U^T x)
+        const int r = w->lr_r;
+        if (nrhs > 64) { *err = "emi_kkt_solve: at most 64 right-hand sides while a low-rank correction is active"; return EMI_ERR_ARG; }
+        hipLaunchKernelGGL(emi_kkt_lr_utx_kernel, dim3((r + 63) / 64, nrhs), dim3(64), 0, stream, w->lrT, w->rhs, w->lr_node,
+                           w->lr_vec, r, N, w->M, w->nv);
+        KKT_HIP(hipGetLastError());
+        KKT_RB(rocsolver_dpotrs(w->handle, rocblas_fill_lower, r, nrhs, w->lrC, r, w->lrT, r));
+        const double one = 1.0;
+        KKT_RB(rocblas_dgemm(w->handle, rocblas_operation_none, rocblas_operation_none, N, nrhs, r, &one, w->lrY, N, w->lrT, r,
+                             &one, w->rhs, N));
     }
     KKT_HIP(hipMemcpyAsync(rhs, w->rhs, elems * sizeof(double), hipMemcpyDeviceToHost, stream));
     KKT_HIP(hipStreamSynchronize(stream));

@@ -192,6 +192,17 @@ class Evaluator:
                                          float(dc), C.byref(info)), "emi_kkt_factor")
         return info.value
 
+    def kkt_lowrank(self, node, vec, delta):
+        """K = K~ - sum delta_c u_c u_c^T; returns True iff K has the inertia of K~ (solves are then with K)."""
+        node = np.ascontiguousarray(node, dtype=np.int32)
+        vec = np.ascontiguousarray(vec, dtype=np.float64)
+        delta = np.ascontiguousarray(delta, dtype=np.float64)
+        exact = C.c_int(0)
+        r = node.size
+        self._ck(self.lib.emi_kkt_lowrank(self.ctx, r, node.ctypes.data_as(C.POINTER(C.c_int)) if r else None,
+                                          _dp(vec) if r else None, _dp(delta) if r else None, C.byref(exact)), "emi_kkt_lowrank")
+        return bool(exact.value)
+
     def kkt_solve(self, rhs):
         """rhs: [N] or [nrhs][N]; returns the solution(s) in the same shape."""
         rhs = np.ascontiguousarray(rhs, dtype=np.float64).copy()

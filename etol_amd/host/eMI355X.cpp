@@ -108,6 +108,12 @@ struct eMI355X::Device : public mi355x::NlpEvaluator, public mi355x::KktBackend 
         const int st = emi_kkt_factor(ctx, Qblk, Jblk, fixed, dc, &info);
         return st == EMI_OK ? info : -1;
     }
+    int lowrank(int r, const int* node, const double* vec, const double* delta, bool* exact) override {
+        int ex = 0;
+        const int st = emi_kkt_lowrank(ctx, r, node, vec, delta, &ex);
+        *exact = ex != 0;
+        return st == EMI_OK ? 0 : -1;
+    }
     int solve(double* rhs, int nrhs) override { return emi_kkt_solve(ctx, rhs, nrhs) == EMI_OK ? 0 : -1; }
     std::string last_error() const override { return ctx ? emi_last_error(ctx) : "no device context"; }
 };

@@ -285,6 +285,7 @@ class DenseHostKkt : public KktBackend {
     int factor(const double* Qblk, const double* Jblk, const unsigned char* fx, double dc) override {
         const int M = _P.M, ns = _P.ns, nv = ns + _P.nc, nz = nv * M, N = nz + ns * M;
         _F.n = N;
+        _r = 0;
         _F.a.assign((size_t)N * N, 0.0);
         _fixed.assign(fx, fx + nz);
         double* a = _F.a.data();
@@ -306,13 +307,84 @@ class DenseHostKkt : public KktBackend {
         _ok = ldlt_factor(_F) && _F.nzero == 0;
         return _ok ? 0 : 1;
     }
+    int lowrank(int r, const int* node, const double* vec, const double* delta, bool* exact) override {
+        _r = 0;
+        *exact = r == 0;
+        if (r == 0) return 0;
+        if (!_ok) return -1;
+        const int M = _P.M, nv = _P.ns + _P.nc, N = _F.n;
+        _node.assign(node, node + r);
+        _vec.assign(vec, vec + (size_t)r * nv);
+        _Y.assign((size_t)N * r, 0.0);
+        for (int c = 0; c < r; ++c) {
+            double* y = &_Y[(size_t)c * N];
+            for (int v = 0; v < nv; ++v) y[v * M + node[c]] = vec[(size_t)c * nv + v];
+            for (size_t q = 0; q < _fixed.size(); ++q)
+                if (_fixed[q]) y[q] = 0.0;
+            ldlt_solve(_F, y);
+        }
+        // C = Delta^-1 - U^T Y, row-major lower triangle; right-looking Cholesky
+        _C.assign((size_t)r * r, 0.0);
+        for (int c = 0; c < r; ++c) {
+            const double* y = &_Y[(size_t)c * N];
+            for (int a = c; a < r; ++a) {
+                double dot = 0;
+                for (int v = 0; v < nv; ++v) dot += vec[(size_t)a * nv + v] * y[v * M + node[a]];
+                _C[(size_t)a * r + c] = -dot;
+            }
+            _C[(size_t)c * r + c] += 1.0 / delta[c];
+        }
+        std::vector<double> colj(r);
+        for (int j = 0; j < r; ++j) {
+            const double djj = _C[(size_t)j * r + j];
+            if (!(djj > 1e-14 * (1.0 / delta[j]))) return 0;          // not positive definite: K~ answers stay
+            const double ljj = std::sqrt(djj);
+            _C[(size_t)j * r + j] = ljj;
+            for (int i = j + 1; i < r; ++i) {
+                _C[(size_t)i * r + j] /= ljj;
+                colj[i] = _C[(size_t)i * r + j];
+            }
+            for (int i = j + 1; i < r; ++i) {
+                const double lij = colj[i];
+                double* row = &_C[(size_t)i * r];
+                for (int t = j + 1; t <= i; ++t) row[t] -= lij * colj[t];
+            }
+        }
+        _r = r;
+        *exact = true;
+        return 0;
+    }
     int solve(double* rhs, int nrhs) override {
         if (!_ok) return -1;
+        const int M = _P.M, nv = _P.ns + _P.nc, N = _F.n;
+        std::vector<double> t(_r);
         for (int c = 0; c < nrhs; ++c) {
-            double* b = rhs + (size_t)c * _F.n;
+            double* b = rhs + (size_t)c * N;
             for (size_t q = 0; q < _fixed.size(); ++q)
                 if (_fixed[q]) b[q] = 0.0;
             ldlt_solve(_F, b);
+            if (_r == 0) continue;
+            // b <- b + Y C^-1 (U^T b)
+            for (int a = 0; a < _r; ++a) {
+                double dot = 0;
+                for (int v = 0; v < nv; ++v) dot += _vec[(size_t)a * nv + v] * b[v * M + _node[a]];
+                t[a] = dot;
+            }
+            for (int i = 0; i < _r; ++i) {
+                double sum = t[i];
+                for (int q = 0; q < i; ++q) sum -= _C[(size_t)i * _r + q] * t[q];
+                t[i] = sum / _C[(size_t)i * _r + i];
+            }
+            for (int i = _r - 1; i >= 0; --i) {
+                double sum = t[i];
+                for (int q = i + 1; q < _r; ++q) sum -= _C[(size_t)q * _r + i] * t[q];
+                t[i] = sum / _C[(size_t)i * _r + i];
+            }
+            for (int a = 0; a < _r; ++a) {
+                const double* y = &_Y[(size_t)a * N];
+                const double ta = t[a];
+                for (int q = 0; q < N; ++q) b[q] += ta * y[q];
+            }
         }
         return 0;
     }
@@ -323,6 +395,9 @@ class DenseHostKkt : public KktBackend {
     LdltFactor _F;
     std::vector<unsigned char> _fixed;
     bool _ok = false;
+    int _r = 0;                       // active low-rank correction (0: none)
+    std::vector<int> _node;
+    std::vector<double> _vec, _Y, _C;
 };
 
 }  // namespace
@@ -338,6 +413,10 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         return R;
     }
     const auto tstart = std::chrono::steady_clock::now();
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double>(b - a).count();
+    };
 
     // free-variable map
     std::vector<int> fidx(nz, -1);
@@ -383,9 +462,10 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     E.H.resize((size_t)nh * M);
     auto evaluate = [&](const std::vector<double>& z, Eval& e, bool jac) -> bool {
         ++R.evaluations;
-        if (P.ev->eval(z.data(), z.data() + (size_t)ns * M, e.RES.data(), jac ? e.VALS.data() : nullptr, &e.cost,
-                       jac) != 0)
-            return false;
+        const auto te = now();
+        const int est = P.ev->eval(z.data(), z.data() + (size_t)ns * M, e.RES.data(), jac ? e.VALS.data() : nullptr, &e.cost, jac);
+        R.t_eval += secs(te, now());
+        if (est != 0) return false;
         for (int j = 0; j < np; ++j) {
             if (sig[j] == 1.0) continue;
             for (int k = 0; k < M; ++k) {
@@ -539,7 +619,6 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
 
     // ---- pieces of one Newton step, shared by the regular step and the second-order correction ----
     const size_t NN = (size_t)nz + md;
-    std::vector<double> Cm;             // Cholesky factor of the r x r Woodbury matrix C (see below)
     int r_mod = 0;
     // r_t of the eliminated path rows for given row residuals  c - s - e1 + e2
     auto fill_rt = [&](const std::vector<double>& rowres) {
@@ -568,31 +647,8 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             }
         for (int r = 0; r < md; ++r) out[nz + r] = -defres[r];
     };
-    // y <- y + Y C^-1 (U^T y): turns a solve with the modified matrix K~ into one with the exact K
-    std::vector<double> tvec, soc_def(md), soc_row(mc), soc_rhs(NN);
-    auto woodbury = [&](double* y0) {
-        tvec.assign(r_mod, 0.0);
-        for (int a = 0; a < r_mod; ++a) {
-            double dot = 0;
-            for (int v = 0; v < nv; ++v) dot += mods[a].v[v] * y0[v * M + mods[a].node];
-            tvec[a] = dot;
-        }
-        for (int i = 0; i < r_mod; ++i) {
-            double sum = tvec[i];
-            for (int t = 0; t < i; ++t) sum -= Cm[(size_t)i * r_mod + t] * tvec[t];
-            tvec[i] = sum / Cm[(size_t)i * r_mod + i];
-        }
-        for (int i = r_mod - 1; i >= 0; --i) {
-            double sum = tvec[i];
-            for (int t = i + 1; t < r_mod; ++t) sum -= Cm[(size_t)t * r_mod + i] * tvec[t];
-            tvec[i] = sum / Cm[(size_t)i * r_mod + i];
-        }
-        for (int c = 0; c < r_mod; ++c) {
-            const double* y = &rhs_full[NN * (1 + c)];
-            const double tc = tvec[c];
-            for (size_t r = 0; r < NN; ++r) y0[r] += tc * y[r];
-        }
-    };
+    std::vector<double> soc_def(md), soc_row(mc), soc_rhs(NN), lr_vec, lr_delta;
+    std::vector<int> lr_node;
     // y = [[Q, J^T], [J, -dc I]] x  with the node blocks Qb (fixed variables: identity rows/columns)
     auto kkt_matvec = [&](const double* Qb, const double* x, double* y, double dcv) {
         const double* V = E.VALS.data();
@@ -738,7 +794,8 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             // (both Schur complements of [[K~, U], [U^T, Delta^-1]]).  So r extra solves with the same
             // factors decide EXACTLY whether the unmodified K has the right inertia; if it has, the
             // Woodbury identity turns the solve with K~ into the exact Newton step (quadratic
-            // convergence is kept); if not, the step of K~ is the inertia-corrected one.
+            // convergence is kept); if not, the step of K~ is the inertia-corrected one.  Y = K~^-1 U and
+            // the factor of C live with the backend (KktBackend::lowrank): on the device for eMI355X.
             const double* V = E.VALS.data();
             std::copy(E.H.begin(), E.H.end(), Qblk.begin());
             for (int v = 0; v < nv; ++v)
@@ -767,53 +824,41 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             }
             Qexact = Qblk;
             dw = convexify_node_blocks(Qblk.data(), fixed_mask.data(), nv, M, &mods);
+            const auto tf0 = now();
             const int info = kkt->factor(Qblk.data(), V, fixed_mask.data(), dc);
+            R.t_factor += secs(tf0, now());
             if (info < 0) { R.msg = "KKT factorisation failed: " + kkt->last_error(); return R; }
             if (info > 0) {   // exactly singular: the defect Jacobian lost rank; regularise the dual block
                 dc = dc == 0.0 ? 1e-8 * std::pow(mu, 0.25) : dc * 100.0;
                 continue;
             }
-            // right-hand sides: column 0 the Newton system, then one column per modified eigenpair
+            // the low-rank correction (kept by the backend, next to its factors) and the inertia verdict
             r_mod = (int)mods.size() <= max_lowrank ? (int)mods.size() : 0;
-            rhs_full.assign(NN * (1 + r_mod), 0.0);
+            lr_node.resize(r_mod);
+            lr_delta.resize(r_mod);
+            lr_vec.resize((size_t)r_mod * nv);
+            for (int c = 0; c < r_mod; ++c) {
+                lr_node[c] = mods[c].node;
+                lr_delta[c] = mods[c].delta;
+                for (int v = 0; v < nv; ++v) lr_vec[(size_t)c * nv + v] = mods[c].v[v];
+            }
+            const auto tl0 = now();
+            bool lr_exact = false;
+            if (kkt->lowrank(r_mod, lr_node.data(), lr_vec.data(), lr_delta.data(), &lr_exact) != 0) {
+                R.msg = "KKT low-rank correction failed: " + kkt->last_error();
+                return R;
+            }
+            R.t_lowrank += secs(tl0, now());
+            exact_step = lr_exact && r_mod == (int)mods.size();
             build_rhs(rhs_full.data(), E.RES.data());
             std::copy(rhs_full.begin(), rhs_full.begin() + NN, rhs_keep.begin());
-            for (int c = 0; c < r_mod; ++c)
-                for (int v = 0; v < nv; ++v) rhs_full[NN * (1 + c) + v * M + mods[c].node] = mods[c].v[v];
-            if (kkt->solve(rhs_full.data(), 1 + r_mod) != 0) { R.msg = "KKT solve failed: " + kkt->last_error(); return R; }
+            const auto ts0 = now();
+            const int sst = kkt->solve(rhs_full.data(), 1);
+            R.t_solve += secs(ts0, now());
+            if (sst != 0) { R.msg = "KKT solve failed: " + kkt->last_error(); return R; }
             bool finite = true;
             for (size_t r = 0; r < NN && finite; ++r) finite = std::isfinite(rhs_full[r]);
             if (!finite) { dc = dc == 0.0 ? 1e-8 * std::pow(mu, 0.25) : dc * 100.0; continue; }
-            exact_step = mods.empty();
-            if (r_mod > 0) {
-                // C = Delta^-1 - U^T Y,  Y = K~^-1 U  (columns 1.. of rhs_full);  Cholesky <=> right inertia
-                Cm.assign((size_t)r_mod * r_mod, 0.0);
-                for (int a = 0; a < r_mod; ++a) {
-                    for (int c = 0; c <= a; ++c) {
-                        double dot = 0;
-                        const double* y = &rhs_full[NN * (1 + c)];
-                        for (int v = 0; v < nv; ++v) dot += mods[a].v[v] * y[v * M + mods[a].node];
-                        Cm[(size_t)a * r_mod + c] = -dot;
-                    }
-                    Cm[(size_t)a * r_mod + a] += 1.0 / mods[a].delta;
-                }
-                bool pd = true;
-                for (int i = 0; i < r_mod && pd; ++i)
-                    for (int j = 0; j <= i; ++j) {
-                        double sum = Cm[(size_t)i * r_mod + j];
-                        for (int t = 0; t < j; ++t) sum -= Cm[(size_t)i * r_mod + t] * Cm[(size_t)j * r_mod + t];
-                        if (i == j) {
-                            if (!(sum > 1e-14 * (1.0 / mods[i].delta))) { pd = false; break; }
-                            Cm[(size_t)i * r_mod + i] = std::sqrt(sum);
-                        } else {
-                            Cm[(size_t)i * r_mod + j] = sum / Cm[(size_t)j * r_mod + j];
-                        }
-                    }
-                if (pd) {
-                    exact_step = true;
-                    woodbury(rhs_full.data());      // x = y0 + Y C^-1 (U^T y0)
-                }
-            }
             // iterative refinement against the matrix the step belongs to (K if exact, K~ otherwise): the
             // factorisation of a 1000-node KKT matrix leaves residuals that would stall the Newton
             // iteration some orders above the requested tolerance
@@ -829,7 +874,6 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                     if (!(rmax > 1e-14 * std::max(1.0, bmax)) || !(rmax < 0.5 * prev)) break;
                     prev = rmax;
                     if (kkt->solve(resid.data(), 1) != 0) break;
-                    if (exact_step && r_mod > 0) woodbury(resid.data());
                     bool fin = true;
                     for (size_t r = 0; r < NN && fin; ++r) fin = std::isfinite(resid[r]);
                     if (!fin) break;
@@ -951,7 +995,6 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                         fill_rt(soc_row);
                         build_rhs(soc_rhs.data(), soc_def.data());
                         if (kkt->solve(soc_rhs.data(), 1) != 0) break;
-                        if (exact_step && r_mod > 0) woodbury(soc_rhs.data());
                         bool fin = true;
                         for (size_t r = 0; r < NN && fin; ++r) fin = std::isfinite(soc_rhs[r]);
                         if (!fin) break;
@@ -1027,6 +1070,10 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     }
     R.cost = E.cost;
     R.rho = rho;
+    R.t_total = secs(tstart, now());
+    if (opt.print_level >= 5)
+        printf("time: total %.2f s = evaluator %.2f + KKT factor %.2f + KKT solves %.2f + low-rank/refinement (host) %.2f + rest\n",
+               R.t_total, R.t_eval, R.t_factor, R.t_solve, R.t_lowrank);
     R.z = it.z;
     R.lamF = it.lam;
     R.lamC.resize(mc);

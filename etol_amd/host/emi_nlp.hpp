@@ -44,6 +44,10 @@ class KktBackend {
     virtual ~KktBackend() {}
     // 0: factorised; > 0: singular; < 0: failure (see last_error)
     virtual int factor(const double* Qblk, const double* Jblk, const unsigned char* fixed, double dc) = 0;
+    // K = K~ - sum_c delta[c] u_c u_c^T with u_c = vec[c*nv .. ) on the variables of node[c] (what the caller
+    // added to the Q blocks).  *exact = true iff K has the inertia of K~; solve() then answers for K (Woodbury
+    // correction kept by the backend), otherwise for K~.  r = 0 clears.  0 on success.
+    virtual int lowrank(int r, const int* node, const double* vec, const double* delta, bool* exact) = 0;
     virtual int solve(double* rhs, int nrhs) = 0;   // rhs [nrhs][nz+md], in place; 0 on success
     virtual std::string last_error() const { return std::string(); }
 };
@@ -80,6 +84,7 @@ struct NlpResult {
     double cost = 0, kkt_error = 0, constr_viol = 0;
     std::vector<double> z;              // (ns+nc)*M solution
     std::vector<double> lamF, lamC;     // multipliers of the defect and path rows
+    double t_eval = 0, t_factor = 0, t_solve = 0, t_lowrank = 0, t_total = 0;   // seconds: evaluator, KKT factor, KKT solves, host low-rank algebra
     double rho = 0;                     // penalty weight the solve ended with (warm start of the next mesh)
 };
 

@@ -189,6 +189,14 @@ int emi_get_layout(emi_ctx_t ctx, emi_layout_t* out);
  * known, and recovers the exact matrix by a low-rank update (emi_nlp.cpp).  */
 int emi_kkt_factor(emi_ctx_t ctx, const double* Qblk, const double* Jblk,
                    const unsigned char* fixed, double dc, int* info);
+/* Low-rank correction of the factorised matrix: K = K~ - sum_c delta_c u_c u_c^T,
+ * u_c = vec[c][0..nv) placed on the variables of node[c] (what the caller added
+ * to make the Q blocks positive definite).  K~^-1 U and the Cholesky factor of
+ * C = Delta^-1 - U^T K~^-1 U stay on the device.  *exact = 1 iff C is positive
+ * definite, i.e. iff K has the inertia of K~; emi_kkt_solve then returns
+ * solutions of K (Woodbury), else of K~.  r = 0 clears the correction.       */
+int emi_kkt_lowrank(emi_ctx_t ctx, int r, const int* node, const double* vec,
+                    const double* delta, int* exact);
 /* rhs [nrhs][N] (one right-hand side after the other) in, solutions out;
  * may be called repeatedly after one factor.                               */
 int emi_kkt_solve(emi_ctx_t ctx, double* rhs, int nrhs);

@@ -131,10 +131,35 @@ struct HostKkt : public mx::KktBackend {
             for (int r = 0; r < N; ++r) put(r, q, 0.0);
             put(q, q, 1.0);
         }
+        A0 = F.a;                 // K~ before the factorisation overwrites it
+        use_exact = false;
         ok = mx::ldlt_factor(F) && F.nzero == 0;
         inertia_ok = ok && F.npos == nz && F.nneg == ns * M;
         if (ok && !inertia_ok) ++wrong_inertia;   // must never happen: Q is convexified by the caller
         return ok ? 0 : 1;
+    }
+    // Independent of the Woodbury route the product takes: build K = K~ - U Delta U^T densely, factorise it and
+    // COUNT its inertia; the verdict must be what the r x r Cholesky test of the product says.
+    int lowrank(int r, const int* node, const double* vec, const double* delta, bool* exact) override {
+        use_exact = false;
+        *exact = r == 0;
+        if (r == 0) return 0;
+        const int M = (int)P->nodes, ns = (int)P->nstates, nv = ns + (int)P->ncontrols, nz = nv * M, N = F.n;
+        F2.n = N;
+        F2.a = A0;
+        for (int c = 0; c < r; ++c)
+            for (int v = 0; v < nv; ++v)
+                for (int q = 0; q <= v; ++q) {
+                    const int rr = v * M + node[c], cc = q * M + node[c];
+                    if (fixed[rr] || fixed[cc]) continue;
+                    F2.a[(size_t)rr * N + cc] -= delta[c] * vec[(size_t)c * nv + v] * vec[(size_t)c * nv + q];
+                }
+        const bool ok2 = mx::ldlt_factor(F2) && F2.nzero == 0;
+        use_exact = ok2 && F2.npos == nz && F2.nneg == ns * M;
+        *exact = use_exact;
+        ++lowrank_calls;
+        if (use_exact) ++lowrank_exact;
+        return 0;
     }
     int solve(double* rhs, int nrhs) override {
         if (!ok) return -1;
@@ -142,10 +167,14 @@ struct HostKkt : public mx::KktBackend {
             double* b = rhs + (size_t)c * F.n;
             for (size_t q = 0; q < fixed.size(); ++q)
                 if (fixed[q]) b[q] = 0.0;
-            mx::ldlt_solve(F, b);
+            mx::ldlt_solve(use_exact ? F2 : F, b);
         }
         return 0;
     }
+    mx::LdltFactor F2;
+    std::vector<double> A0;
+    bool use_exact = false;
+    int lowrank_calls = 0, lowrank_exact = 0;
     bool inertia_ok = false;
     int wrong_inertia = 0;
 };

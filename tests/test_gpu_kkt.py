@@ -31,8 +31,9 @@ def dense_kkt(D, Qblk, Jblk, fixed, dc, M, ns, nv):
     return K
 
 
-@pytest.mark.parametrize("M,model", [(9, 0), (33, 1), (64, 1)])
-def test_kkt_factor_solve_matches_numpy(built, M, model):
+@pytest.mark.parametrize("method", [1, 0])       # 1: Schur complement + Cholesky, 0: LU of the full matrix
+@pytest.mark.parametrize("M,model", [(9, 0), (33, 1), (64, 1), (200, 1)])
+def test_kkt_factor_solve_matches_numpy(built, M, model, method):
     import etol_amd as E
     from etol_amd import workloads as W
     ns, nc, _ = E.model_dims(model)
@@ -41,6 +42,7 @@ def test_kkt_factor_solve_matches_numpy(built, M, model):
     ev.set_mesh(M, 0.0, 4.0)
     ev.set_model(model, W.QUAD_PARAMS if model == 1 else [])
     ev.set_batch(1)
+    ev.set_option("kkt_method", method)
     rng = np.random.default_rng(M)
     # SPD node blocks (as after inertia correction), arbitrary Jacobian node entries
     Qblk = np.zeros((nh, M))
@@ -78,6 +80,36 @@ def test_kkt_factor_solve_matches_numpy(built, M, model):
         assert np.abs(sol - ref).max() < 1e-7 * (np.abs(ref).max() + 1)
 
 
+def test_schur_method_falls_back_to_lu_for_indefinite_blocks(built):
+    """Method 1 needs positive definite node blocks; anything else must silently take the general LU."""
+    import etol_amd as E
+    from etol_amd import workloads as W
+    M, ns, nv, nh = 17, 6, 8, 36
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 2.0)
+    ev.set_model(1, W.QUAD_PARAMS)
+    ev.set_batch(1)
+    rng = np.random.default_rng(3)
+    Qblk = np.zeros((nh, M))
+    for k in range(M):
+        A = rng.standard_normal((nv, nv))
+        Qk = A + A.T                                  # indefinite
+        for v in range(nv):
+            for q in range(v + 1):
+                Qblk[v * (v + 1) // 2 + q, k] = Qk[v, q]
+    Jblk = rng.standard_normal((ns * nv, M))
+    for i in range(ns):
+        Jblk[i * nv + i] += np.diag(ev.D)
+    fixed = np.zeros(nv * M, dtype=np.uint8)
+    fixed[np.arange(ns) * M] = 1
+    assert ev.kkt_factor(Qblk, Jblk, fixed, 1e-9) == 0
+    K = dense_kkt(ev.D, Qblk, Jblk, fixed, 1e-9, M, ns, nv)
+    rhs = rng.standard_normal((nv + ns) * M)
+    sol = ev.kkt_solve(rhs)
+    rhs[np.nonzero(fixed)[0]] = 0
+    assert np.abs(K @ sol - rhs).max() < 1e-9 * (np.abs(K).max() * np.abs(sol).max() + 1)
+
+
 def test_kkt_reports_singular_matrix_and_state_errors(built):
     import etol_amd as E
     from etol_amd import _lib
@@ -92,3 +124,57 @@ def test_kkt_reports_singular_matrix_and_state_errors(built):
     assert info > 0
     with pytest.raises(_lib.EmiError):
         ev.kkt_solve(np.zeros(6 * 5))
+
+
+@pytest.mark.parametrize("method", [1, 0])
+def test_lowrank_correction_gives_exact_solves_and_the_inertia_verdict(built, method):
+    """K = K~ - U Delta U^T: after emi_kkt_lowrank the solves answer for K, and `exact` says whether K has
+    the inertia of K~ (checked against numpy eigenvalues)."""
+    import etol_amd as E
+    from etol_amd import workloads as W
+    M, ns, nv, nh = 24, 6, 8, 36
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 3.0)
+    ev.set_model(1, W.QUAD_PARAMS)
+    ev.set_batch(1)
+    ev.set_option("kkt_method", method)
+    rng = np.random.default_rng(7)
+    fixed = np.zeros(nv * M, dtype=np.uint8)
+    fixed[np.arange(ns) * M] = 1
+    Jblk = rng.standard_normal((ns * nv, M))
+    for i in range(ns):
+        Jblk[i * nv + i] += np.diag(ev.D)
+    for scale, expect in ((0.05, True), (50.0, False)):
+        # Q~ positive definite blocks; the "true" Q differs by reflected eigen-directions at some nodes
+        Qt = np.zeros((nh, M))
+        node, vec, delta = [], [], []
+        for k in range(M):
+            A = rng.standard_normal((nv, nv))
+            Qk = A @ A.T + nv * np.eye(nv)
+            for v in range(nv):
+                for q in range(v + 1):
+                    Qt[v * (v + 1) // 2 + q, k] = Qk[v, q]
+            if k % 3 == 1:
+                u = rng.standard_normal(nv)
+                u[fixed[np.arange(nv) * M + k] != 0] = 0
+                node.append(k); vec.append(u); delta.append(scale * (1 + rng.random()))
+        assert ev.kkt_factor(Qt, Jblk, fixed, 1e-9) == 0
+        Kt = dense_kkt(ev.D, Qt, Jblk, fixed, 1e-9, M, ns, nv)
+        K = Kt.copy()
+        for k, u, d in zip(node, vec, delta):
+            idx = np.arange(nv) * M + k
+            K[np.ix_(idx, idx)] -= d * np.outer(u, u)
+        eig = np.linalg.eigvalsh(K)
+        true_ok = (eig > 0).sum() == nv * M and (eig < 0).sum() == ns * M
+        assert true_ok == expect                      # the two scales were chosen to land on either side
+        exact = ev.kkt_lowrank(node, np.array(vec), delta)
+        assert exact == true_ok
+        rhs = rng.standard_normal((nv + ns) * M)
+        sol = ev.kkt_solve(rhs)
+        b = rhs.copy()
+        b[np.nonzero(fixed)[0]] = 0
+        Kref = K if exact else Kt
+        assert np.abs(Kref @ sol - b).max() < 1e-9 * (np.abs(Kref).max() * np.abs(sol).max() + 1)
+        assert ev.kkt_lowrank([], np.zeros((0, nv)), []) is True     # cleared: back to K~
+        sol2 = ev.kkt_solve(rhs)
+        assert np.abs(Kt @ sol2 - b).max() < 1e-9 * (np.abs(Kt).max() * np.abs(sol2).max() + 1)
