@@ -501,7 +501,7 @@ void eMI355X::solve() {
         const bool dev_kkt = _algorithm.linear_solver == "device" ||
                              (_algorithm.linear_solver == "auto" && kkt_rows > 1200);
         nlp.kkt = dev_kkt ? static_cast<mi355x::KktBackend*>(_dev.get()) : nullptr;
-        _solution.linear_solver = dev_kkt ? "device: KKT assembly + LU (rocSOLVER), Woodbury-corrected" : "host LDL^T";
+        _solution.linear_solver = dev_kkt ? "device: structured KKT factorisation (Schur complement + Cholesky), Woodbury-corrected" : "host LDL^T";
         r = mi355x::solve_nlp(nlp, o, mi355x::initial_guess(P));
         _solution.nlp_iterations_total += r.iterations;
     };

@@ -172,8 +172,8 @@ def _set_linear_solver(H, name):
 
 
 def test_device_newton_step_gives_the_host_solution(H, xmls):
-    """Same NLP iteration, Newton step once through the host LDL^T (inertia) and once through the
-    device KKT assembly + LU with the curvature test: same solutions."""
+    """Same NLP iteration, Newton step once through the dense host backend and once through the device
+    backend (Schur complement + Cholesky, low-rank correction on the device): same solutions."""
     try:
         _set_linear_solver(H, "host")
         h1 = solve(H, xmls["ocp_2d_ex1.xml"], 1)
