@@ -183,10 +183,12 @@ int emi_get_layout(emi_ctx_t ctx, emi_layout_t* out);
  *                       on it (the defect entries of VALS, which hold D_kk)
  * Unknown order: variables v*M+k, then defect multipliers i*M+k.  fixed
  * [(ns+nc)*M]: 1 = the variable does not move (identity row/column, rhs 0).
- * Host pointers.  *info = 0 factorised, > 0 a pivot was exactly zero.
- * The factorisation is an LU and reports no inertia: the caller passes a
- * quasi-definite matrix (every Q block positive definite), whose inertia is
- * known, and recovers the exact matrix by a low-rank update (emi_nlp.cpp).  */
+ * Host pointers.  *info = 0 factorised, > 0 singular.
+ * Option "kkt_method" (emi_set_option): 1 (default) factorises the Schur
+ * complement J Q^-1 J^T + dc I with a Cholesky -- valid when every Q block is
+ * positive definite, which also fixes the inertia of K by construction; a
+ * matrix that is not takes method 0 automatically: K assembled in HBM and
+ * LU-factorised.  Neither reports an inertia; see emi_kkt_lowrank.           */
 int emi_kkt_factor(emi_ctx_t ctx, const double* Qblk, const double* Jblk,
                    const unsigned char* fixed, double dc, int* info);
 /* Low-rank correction of the factorised matrix: K = K~ - sum_c delta_c u_c u_c^T,
