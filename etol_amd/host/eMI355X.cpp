@@ -499,7 +499,7 @@ void eMI355X::solve() {
         // Newton-step linear algebra: small KKT systems on the host, the rest on the device
         const size_t kkt_rows = (2 * ns + nc) * P.nodes;
         const bool dev_kkt = _algorithm.linear_solver == "device" ||
-                             (_algorithm.linear_solver == "auto" && kkt_rows > 1200);
+                             (_algorithm.linear_solver == "auto" && kkt_rows > 400);
         nlp.kkt = dev_kkt ? static_cast<mi355x::KktBackend*>(_dev.get()) : nullptr;
         _solution.linear_solver = dev_kkt ? "device: structured KKT factorisation (Schur complement + Cholesky), Woodbury-corrected" : "host LDL^T";
         r = mi355x::solve_nlp(nlp, o, mi355x::initial_guess(P));

@@ -34,7 +34,7 @@ struct Alg {
     int mr_max_nodes = 513;                        // refinement stops adding nodes here
     bool mesh_sequencing = true;                   // meshes above 80 nodes are reached through 33, 65, 129, ... nodes
     std::string linear_solver = "auto";            // Newton step: "host" (dense LDL^T), "device" (structured
-                                                   // factorisation in HBM, emi_kkt_*), "auto" = device above 1200 KKT rows
+                                                   // factorisation in HBM, emi_kkt_*), "auto" = device above 400 KKT rows
     int nlp_iter_max = 200;
     double nlp_tolerance = 1.e-6;
     double max_cpu_time = 1.e9;

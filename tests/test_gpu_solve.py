@@ -191,7 +191,7 @@ def test_device_newton_step_gives_the_host_solution(H, xmls):
 
 def test_quadrotor_256_nodes_end_to_end_on_the_device(H):
     """Config-2 mesh (256 LGL nodes, 6 states): evaluation, derivatives AND the Newton step on the GPU
-    ("auto" picks the device above 1200 KKT rows: here 3584).  Feasibility by the CPU oracle."""
+    ("auto" picks the device above 400 KKT rows: here 3584).  Feasibility by the CPU oracle."""
     import time
     t0 = time.time()
     cost, X, U, iters, mesh_iters, _ = _solve_quadrotor_cap(H, 255, 4.0 / 255, 2, cap=300)
