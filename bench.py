@@ -123,7 +123,7 @@ def main():
     ev.set_batch(B)
     if os.environ.get("EMI_OVERLAP", "1") == "0":
         ev.set_option("overlap", 0)        # A/B switch: sequential general path
-    for opt in ("sym_ct", "overlap_mode", "sym_order", "sym_ablate"):          # experiment knobs of the overlapped path
+    for opt in ("sym_ct", "overlap_mode", "sym_order", "sym_ablate", "cu_split"):          # experiment knobs of the overlapped path
         if os.environ.get("EMI_" + opt.upper()):
             ev.set_option(opt, int(os.environ["EMI_" + opt.upper()]))
     X, U, recs = W.quadrotor_batch(3, B, M, n_obs, first_instance=rank * B)   # scenario s -> rank s // B

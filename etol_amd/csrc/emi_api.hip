@@ -38,7 +38,10 @@ struct emi_ctx_s {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t stream2 = nullptr;          // the node kernel runs here while the MFMA defect kernel runs on `stream`
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    // "cu_split" option: the two kernels of the overlapped pass on disjoint CU sets (CU-masked streams)
+    int cu_split = 0;                       // CUs given to the MFMA defect kernel; 0 = both kernels share every CU
+    hipStream_t s_mfma = nullptr, s_node = nullptr;
     std::string err;
 
     // mesh
@@ -252,6 +255,9 @@ int emi_destroy(emi_ctx_t c) {
         for (int i = 0; i < 4; ++i) (void)hipEventDestroy(pe.k[i]);
     }
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->s_mfma) { (void)hipStreamSynchronize(c->s_mfma); (void)hipStreamDestroy(c->s_mfma); }
+    if (c->s_node) { (void)hipStreamSynchronize(c->s_node); (void)hipStreamDestroy(c->s_node); }
+    if (c->ev_join2) (void)hipEventDestroy(c->ev_join2);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->t_start) (void)hipEventDestroy(c->t_start);
@@ -572,21 +578,24 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         emi::NodeArgs<double> na;
         fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
         const bool two = c->overlap_mode == 2;
-        hipStream_t s2 = two ? c->stream2 : c->stream;
+        const bool split = two && c->cu_split > 0;
+        hipStream_t s1 = split ? c->s_mfma : c->stream;
+        hipStream_t s2 = split ? c->s_node : (two ? c->stream2 : c->stream);
         const unsigned bit = 1u << c->sym_ct;
         if (two) {
             HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
+            if (split) HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_fork, 0));
         }
-        if (pe) HIP_TRY(c, hipEventRecord(pe->k[0], c->stream));
+        if (pe) HIP_TRY(c, hipEventRecord(pe->k[0], s1));
         if (c->rtc) {
-            HIP_TRY(c, emi::rtc_launch_symdefect(c->rtc, sa, c->stream));
+            HIP_TRY(c, emi::rtc_launch_symdefect(c->rtc, sa, s1));
         } else {
-            HIP_TRY(c, emi::launch_symdefect(c->model, sa, c->stream, !(c->fused_attr_mask & bit), c->sym_ct));
+            HIP_TRY(c, emi::launch_symdefect(c->model, sa, s1, !(c->fused_attr_mask & bit), c->sym_ct));
             c->fused_attr_mask |= bit;
         }
         if (pe) {
-            HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
+            HIP_TRY(c, hipEventRecord(pe->k[1], s1));
             HIP_TRY(c, hipEventRecord(pe->k[2], s2));
         }
         if (c->rtc) HIP_TRY(c, emi::rtc_launch_nodes<double>(c->rtc, na, jac, false, s2));
@@ -595,8 +604,12 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         HIP_TRY(c, emi::launch_cost_finish<double>(na.cost_part, na.cost, c->B, emi::node_chunks(c->M),
                                                    na.sgn * na.h, s2));
         if (two) {
-            HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+            HIP_TRY(c, hipEventRecord(c->ev_join, s2));
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+            if (split) {
+                HIP_TRY(c, hipEventRecord(c->ev_join2, s1));
+                HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
+            }
         }
         if (pe) {
             HIP_TRY(c, hipEventRecord(pe->e[1], c->stream));
@@ -821,6 +834,26 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
     if (strcmp(name, "sym_ct") == 0) {
         if (value < 1 || value > 3) return fail(c, EMI_ERR_ARG, "sym_ct must be 1, 2 or 3 (3 = LDS-DMA ring)");
         c->sym_ct = value;
+        return EMI_OK;
+    }
+    if (strcmp(name, "cu_split") == 0) {
+        // experiment: spatial instead of temporal sharing of the chip between the MFMA and the streaming kernel
+        hipDeviceProp_t prop;
+        HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+        const int ncu = prop.multiProcessorCount;
+        if (value < 0 || value >= ncu) return fail(c, EMI_ERR_ARG, "cu_split must be in [0, %d)", ncu);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->s_mfma) { HIP_TRY(c, hipStreamDestroy(c->s_mfma)); c->s_mfma = nullptr; }
+        if (c->s_node) { HIP_TRY(c, hipStreamDestroy(c->s_node)); c->s_node = nullptr; }
+        c->cu_split = value;
+        if (value > 0) {
+            const int words = (ncu + 31) / 32;
+            std::vector<uint32_t> m1(words, 0u), m2(words, 0u);
+            for (int i = 0; i < ncu; ++i) (i < value ? m1 : m2)[i / 32] |= 1u << (i % 32);
+            HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->s_mfma, words, m1.data()));
+            HIP_TRY(c, hipExtStreamCreateWithCUMask(&c->s_node, words, m2.data()));
+            if (!c->ev_join2) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming));
+        }
         return EMI_OK;
     }
     if (strcmp(name, "kkt_method") == 0) {
