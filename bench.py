@@ -49,8 +49,9 @@ def usable_cores():
 
 
 def cpu_baseline(M, n_obs, budget_s=10.0):
-    """ePSOPT-style CPU port (oracle/epsopt_style.cpp) on a bounded sample of the same workload,
-    all host cores via OpenMP over instances.  Checker/baseline only, never the product path."""
+    """ePSOPT-style CPU port (oracle/epsopt_style.cpp) on a bounded sample of the same workload: all host
+    cores via OpenMP over instances (the reported value), the same port on one thread, and the plain-C
+    checker oracle (oracle/emi_oracle.c, one thread) for reference.  Checker/baseline only, never the product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
@@ -60,18 +61,30 @@ def cpu_baseline(M, n_obs, budget_s=10.0):
     Bs = max(cores, 8)
     X, U, recs = W.quadrotor_batch(2, Bs, M, n_obs)
     mesh = lgl(M)
-    O.evaluate(1, W.QUAD_PARAMS, M, mesh, 0.0, W.TF, X, U, recs, style="epsopt", nthreads=cores)  # warm
-    t0 = time.perf_counter()
-    passes = 0
-    while True:
-        O.evaluate(1, W.QUAD_PARAMS, M, mesh, 0.0, W.TF, X, U, recs, style="epsopt", nthreads=cores)
-        passes += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or passes >= 200:
-            break
-    return {"value": Bs * M * passes / el, "unit": "node-evals/s", "cores": int(cores), "kind": "port",
+
+    def rate(style, nthreads, nb, budget):
+        Xs, Us, rs = X[:nb], U[:nb], recs[:nb]
+        O.evaluate(1, W.QUAD_PARAMS, M, mesh, 0.0, W.TF, Xs, Us, rs, style=style, nthreads=nthreads)  # warm
+        t0 = time.perf_counter()
+        passes = 0
+        while True:
+            O.evaluate(1, W.QUAD_PARAMS, M, mesh, 0.0, W.TF, Xs, Us, rs, style=style, nthreads=nthreads)
+            passes += 1
+            el = time.perf_counter() - t0
+            if el > budget:
+                break
+        return nb * M * passes / el, passes, el
+
+    v_all, passes, el = rate("epsopt", cores, Bs, 0.5 * budget_s)
+    v_one, p1, e1 = rate("epsopt", 1, min(Bs, 2), 0.25 * budget_s)
+    v_orc, p2, e2 = rate("oracle", cores, Bs, 0.25 * budget_s)
+    return {"value": v_all, "unit": "node-evals/s", "cores": int(cores), "kind": "port",
             "sample": f"{passes} passes over {Bs} instances x {M} nodes (ePSOPT-style std::any/dual-number port, "
-                      f"OpenMP over instances), {el:.1f} s"}
+                      f"OpenMP over instances), {el:.1f} s",
+            "single_thread": {"value": v_one, "sample": f"{p1} passes over {min(Bs, 2)} instances, {e1:.1f} s"},
+            "checker_oracle": {"value": v_orc, "cores": 1,
+                               "sample": f"{p2} passes over {Bs} instances (oracle/emi_oracle.c, one thread: complex-step "
+                                         f"derivatives and long-double D.X -- built for checking, not for speed), {e2:.1f} s"}}
 
 
 def main():
