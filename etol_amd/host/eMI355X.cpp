@@ -263,6 +263,8 @@ void eMI355X::setup() {
     P.t0 = 0.;
     P.tf = getNSteps() * getDt();                    // fixed horizon, ePSOPT.cpp:151-154
     if (P.nodes < 2 || !(P.tf > 0)) die("nsteps and dt must be positive");
+    P.guess_states.clear();                          // a fresh transcription starts from the default guess
+    P.guess_controls.clear();
 
     traceCallbacks();
     setMesh(P.nodes);

@@ -241,3 +241,15 @@ def test_config3_sized_problem_end_to_end(H):
     assert np.allclose(X[:, 0], [1, 1, 0, 0, 0, 0]) and np.all(np.abs(X[:3, -1] - [8, 6, 0]) <= 0.01 + 1e-9)
     assert 380 < cost < 460
     print(f"quadrotor M=1024, 20 keep-outs: {mesh_iters} meshes, last solve {iters} iterations, {dt:.1f} s wall")
+
+
+def test_device_newton_step_without_path_rows(H):
+    """No keep-outs at all (np = 0): the device backend must cope with an empty path table."""
+    try:
+        _set_linear_solver(H, "device")
+        cost, X, U, iters, _, _ = _solve_quadrotor(H, 32, 0.125, 0, refine=0)
+    finally:
+        _set_linear_solver(H, "auto")
+    m = X.shape[1]
+    RES, _, COST = O.evaluate(1, [1.0, 0.01, 9.81, 1.0, 1.0], m, O.lgl(m), 0.0, 4.0, X[None], U[None], None)
+    assert np.abs(RES[0, :6]).max() < 1e-7 and abs(COST[0] - cost) < 1e-8 and iters < 100
