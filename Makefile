@@ -28,7 +28,7 @@ all: lib oracle
 endif
 
 lib: $(LIBDIR)/libemi355x.so
-host: $(LIBDIR)/libetol_mi355x.so $(LIBDIR)/etol_mi355x_example1 tests/harness/libetol_harness.so
+host: $(LIBDIR)/libetol_mi355x.so $(LIBDIR)/etol_mi355x_example1 $(LIBDIR)/etol_mi355x_montecarlo tests/harness/libetol_harness.so
 
 $(LIBDIR):
 	mkdir -p $(LIBDIR)
@@ -68,6 +68,9 @@ $(LIBDIR)/libetol_mi355x.so: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libemi355x.so
 
 $(LIBDIR)/etol_mi355x_example1: etol_amd/examples/etol_mi355x_example1.cpp $(LIBDIR)/libetol_mi355x.so
 	$(CXX) $(CXXFLAGS) -I$(HOST) -o $@ $< -L$(LIBDIR) -letol_mi355x -lemi355x -Wl,-rpath,'$$ORIGIN'
+
+$(LIBDIR)/etol_mi355x_montecarlo: etol_amd/examples/etol_mi355x_montecarlo.cpp $(LIBDIR)/libetol_mi355x.so
+	$(CXX) $(CXXFLAGS) -I$(HOST) -pthread -o $@ $< -L$(LIBDIR) -letol_mi355x -lemi355x -Wl,-rpath,'$$ORIGIN'
 
 tests/harness/libetol_harness.so: tests/harness/etol_harness.cpp $(LIBDIR)/libetol_mi355x.so $(HOST_HDR)
 	$(CXX) $(CXXFLAGS) -I$(HOST) -shared -o $@ $< -L$(LIBDIR) -letol_mi355x -lemi355x -ldl \

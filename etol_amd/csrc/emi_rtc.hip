@@ -12,6 +12,8 @@
 
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -145,13 +147,45 @@ int rtc_check(bool f32, const char* struct_name, const char* source, int ns, int
     return compile(f32, struct_name, source, ns, nc, &code, &low, &ring, log);
 }
 
+namespace {
+// code objects by (arithmetic type, struct name, dimensions, text): a Monte-Carlo run sets the same traced model up
+// in many contexts and pays the ~4 s of hiprtc once per process
+struct CachedProgram {
+    std::vector<char> code;
+    std::vector<std::string> lowered;
+    bool ring = false;
+};
+std::mutex g_cache_mutex;
+std::map<std::string, CachedProgram> g_cache;
+}  // namespace
+
 int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int nc, RtcModel** out, std::string* log) {
     *out = nullptr;
     std::vector<char> code;
     std::vector<std::string> low;
     bool ring = false;
-    const int st = compile(f32, struct_name, source, ns, nc, &code, &low, &ring, log);
-    if (st) return st;
+    const std::string key = std::string(f32 ? "f32|" : "f64|") + (struct_name ? struct_name : "") + "|" + std::to_string(ns) + "|" +
+                            std::to_string(nc) + "|" + (source ? source : "");
+    bool hit = false;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mutex);
+        auto it = g_cache.find(key);
+        if (it != g_cache.end()) {
+            code = it->second.code;
+            low = it->second.lowered;
+            ring = it->second.ring;
+            hit = true;
+        }
+    }
+    if (!hit) {
+        const int st = compile(f32, struct_name, source, ns, nc, &code, &low, &ring, log);
+        if (st) return st;
+        std::lock_guard<std::mutex> lk(g_cache_mutex);
+        CachedProgram& cp = g_cache[key];
+        cp.code = code;
+        cp.lowered = low;
+        cp.ring = ring;
+    }
     RtcModel* m = new RtcModel();
     m->f32 = f32;
     m->ns = ns;

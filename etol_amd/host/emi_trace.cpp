@@ -11,7 +11,7 @@ namespace ETOL {
 namespace mi355x {
 
 Trace& Trace::active() {
-    static Trace t;
+    static thread_local Trace t;     // one trace per thread: solvers may be set up concurrently
     return t;
 }
 

@@ -253,3 +253,28 @@ def test_device_newton_step_without_path_rows(H):
     m = X.shape[1]
     RES, _, COST = O.evaluate(1, [1.0, 0.01, 9.81, 1.0, 1.0], m, O.lgl(m), 0.0, 4.0, X[None], U[None], None)
     assert np.abs(RES[0, :6]).max() < 1e-7 and abs(COST[0] - cost) < 1e-8 and iters < 100
+
+
+def test_montecarlo_example_shards_scenarios_over_ranks_and_threads(built):
+    """etol_mi355x_montecarlo: independent scenarios, static block partition over ranks (RANK / WORLD_SIZE /
+    LOCAL_RANK), host threads inside a rank.  Two 'ranks' on the one GPU of the test box must solve, between
+    them, exactly the scenarios a single rank solves, with the same costs."""
+    exe = os.path.join(ROOT, "etol_amd", "lib", "etol_mi355x_montecarlo")
+
+    def run(rank, world, threads):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+        r = subprocess.run([exe, "6", "40", "4", str(threads)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = r.stdout.strip().split("\n")
+        summary = json.loads(lines[-1])
+        costs = {int(l.split()[1]): float(l.split()[l.split().index("cost") + 1]) for l in lines if l.startswith("scenario")}
+        return summary, costs
+
+    s_all, c_all = run(0, 1, 3)
+    assert s_all["solved"] == 6 and sorted(c_all) == list(range(6))
+    s0, c0 = run(0, 2, 2)
+    s1, c1 = run(1, 2, 1)
+    assert sorted(c0) == [0, 1, 2] and sorted(c1) == [3, 4, 5] and s0["solved"] == 3 and s1["solved"] == 3
+    for s, c in {**c0, **c1}.items():
+        assert abs(c - c_all[s]) < 1e-6 * c_all[s]
+    assert len(set(round(c, 3) for c in c_all.values())) > 1          # the scenarios really differ
