@@ -61,7 +61,7 @@ HOST_SRC := $(HOST)/TrajectoryOptimizer.cpp $(HOST)/eMI355X.cpp $(HOST)/emi_nlp.
 HOST_HDR := $(wildcard include/ETOL/*.hpp) $(wildcard $(HOST)/*.hpp) include/emi355x.h
 
 # the host side of the Newton step (block eigen-decompositions, r x r Cholesky of the low-rank correction) wants AVX2
-$(LIBDIR)/libetol_mi355x.so: CXXFLAGS := -O3 -march=x86-64-v3 -std=c++17 -fPIC -Iinclude -Wall
+$(LIBDIR)/libetol_mi355x.so: CXXFLAGS := -O3 -march=x86-64-v3 -fopenmp-simd -std=c++17 -fPIC -Iinclude -Wall
 $(LIBDIR)/libetol_mi355x.so: $(HOST_SRC) $(HOST_HDR) $(LIBDIR)/libemi355x.so
 	$(CXX) $(CXXFLAGS) $(XML2_INC) -I$(HOST) -shared -o $@ $(HOST_SRC) -L$(LIBDIR) -lemi355x $(XML2_LIB) \
 		-Wl,-rpath,'$$ORIGIN'

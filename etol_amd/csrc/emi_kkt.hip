@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <rocsolver/rocsolver.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "emi_kernels.hpp"
@@ -353,6 +355,10 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
             w->S_elems = md * md;
             w->cap_schur = (size_t)N;
         }
+        // S = J Q^-1 J^T squares the conditioning of J; late interior-point iterations (barrier terms of 1e10 in Q)
+        // leave it numerically semidefinite.  A dual regularisation of IPOPT's size (its delta_c is 1e-8 mu^1/4),
+        // raised x1000 on a failed Cholesky, keeps the factorisation alive; the caller's iterative refinement
+        // works against the matrix with the nominal dc.
         KKT_HIP(hipMemsetAsync(w->flag, 0, sizeof(int), stream));
         const unsigned nb2 = (unsigned)(((size_t)M * M + 255) / 256);
         hipLaunchKernelGGL(emi_kkt_doff_kernel, dim3(nb2), dim3(256), 0, stream, dD, w->Doff, M);
@@ -361,23 +367,30 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         KKT_HIP(hipGetLastError());
         // Doff is stored [k][j] row-major, i.e. as the column-major matrix Dc = Doff^T:  Doff diag(p) Doff^T = Dc^T (diag(p) Dc)
         const double one = 1.0, zero = 0.0;
-        for (int i = 0; i < ns; ++i)
-            for (int ip = 0; ip <= i; ++ip) {
-                hipLaunchKernelGGL(emi_kkt_scale_kernel, dim3(nb2), dim3(256), 0, stream, w->Doff,
-                                   w->Pinv + (size_t)(i * nv + ip) * M, w->W, M);
-                double* Sblk = w->S + ((size_t)ip * M) * md + (size_t)i * M;
-                KKT_RB(rocblas_dgemm(w->handle, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &one, w->Doff, M,
-                                     w->W, M, &zero, Sblk, (rocblas_int)md));
-                hipLaunchKernelGGL(emi_kkt_sblock_terms_kernel, dim3(nb2), dim3(256), 0, stream, w->S, w->Doff, w->G, w->Rk, M, ns,
-                                   i, ip, dc);
-            }
-        KKT_HIP(hipGetLastError());
-        KKT_RB(rocsolver_dpotrf(w->handle, rocblas_fill_lower, (rocblas_int)md, w->S, (rocblas_int)md, w->info));
         rocblas_int hinfo = 0;
         int hflag = 0;
-        KKT_HIP(hipMemcpyAsync(&hinfo, w->info, sizeof hinfo, hipMemcpyDeviceToHost, stream));
-        KKT_HIP(hipMemcpyAsync(&hflag, w->flag, sizeof hflag, hipMemcpyDeviceToHost, stream));
-        KKT_HIP(hipStreamSynchronize(stream));
+        double dc_schur = dc > 1e-9 ? dc : 1e-9;
+        for (int attempt = 0; attempt < 3; ++attempt, dc_schur *= 1e3) {
+            for (int i = 0; i < ns; ++i)
+                for (int ip = 0; ip <= i; ++ip) {
+                    hipLaunchKernelGGL(emi_kkt_scale_kernel, dim3(nb2), dim3(256), 0, stream, w->Doff,
+                                       w->Pinv + (size_t)(i * nv + ip) * M, w->W, M);
+                    double* Sblk = w->S + ((size_t)ip * M) * md + (size_t)i * M;
+                    KKT_RB(rocblas_dgemm(w->handle, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &one, w->Doff, M,
+                                         w->W, M, &zero, Sblk, (rocblas_int)md));
+                    hipLaunchKernelGGL(emi_kkt_sblock_terms_kernel, dim3(nb2), dim3(256), 0, stream, w->S, w->Doff, w->G, w->Rk, M,
+                                       ns, i, ip, dc_schur);
+                }
+            KKT_HIP(hipGetLastError());
+            KKT_RB(rocsolver_dpotrf(w->handle, rocblas_fill_lower, (rocblas_int)md, w->S, (rocblas_int)md, w->info));
+            KKT_HIP(hipMemcpyAsync(&hinfo, w->info, sizeof hinfo, hipMemcpyDeviceToHost, stream));
+            KKT_HIP(hipMemcpyAsync(&hflag, w->flag, sizeof hflag, hipMemcpyDeviceToHost, stream));
+            KKT_HIP(hipStreamSynchronize(stream));
+            if (hinfo == 0 || hflag != 0) break;      // factorised, or hopeless (a Q block is not positive definite)
+            if (getenv("EMI_KKT_DEBUG"))
+                fprintf(stderr, "emi_kkt_factor: S not positive definite at %d with dual regularisation %.1e (M %d), retrying\n",
+                        (int)hinfo, dc_schur, M);
+        }
         if (hinfo == 0 && hflag == 0) {
             *info = 0;
             w->factored = true;
@@ -385,6 +398,9 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
             return EMI_OK;
         }
         // a block was not positive definite or S is not: not the quasi-definite case -- general path below
+        if (getenv("EMI_KKT_DEBUG"))
+            fprintf(stderr, "emi_kkt_factor: Schur path gave up (block flag %d, potrf info %d, M %d, dc %.3g) -> LU\n", hflag,
+                    (int)hinfo, M, dc);
     }
     w->method_used = 0;
     if (w->K_elems < (size_t)N * N) {

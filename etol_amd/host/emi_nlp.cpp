@@ -650,6 +650,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     std::vector<double> soc_def(md), soc_row(mc), soc_rhs(NN), lr_vec, lr_delta;
     std::vector<int> lr_node;
     // y = [[Q, J^T], [J, -dc I]] x  with the node blocks Qb (fixed variables: identity rows/columns)
+    std::vector<double> xfree;
     auto kkt_matvec = [&](const double* Qb, const double* x, double* y, double dcv) {
         const double* V = E.VALS.data();
         std::fill(y, y + NN, 0.0);
@@ -664,17 +665,25 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 }
                 y[v * M + k] = acc;
             }
-        for (int i = 0; i < ns; ++i)
+        // D part: plain dot / axpy over whole rows of D (vectorisable), with x of fixed variables taken as 0
+        // and the node-diagonal term (which lives in the node blocks V) taken out again
+        xfree.assign(x, x + nz);
+        for (int q = 0; q < nz; ++q)
+            if (fixed_mask[q]) xfree[q] = 0.0;
+        for (int i = 0; i < ns; ++i) {
+            const double* xi = &xfree[(size_t)i * M];
+            double* yi = &y[(size_t)i * M];
             for (int k = 0; k < M; ++k) {
                 const int R = nz + i * M + k;
                 const double* Dk = &P.D[(size_t)k * M];
                 const double xr = x[R];
                 double acc = 0;
-                for (int j = 0; j < M; ++j) {
-                    if (j == k || fixed_mask[i * M + j]) continue;
-                    acc += Dk[j] * x[i * M + j];
-                    y[i * M + j] += Dk[j] * xr;
-                }
+#pragma omp simd reduction(+ : acc)
+                for (int j = 0; j < M; ++j) acc += Dk[j] * xi[j];
+#pragma omp simd
+                for (int j = 0; j < M; ++j) yi[j] += Dk[j] * xr;
+                acc -= Dk[k] * xi[k];
+                yi[k] -= Dk[k] * xr;
                 for (int v = 0; v < nv; ++v) {
                     if (fixed_mask[v * M + k]) continue;
                     const double jv = V[(size_t)(i * nv + v) * M + k];
@@ -683,6 +692,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 }
                 y[R] = acc - dcv * xr;
             }
+        }
         for (int q = 0; q < nz; ++q)
             if (fixed_mask[q]) y[q] = x[q];
     };
