@@ -317,7 +317,12 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         rocblas_status s_ = (call);                                                        \
         if (s_ != rocblas_status_success) { *err = std::string(#call) + ": " + rb(s_); return EMI_ERR_HIP; } \
     } while (0)
-    if (!w->handle) KKT_RB(rocblas_create_handle(&w->handle));
+    if (!w->handle) {
+        KKT_RB(rocblas_create_handle(&w->handle));
+        // split-K kernels that accumulate with atomics make the factorisation, and with it the iteration path of
+        // the NLP solver, differ from run to run: a solver has to be reproducible
+        KKT_RB(rocblas_set_atomics_mode(w->handle, rocblas_atomics_not_allowed));
+    }
     KKT_RB(rocblas_set_stream(w->handle, stream));
     if (w->cap_small < (size_t)N) {
         void** small[] = {(void**)&w->ipiv, (void**)&w->info, (void**)&w->Q, (void**)&w->J, (void**)&w->fixed};

@@ -49,6 +49,11 @@ std::vector<std::array<double, 3>> scenario_discs(int s, int ndiscs) {
     return d;
 }
 
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 struct Result {
     int scenario = -1, rc = 0, nodes = 0, iterations = 0;
     double cost = 0, seconds = 0;
@@ -103,6 +108,7 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
     solver.getAlgorithm()->nlp_tolerance = 1e-7;
     solver.getAlgorithm()->nlp_iter_max = 400;
     solver.getAlgorithm()->mesh_refinement = "none";
+    solver.getAlgorithm()->print_level = env_int("EMI_MC_PRINT_LEVEL", 0);
     t->solve();
     const mx::Sol* sol = solver.getSolution();
     R.rc = sol->error_flag;
@@ -112,11 +118,6 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
     t->close();
     R.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return R;
-}
-
-int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
 }
 
 }  // namespace

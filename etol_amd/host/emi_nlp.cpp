@@ -724,6 +724,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
 
     grad_and_jt(it);
     int n_acceptable = 0;
+    bool force_modified = false;
     for (int iter = 0;; ++iter) {
         R.iterations = iter;
         double viol = 0, emax = 0;
@@ -854,12 +855,13 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             }
             const auto tl0 = now();
             bool lr_exact = false;
+            if (force_modified) r_mod = 0;      // the exact step failed the line search here: take the convexified one
             if (kkt->lowrank(r_mod, lr_node.data(), lr_vec.data(), lr_delta.data(), &lr_exact) != 0) {
                 R.msg = "KKT low-rank correction failed: " + kkt->last_error();
                 return R;
             }
             R.t_lowrank += secs(tl0, now());
-            exact_step = lr_exact && r_mod == (int)mods.size();
+            exact_step = !force_modified && lr_exact && r_mod == (int)mods.size();
             build_rhs(rhs_full.data(), E.RES.data());
             std::copy(rhs_full.begin(), rhs_full.begin() + NN, rhs_keep.begin());
             const auto ts0 = now();
@@ -1045,6 +1047,13 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         if (opt.print_level >= 6)
             printf("          apr %.3e  alpha %.3e  adu %.3e  dphi %.3e  infeas1 %.3e  slope %.3e\n", apr, alpha, adu, dphi,
                    infeas0, slope);
+        if (!accepted && exact_step && !mods.empty() && !force_modified) {
+            // the exact Newton direction is not a descent direction the merit function accepts at this point:
+            // redo the iteration with the step of the convexified matrix (a descent direction by construction)
+            force_modified = true;
+            continue;
+        }
+        force_modified = false;
         if (!accepted) {
             R.msg = "line search failed";
             if (err0 <= 1e3 * opt.tol && emax <= 1e-6) { R.ok = true; R.msg = "converged to acceptable level (line search at round-off)"; }
