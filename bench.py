@@ -132,7 +132,15 @@ def main():
     M, B, n_obs = a.nodes, a.batch, a.obstacles
     ev = E.Evaluator(local)
     ev.set_mesh(M, 0.0, W.TF)
-    ev.set_model(E.MODEL_QUADROTOR2D, W.QUAD_PARAMS)
+    if os.environ.get("EMI_BENCH_TRACED", "0") == "1":
+        # A/B knob: the same model written as mi355x::Var arithmetic, differentiated and compiled at run time
+        # (text from the test harness); the default run uses the hand-written kernel instantiation
+        import ctypes
+        hl = ctypes.CDLL(os.path.join(ROOT, "tests", "harness", "libetol_harness.so"))
+        hl.harness_traced_model_source.restype = ctypes.c_char_p
+        ev.set_model_source("TracedModel", hl.harness_traced_model_source(0).decode(), 6, 2)
+    else:
+        ev.set_model(E.MODEL_QUADROTOR2D, W.QUAD_PARAMS)
     ev.set_batch(B)
     if os.environ.get("EMI_OVERLAP", "1") == "0":
         ev.set_option("overlap", 0)        # A/B switch: sequential general path
