@@ -131,7 +131,8 @@ int main(int argc, char** argv) {
     const bool traced = argc > 5 && std::string(argv[5]) == "traced";
     const int rank = env_int("RANK", 0), world = std::max(1, env_int("WORLD_SIZE", 1)), device = env_int("LOCAL_RANK", 0);
     // static block partition, as etol_amd/batch.py shard_range: scenario s -> rank floor(s * world / nscen)
-    const int lo = (int)((long long)rank * nscen / world), hi = (int)((long long)(rank + 1) * nscen / world);
+    int lo = (int)((long long)rank * nscen / world), hi = (int)((long long)(rank + 1) * nscen / world);
+    if (env_int("EMI_MC_ONLY", -1) >= 0) { lo = env_int("EMI_MC_ONLY", 0); hi = lo + 1; }   // diagnostics: one scenario
 
     std::vector<Result> results(hi - lo);
     std::atomic<int> next(lo);

@@ -571,6 +571,15 @@ void eMI355X::solve() {
     for (int mr = 0;; ++mr) {
         solve_current_mesh(sequenced && mr == 0 ? warm : opt);
         ++_solution.mesh_iterations;
+        if (!r.ok && sequenced && mr == 0) {
+            // the ladder led into a corner (typically an interpolant cutting through a keep-out the coarse meshes
+            // did not see): start over on the requested mesh from the default guess
+            if (_algorithm.print_level >= 5) printf("mesh sequencing: warm start failed (%s), cold start on %zu nodes\n", r.msg.c_str(), P.nodes);
+            P.guess_states.clear();
+            P.guess_controls.clear();
+            solve_current_mesh(opt);
+            ++_solution.mesh_iterations;
+        }
         if (!r.ok || !refine) break;
         std::vector<double> zf;
         size_t M2 = 0;

@@ -612,7 +612,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     std::vector<double> dz(nz), ds(mc), de1(mc), de2(mc), dlam(md), dy(mc), dzL(nz), dzU(nz), dvL(mc), dvU(mc),
         dw1(mc), dw2(mc);
     std::vector<double> sig_t(mc), r_t(mc), sig_s(mc), rhat_s(mc);
-    Eval Et;
+    Eval Et, Ekeep;
     Et.RES.resize(E.RES.size());
     Et.VALS.resize(E.VALS.size());
     std::vector<double> zt(nz), st(mc), e1t(mc), e2t(mc);
@@ -969,9 +969,41 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 if (take < keep) st[r] = target;
             }
         };
+        // the iterate after a step of length a_pr (primal: zt, st, e1t, e2t hold the trial point) / a_du (bound
+        // multipliers), re-evaluated with derivatives
+        auto take_step = [&](double a_pr, double a_du) -> bool {
+            it.z = zt;
+            it.s = st;
+            it.e1 = e1t;
+            it.e2 = e2t;
+            auto clampm = [&](double m, double g) { return std::max(std::min(m, kappa_sigma * mu / g), mu / (kappa_sigma * g)); };
+            for (int r = 0; r < md; ++r) it.lam[r] += a_pr * dlam[r];
+            for (int r = 0; r < mc; ++r) {
+                it.y[r] += a_pr * dy[r];
+                it.vL[r] += a_du * dvL[r];
+                it.vU[r] += a_du * dvU[r];
+                it.w1[r] += a_du * dw1[r];
+                it.w2[r] += a_du * dw2[r];
+                if (shasL(r)) it.vL[r] = clampm(it.vL[r], it.s[r] - cL(r));
+                if (shasU(r)) it.vU[r] = clampm(it.vU[r], cU(r) - it.s[r]);
+                it.w1[r] = clampm(it.w1[r], it.e1[r]);
+                it.w2[r] = clampm(it.w2[r], it.e2[r]);
+            }
+            for (int q = 0; q < nz; ++q) {
+                if (fidx[q] < 0) continue;
+                it.zL[q] += a_du * dzL[q];
+                it.zU[q] += a_du * dzU[q];
+                if (hasL(q)) it.zL[q] = clampm(it.zL[q], it.z[q] - P.zl[q]);
+                if (hasU(q)) it.zU[q] = clampm(it.zU[q], P.zu[q] - it.z[q]);
+            }
+            if (!evaluate(it.z, E, true)) return false;
+            grad_and_jt(it);
+            return true;
+        };
         // backtracking
         double alpha = apr;
         bool accepted = false;
+        bool newton_accepted = false;
         for (int ls = 0; ls < 40; ++ls) {
             for (int q = 0; q < nz; ++q) zt[q] = it.z[q] + alpha * dz[q];
             for (int r = 0; r < mc; ++r) {
@@ -1042,11 +1074,42 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                     apr = b_apr; adu = b_adu;
                 }
             }
+            // Close to a solution the merit function stops resolving progress: the full Newton step changes it
+            // by less than constraint curvature and round-off move it, and the backtracking then crawls with steps
+            // of 1e-6 for a hundred iterations.  There the KKT residual itself is the better judge: take the full
+            // step if it reduces the residual of the current barrier problem (else undo and backtrack as usual).
+            if (ls == 0 && err0 <= 1e-2) {
+                const double err_mu = kkt_error(it, mu, nullptr, nullptr);
+                const Iterate it_keep = it;
+                const std::vector<double> gradf_keep = gradf, jtl_keep = jtl;
+                Ekeep.RES = E.RES; Ekeep.VALS = E.VALS; Ekeep.cost = E.cost;
+                for (int q = 0; q < nz; ++q) zt[q] = it.z[q] + apr * dz[q];
+                for (int r = 0; r < mc; ++r) {
+                    st[r] = it.s[r] + apr * ds[r];
+                    e1t[r] = it.e1[r] + apr * de1[r];
+                    e2t[r] = it.e2[r] + apr * de2[r];
+                }
+                if (!take_step(apr, adu)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
+                const double err_tr = kkt_error(it, mu, nullptr, nullptr);
+                if (std::isfinite(err_tr) && err_tr <= 0.9 * err_mu) {
+                    newton_accepted = true;
+                    ++R.newton_steps;
+                    break;
+                }
+                it = it_keep;
+                gradf = gradf_keep;
+                jtl = jtl_keep;
+                E.RES = Ekeep.RES; E.VALS = Ekeep.VALS; E.cost = Ekeep.cost;
+            }
             alpha *= 0.5;
         }
         if (opt.print_level >= 6)
             printf("          apr %.3e  alpha %.3e  adu %.3e  dphi %.3e  infeas1 %.3e  slope %.3e\n", apr, alpha, adu, dphi,
                    infeas0, slope);
+        if (newton_accepted) {       // the iterate is already updated and re-evaluated
+            force_modified = false;
+            continue;
+        }
         if (!accepted && exact_step && !mods.empty() && !force_modified) {
             // the exact Newton direction is not a descent direction the merit function accepts at this point:
             // redo the iteration with the step of the convexified matrix (a descent direction by construction)
@@ -1060,32 +1123,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             break;
         }
         // accept
-        it.z = zt;
-        it.s = st;
-        it.e1 = e1t;
-        it.e2 = e2t;
-        auto clampm = [&](double m, double g) { return std::max(std::min(m, kappa_sigma * mu / g), mu / (kappa_sigma * g)); };
-        for (int r = 0; r < md; ++r) it.lam[r] += alpha * dlam[r];
-        for (int r = 0; r < mc; ++r) {
-            it.y[r] += alpha * dy[r];
-            it.vL[r] += adu * dvL[r];
-            it.vU[r] += adu * dvU[r];
-            it.w1[r] += adu * dw1[r];
-            it.w2[r] += adu * dw2[r];
-            if (shasL(r)) it.vL[r] = clampm(it.vL[r], it.s[r] - cL(r));
-            if (shasU(r)) it.vU[r] = clampm(it.vU[r], cU(r) - it.s[r]);
-            it.w1[r] = clampm(it.w1[r], it.e1[r]);
-            it.w2[r] = clampm(it.w2[r], it.e2[r]);
-        }
-        for (int q = 0; q < nz; ++q) {
-            if (fidx[q] < 0) continue;
-            it.zL[q] += adu * dzL[q];
-            it.zU[q] += adu * dzU[q];
-            if (hasL(q)) it.zL[q] = clampm(it.zL[q], it.z[q] - P.zl[q]);
-            if (hasU(q)) it.zU[q] = clampm(it.zU[q], P.zu[q] - it.z[q]);
-        }
-        if (!evaluate(it.z, E, true)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
-        grad_and_jt(it);
+        if (!take_step(alpha, adu)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
     }
     R.cost = E.cost;
     R.rho = rho;

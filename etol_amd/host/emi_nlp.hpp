@@ -80,6 +80,7 @@ struct NlpResult {
     std::string msg;
     int iterations = 0;
     int evaluations = 0;
+    int newton_steps = 0;               // iterations accepted on the KKT residual alone (near the solution)
     int soc_steps = 0;                  // iterations accepted through a second-order correction
     double cost = 0, kkt_error = 0, constr_viol = 0;
     std::vector<double> z;              // (ns+nc)*M solution
