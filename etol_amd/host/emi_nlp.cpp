@@ -500,9 +500,13 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     }
     it.lam.assign(md, 0.0);
     it.y.assign(mc, 0.0);
+    if ((int)P.lamF0.size() == md) it.lam = P.lamF0;
+    if ((int)P.lamC0.size() == mc)      // iterated on in scaled form; inside the penalty box
+        for (int r = 0; r < mc; ++r) it.y[r] = std::min(std::max(P.lamC0[r] / sig[r / M], -0.9 * rho), 0.9 * rho);
     it.zL.assign(nz, 0.0); it.zU.assign(nz, 0.0);
     it.vL.assign(mc, 0.0); it.vU.assign(mc, 0.0);
     it.w1.assign(mc, rho); it.w2.assign(mc, rho);
+    for (int r = 0; r < mc; ++r) { it.w1[r] = std::max(1e-8, rho - it.y[r]); it.w2[r] = std::max(1e-8, rho + it.y[r]); }
     for (int q = 0; q < nz; ++q) if (fidx[q] >= 0) { if (hasL(q)) it.zL[q] = 1.0; if (hasU(q)) it.zU[q] = 1.0; }
     for (int r = 0; r < mc; ++r) { if (shasL(r)) it.vL[r] = 1.0; if (shasU(r)) it.vU[r] = 1.0; }
 

@@ -76,6 +76,7 @@ struct Prob {
     std::vector<double> path_lower, path_upper;
     std::vector<double> event_lower, event_upper;  // [2*nstates]: x(t0) then x(tf)
     std::vector<double> guess_states, guess_controls;   // optional warm start, [n][nodes]
+    std::vector<double> guess_lamF, guess_lamC;         // multipliers to go with it, [nstates][nodes] / [npath][nodes]
 };
 
 }  // namespace mi355x
