@@ -2,8 +2,13 @@
 // See emi_nlp.hpp for what this stands in for in the reference (IPOPT behind
 // PSOPT, src/ePSOPT/ePSOPT.cpp:62-66,84).  Written from the published
 // algorithm (Waechter & Biegler 2006: barrier subproblems, fraction-to-the-
-// boundary rule, inertia correction of the KKT matrix), with an l1 merit
-// function instead of a filter.
+// boundary rule, second-order correction, acceptable-level termination), with
+// an l1 merit function instead of a filter, and with the inertia of the KKT
+// matrix fixed by construction instead of by trial factorisations: the node
+// blocks of the Hessian are made positive definite (quasi-definite matrix for
+// the backend: Cholesky of a Schur complement on the device) and the exact
+// matrix comes back, together with an exact inertia verdict, through a
+// low-rank correction.
 //
 // NLP in per-instance numbering (DESIGN.md "NLP layout"):
 //   variables   z (states then controls, index v*M+k), slacks s for the path rows
