@@ -65,6 +65,7 @@ struct emi_ctx_s {
     // batch / path
     int B = 0;
     int np = 0, path_sets = 0, px = 0, py = 1;
+    int np_model = 0;           // path rows computed by the model itself (emi_set_model_source npath)
     DevBuf d_path;
     int ntracks = 0, track_sets = 0;
     DevBuf d_trkx, d_trky;
@@ -147,8 +148,9 @@ bool overlapped_path(emi_ctx_t c) {
     return emi::fused_supported(c->model, c->M, c->sym_ct);
 }
 
-int nvals_of(emi_ctx_t c) { return c->ns * (c->ns + c->nc) + 2 * c->np + (c->ns + c->nc); }
-int nres_of(emi_ctx_t c) { return c->ns + c->np; }
+int np_total(emi_ctx_t c) { return c->np + c->np_model; }     // rows of the record table, then the model's own (traced) rows
+int nvals_of(emi_ctx_t c) { return c->ns * (c->ns + c->nc) + 2 * np_total(c) + (c->ns + c->nc); }
+int nres_of(emi_ctx_t c) { return c->ns + np_total(c); }
 int nhess_of(emi_ctx_t c) { const int nv = c->ns + c->nc; return nv * (nv + 1) / 2; }
 
 int ready(emi_ctx_t c) {
@@ -180,7 +182,7 @@ void fill_node_args(emi_ctx_t c, emi::NodeArgs<T>& a, const void* dX, const void
     a.track_y = (const T*)c->d_trky.p;
     a.M = c->M;
     a.B = c->B;
-    a.np = c->np;
+    a.np = np_total(c);
     a.nres = nres_of(c);
     a.nvals = nvals_of(c);
     a.path_sets = c->path_sets;
@@ -380,22 +382,24 @@ int emi_set_model(emi_ctx_t c, int model, const double* params, int nparams, int
     c->model = model;
     c->ns = ns;
     c->nc = nc;
+    c->np_model = 0;
     c->maximize = maximize ? 1 : 0;
     memset(c->params, 0, sizeof c->params);
     for (int i = 0; i < nparams; ++i) c->params[i] = params[i];
     return EMI_OK;
 }
 
-int emi_set_model_source(emi_ctx_t c, const char* struct_name, const char* source, int ns, int nc,
+int emi_set_model_source(emi_ctx_t c, const char* struct_name, const char* source, int ns, int nc, int npath,
                          const double* params, int nparams, int maximize) {
     if (!c) return EMI_ERR_ARG;
+    if (npath < 0 || npath > 64) return fail(c, EMI_ERR_ARG, "emi_set_model_source: npath must be in [0, 64]");
     if (nparams < 0 || nparams > EMI_MAX_PARAMS || (nparams > 0 && !params))
         return fail(c, EMI_ERR_ARG, "emi_set_model_source: at most %d parameters", EMI_MAX_PARAMS);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     emi::RtcModel* m = nullptr;
     std::string log;
-    const int st = emi::rtc_build(c->f32, struct_name, source, ns, nc, &m, &log);
+    const int st = emi::rtc_build(c->f32, struct_name, source, ns, nc, npath, &m, &log);
     if (st) {
         c->err = log;
         return st;
@@ -405,6 +409,7 @@ int emi_set_model_source(emi_ctx_t c, const char* struct_name, const char* sourc
     c->model = EMI_MODEL_SOURCE;
     c->ns = ns;
     c->nc = nc;
+    c->np_model = npath;
     c->maximize = maximize ? 1 : 0;
     memset(c->params, 0, sizeof c->params);
     for (int i = 0; i < nparams; ++i) c->params[i] = params[i];
@@ -414,10 +419,10 @@ int emi_set_model_source(emi_ctx_t c, const char* struct_name, const char* sourc
     return EMI_OK;
 }
 
-int emi_check_model_source(const char* struct_name, const char* source, int ns, int nc, int f32, char* log,
+int emi_check_model_source(const char* struct_name, const char* source, int ns, int nc, int npath, int f32, char* log,
                            size_t log_len) {
     std::string l;
-    const int st = emi::rtc_check(f32 != 0, struct_name, source, ns, nc, &l);
+    const int st = emi::rtc_check(f32 != 0, struct_name, source, ns, nc, npath, &l);
     if (log && log_len) {
         strncpy(log, l.c_str(), log_len - 1);
         log[log_len - 1] = '\0';
@@ -476,7 +481,7 @@ int emi_get_layout(emi_ctx_t c, emi_layout_t* o) {
     o->model = c->model;
     o->ns = c->ns;
     o->nc = c->nc;
-    o->np = c->np;
+    o->np = np_total(c);
     o->M = c->M;
     o->B = c->B;
     o->nres = nres_of(c);
@@ -497,7 +502,7 @@ int emi_get_layout(emi_ctx_t c, emi_layout_t* o) {
 int emi_jac_structure(emi_ctx_t c, int* rows, int* cols) {
     if (!c || !rows || !cols) return EMI_ERR_ARG;
     if (c->M <= 0 || c->model < 0) return fail(c, EMI_ERR_STATE, "mesh and model must be set");
-    const int M = c->M, ns = c->ns, nv = c->ns + c->nc, np = c->np;
+    const int M = c->M, ns = c->ns, nv = c->ns + c->nc, np = np_total(c);
     size_t e = 0;
     for (int i = 0; i < ns; ++i)
         for (int v = 0; v < nv; ++v)
@@ -685,7 +690,7 @@ int emi_hess_dev(emi_ctx_t c, const void* dX, const void* dU, const void* dLamF,
     if (st) return st;
     if (c->model == EMI_MODEL_FIXEDWING12)
         return fail(c, EMI_ERR_UNSUPPORTED, "no second-derivative kernel for the fixed-wing model yet");
-    if (!dX || !dU || !dLamF || !dH || (c->np > 0 && !dLamC))
+    if (!dX || !dU || !dLamF || !dH || (np_total(c) > 0 && !dLamC))
         return fail(c, EMI_ERR_ARG, "emi_hess: null device pointer");
     HIP_TRY(c, hipSetDevice(c->device));
     auto fill = [&](auto& a) {
@@ -693,7 +698,7 @@ int emi_hess_dev(emi_ctx_t c, const void* dX, const void* dU, const void* dLamF,
         a.X = (const T*)dX; a.U = (const T*)dU; a.lamF = (const T*)dLamF; a.lamC = (const T*)dLamC;
         a.H = (T*)dH; a.w = (const T*)c->d_w.p; a.node_t = (const T*)c->d_t.p;
         a.path = (const T*)c->d_path.p;
-        a.M = c->M; a.B = c->B; a.np = c->np; a.path_sets = c->path_sets; a.px = c->px; a.py = c->py;
+        a.M = c->M; a.B = c->B; a.np = np_total(c); a.path_sets = c->path_sets; a.px = c->px; a.py = c->py;
         a.h = (T)((c->tf - c->t0) / 2.0); a.sgn = c->maximize ? T(-1) : T(1); a.sigma = (T)sigma;
         for (int i = 0; i < EMI_MAX_PARAMS; ++i) a.P.p[i] = (T)c->params[i];
     };
@@ -715,10 +720,10 @@ int emi_hess_host(emi_ctx_t c, const double* X, const double* U, const double* L
                   const double* LamC, double sigma, double* H) {
     int st = ready(c);
     if (st) return st;
-    if (!X || !U || !LamF || !H || (c->np > 0 && !LamC)) return fail(c, EMI_ERR_ARG, "emi_hess_host: null pointer");
+    if (!X || !U || !LamF || !H || (np_total(c) > 0 && !LamC)) return fail(c, EMI_ERR_ARG, "emi_hess_host: null pointer");
     const size_t rb = c->f32 ? 4 : 8;
     const size_t nX = (size_t)c->B * c->ns * c->M, nU = (size_t)c->B * c->nc * c->M;
-    const size_t nC = (size_t)c->B * c->np * c->M, nH = (size_t)c->B * nhess_of(c) * c->M;
+    const size_t nC = (size_t)c->B * np_total(c) * c->M, nH = (size_t)c->B * nhess_of(c) * c->M;
     if ((st = upload_real(c, c->s_X, X, nX))) return st;
     if ((st = upload_real(c, c->s_U, U, nU))) return st;
     if ((st = upload_real(c, c->s_LF, LamF, nX))) return st;

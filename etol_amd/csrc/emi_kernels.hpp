@@ -31,8 +31,8 @@ hipError_t launch_symdefect(int model, const SymDefectArgs& a, hipStream_t s, bo
 
 // model programs compiled at run time (emi_rtc.hip); the int results are EMI_* status codes
 struct RtcModel;
-int rtc_check(bool f32, const char* struct_name, const char* source, int ns, int nc, std::string* log);
-int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int nc, RtcModel** out, std::string* log);
+int rtc_check(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, std::string* log);
+int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, RtcModel** out, std::string* log);
 void rtc_destroy(RtcModel* m);
 bool rtc_has_symdefect(const RtcModel* m);
 template <typename T>

@@ -12,6 +12,10 @@
 //   L(z)   integrand cost               g[v]    = dL/dz_v
 //   hess() adds  cL*L_zz + sum_i cf[i]*f_i,zz  into the packed lower triangle
 //          H[v*(v+1)/2 + q], q<=v
+//   NPATH  path rows the model computes itself (0 for the hand-written models, whose keep-outs come from the
+//          record table; generated models carry the user's traced constraint callbacks):
+//          path(P, z, t, c, cx, cy)      values and partials w.r.t. the two path states
+//          path_hess(P, z, t, mu, h)     h[0..2] += sum_j mu_j (c_j,xx  c_j,xy  c_j,yy)
 #pragma once
 #ifndef __HIPCC_RTC__   // hiprtc (models compiled at run time, emi_rtc.hip) predeclares the device runtime
 #include <hip/hip_runtime.h>
@@ -49,7 +53,7 @@ EMI_DEV float emi_pow(float a, float c) { return powf(a, c); }
 //   objFunction :101-114 (L = u0^2 + u1^2).   No parameters.
 // ---------------------------------------------------------------------------
 template <typename T> struct PointMass2D {
-    static constexpr int NS = 2, NC = 2, NV = 4, NPARAM = 0;
+    static constexpr int NS = 2, NC = 2, NV = 4, NPARAM = 0, NPATH = 0;
     EMI_DEV static void f(const ModelParams<T>&, const T* z, T, T* fo) {
         fo[0] = z[2];
         fo[1] = z[3];
@@ -84,7 +88,7 @@ template <typename T> struct PointMass2D {
 //       example objective, etol_psopt_example1.cpp:101-114, with weights)
 // ---------------------------------------------------------------------------
 template <typename T> struct Quadrotor2D {
-    static constexpr int NS = 6, NC = 2, NV = 8, NPARAM = 5;
+    static constexpr int NS = 6, NC = 2, NV = 8, NPARAM = 5, NPATH = 0;
     EMI_DEV static void f(const ModelParams<T>& P, const T* z, T, T* fo) {
         T s, c;
         emi_sincos(z[2], &s, &c);
@@ -145,7 +149,7 @@ template <typename T> struct Quadrotor2D {
 //   L = w_ctrl * (thrust^2 + da^2 + de^2 + dr^2)
 // ---------------------------------------------------------------------------
 template <typename T> struct FixedWing12 {
-    static constexpr int NS = 12, NC = 4, NV = 16, NPARAM = 16;
+    static constexpr int NS = 12, NC = 4, NV = 16, NPARAM = 16, NPATH = 0;
     struct Pre {
         T sph, cph, sth, cth, sps, cps, tth, icth;
     };

@@ -132,8 +132,8 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T>
             for (int v = 0; v < NV; ++v) store_vec<T, VEC>(Gb + (size_t)v * M + k0, gv[v]);
         }
         // ---- K2 path constraints (records are wave-uniform: scalar loads) --
-        const int np = a.np;
-        if (np > 0) {
+        const int np = a.np - Model::NPATH;      // rows of the record table; the model's own rows follow them
+        if (a.np > 0) {
             const int set = a.path_sets > 1 ? b : 0;
             typedef const __attribute__((address_space(4))) T* cptr_t;   // read-only table: scalar loads
             cptr_t rec = (cptr_t)(a.path + (size_t)set * np * EMI_PATH_REC);
@@ -200,6 +200,28 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T>
                     store_vec<T, VEC>(JCb + (size_t)(2 * j + 1) * M + k0, cy);
                 }
             }
+            if constexpr (Model::NPATH > 0) {
+                // rows traced from the user's constraint callbacks (generated straight-line code)
+                constexpr int NPM = Model::NPATH;
+                T cm[NPM][VEC], cxm[NPM][VEC], cym[NPM][VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    T ze[NV], ce[NPM], cxe[NPM], cye[NPM];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) ze[v] = z[v][e];
+                    Model::path(a.P, ze, tk[e], ce, cxe, cye);
+#pragma unroll
+                    for (int j = 0; j < NPM; ++j) { cm[j][e] = ce[j]; cxm[j][e] = cxe[j]; cym[j][e] = cye[j]; }
+                }
+#pragma unroll
+                for (int j = 0; j < NPM; ++j) {
+                    store_vec<T, VEC>(Cb + (size_t)(np + j) * M + k0, cm[j]);
+                    if (JAC) {
+                        store_vec<T, VEC>(JCb + (size_t)(2 * (np + j)) * M + k0, cxm[j]);
+                        store_vec<T, VEC>(JCb + (size_t)(2 * (np + j) + 1) * M + k0, cym[j]);
+                    }
+                }
+            }
         }
     }
     // ---- K3 cost quadrature: wave reduction, then across the block's waves --
@@ -248,15 +270,15 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_hess_kernel(HessArgs<T> 
     for (int q = 0; q < NH; ++q) H[q] = T(0);
     const T cL = a.sigma * a.sgn * a.h * a.w[k];
     Model::hess(a.P, z, a.node_t[k], cL, cf, H);
-    const int np = a.np;
-    if (np > 0) {
+    const int np = a.np - Model::NPATH;          // rows of the record table; the model's own rows follow them
+    if (a.np > 0) {
         const int set = a.path_sets > 1 ? b : 0;
         const T* __restrict__ rec = a.path + (size_t)set * np * EMI_PATH_REC;
         T hxx = T(0), hxy = T(0), hyy = T(0);
         for (int j = 0; j < np; ++j) {
             const T* __restrict__ r = rec + j * EMI_PATH_REC;
             const int kind = (int)r[0];
-            const T mu = a.lamC[((size_t)b * np + j) * M + k];
+            const T mu = a.lamC[((size_t)b * a.np + j) * M + k];
             if (kind == EMI_PATH_ELLIPSE) {
                 const T ct = r[3], st = r[4], asq = r[5], bsq = r[6];
                 hxx += mu * T(-2) * (bsq * ct * ct + asq * st * st);
@@ -266,6 +288,15 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_hess_kernel(HessArgs<T> 
                 hxx += mu * T(-2);
                 hyy += mu * T(-2);
             }
+        }
+        if constexpr (Model::NPATH > 0) {
+            T mu[Model::NPATH], h3[3] = {T(0), T(0), T(0)};
+#pragma unroll
+            for (int j = 0; j < Model::NPATH; ++j) mu[j] = a.lamC[((size_t)b * a.np + np + j) * M + k];
+            Model::path_hess(a.P, z, a.node_t[k], mu, h3);
+            hxx += h3[0];
+            hxy += h3[1];
+            hyy += h3[2];
         }
         const int lo = a.px < a.py ? a.px : a.py, hi = a.px < a.py ? a.py : a.px;
         const int qxx = a.px * (a.px + 1) / 2 + a.px, qyy = a.py * (a.py + 1) / 2 + a.py;

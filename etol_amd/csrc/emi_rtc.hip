@@ -65,7 +65,7 @@ Names kernel_names(const char* sn, bool f32, bool with_ring) {
 
 // compile; on success *code holds the gfx950 code object and *lowered the mangled kernel names in
 // the order nodes[0][0][0..1], nodes[0][1][..], nodes[1][..][..], hess, ring
-int compile(bool f32, const char* sn, const char* source, int ns, int nc, std::vector<char>* code,
+int compile(bool f32, const char* sn, const char* source, int ns, int nc, int npath, std::vector<char>* code,
             std::vector<std::string>* lowered, bool* has_ring, std::string* log) {
     if (!valid_identifier(sn) || !source || ns < 1 || nc < 0 || ns + nc > 64) {
         if (log) *log = "emi_set_model_source: bad struct name, null source or dimensions out of range";
@@ -77,9 +77,10 @@ int compile(bool f32, const char* sn, const char* source, int ns, int nc, std::v
     prog += "namespace emi {\n";
     prog += source;
     prog += "\n}  // namespace emi\n";
-    char chk[256];
-    snprintf(chk, sizeof chk, "static_assert(emi::%s<double>::NS == %d && emi::%s<double>::NC == %d && emi::%s<double>::NV == %d, "
-             "\"model struct dimensions differ from emi_set_model_source(ns, nc)\");\n", sn, ns, sn, nc, sn, ns + nc);
+    char chk[400];
+    snprintf(chk, sizeof chk, "static_assert(emi::%s<double>::NS == %d && emi::%s<double>::NC == %d && emi::%s<double>::NV == %d && "
+             "emi::%s<double>::NPATH == %d, \"model struct dimensions differ from emi_set_model_source(ns, nc, npath)\");\n", sn, ns,
+             sn, nc, sn, ns + nc, sn, npath);
     prog += chk;
 
     hiprtcProgram p;
@@ -140,11 +141,11 @@ hipError_t launch(hipFunction_t f, dim3 grid, dim3 block, size_t lds, hipStream_
 
 }  // namespace
 
-int rtc_check(bool f32, const char* struct_name, const char* source, int ns, int nc, std::string* log) {
+int rtc_check(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, std::string* log) {
     std::vector<char> code;
     std::vector<std::string> low;
     bool ring = false;
-    return compile(f32, struct_name, source, ns, nc, &code, &low, &ring, log);
+    return compile(f32, struct_name, source, ns, nc, npath, &code, &low, &ring, log);
 }
 
 namespace {
@@ -159,13 +160,14 @@ std::mutex g_cache_mutex;
 std::map<std::string, CachedProgram> g_cache;
 }  // namespace
 
-int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int nc, RtcModel** out, std::string* log) {
+int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, RtcModel** out,
+              std::string* log) {
     *out = nullptr;
     std::vector<char> code;
     std::vector<std::string> low;
     bool ring = false;
     const std::string key = std::string(f32 ? "f32|" : "f64|") + (struct_name ? struct_name : "") + "|" + std::to_string(ns) + "|" +
-                            std::to_string(nc) + "|" + (source ? source : "");
+                            std::to_string(nc) + "|" + std::to_string(npath) + "|" + (source ? source : "");
     bool hit = false;
     {
         std::lock_guard<std::mutex> lk(g_cache_mutex);
@@ -178,7 +180,7 @@ int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int
         }
     }
     if (!hit) {
-        const int st = compile(f32, struct_name, source, ns, nc, &code, &low, &ring, log);
+        const int st = compile(f32, struct_name, source, ns, nc, npath, &code, &low, &ring, log);
         if (st) return st;
         std::lock_guard<std::mutex> lk(g_cache_mutex);
         CachedProgram& cp = g_cache[key];

@@ -88,10 +88,10 @@ class Evaluator:
         self._ck(self.lib.emi_set_model(self.ctx, model, _dp(p) if p.size else None, p.size, int(maximize)),
                  "emi_set_model")
 
-    def set_model_source(self, struct_name, source, ns, nc, params=(), maximize=False):
+    def set_model_source(self, struct_name, source, ns, nc, params=(), maximize=False, npath=0):
         """Install a model given as the text of a model struct (compiled for gfx950 here)."""
         p = np.ascontiguousarray(params, dtype=np.float64)
-        self._ck(self.lib.emi_set_model_source(self.ctx, struct_name.encode(), source.encode(), ns, nc,
+        self._ck(self.lib.emi_set_model_source(self.ctx, struct_name.encode(), source.encode(), ns, nc, npath,
                                                _dp(p) if p.size else None, p.size, int(maximize)),
                  "emi_set_model_source")
 

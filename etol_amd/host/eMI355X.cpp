@@ -183,22 +183,31 @@ void eMI355X::traceCallbacks() {
                 die("gradient callback " + std::to_string(i) + " does not describe state derivative " +
                     std::to_string(i) + " of the objective's model");
         }
-        if (traced) {
-            // derivatives and code for the device, once (ePSOPT: ADOL-C tape re-interpreted per evaluation)
-            P.model = EMI_MODEL_SOURCE;
-            P.model_params.clear();
-            P.model_source = mi355x::Trace::active().generate_model("TracedModel", (int)getNStates(),
-                                                                     (int)getNControls(), f_nodes, cost_node);
-        }
         P.path_records.clear();
         P.tracks.clear();
         P.ntracks = 0;
+        P.row_order.clear();
+        P.traced_scale.clear();
         bool have_xy = false;
+        std::vector<int> path_nodes;            // traced rows, in callback order
+        std::vector<size_t> table_pos, traced_pos;   // position of every row in callback (= parameter) order
+        size_t row_counter = 0;
         for (size_t c = 0; c < _constraints.size(); ++c) {
             vector_t params = {std::string()};
             std::vector<std::string> pnames = {std::string("")};
-            const fout_mi355x_t blk =
-                std::any_cast<fout_mi355x_t>((*_constraints.at(c))(x, u, params, pnames, tsym, getDt()));
+            const std::any cout_ = (*_constraints.at(c))(x, u, params, pnames, tsym, getDt());
+            if (cout_.type() == typeid(fout_mi355x_vars_t)) {
+                // rows computed with the handles, as ePSOPT's fout_psopt_t of adoubles (etol_psopt_example1.cpp:153-190)
+                if (!traced) die("traced constraint rows need a traced objective and traced dynamics (return mi355x::Var there too)");
+                for (const mi355x::Var& v : std::any_cast<fout_mi355x_vars_t>(cout_)) {
+                    if (v.node < 0) die("constraint callback " + std::to_string(c) + " returned a Var outside the trace");
+                    path_nodes.push_back(v.node);
+                    traced_pos.push_back(row_counter++);
+                }
+                continue;
+            }
+            const fout_mi355x_t blk = std::any_cast<fout_mi355x_t>(cout_);
+            for (size_t q = 0; q < blk.rows.size() + blk.tracks.size(); ++q) table_pos.push_back(row_counter++);
             if (blk.rows.empty() && blk.tracks.empty()) continue;
             if (have_xy && (blk.px != P.px || blk.py != P.py))
                 die("all keep-out rows must act on the same two states");
@@ -216,12 +225,56 @@ void eMI355X::traceCallbacks() {
                 P.path_records.insert(P.path_records.end(), rec.begin(), rec.end());
             }
         }
+        P.npath_traced = path_nodes.size();
+        if (!path_nodes.empty()) {
+            // the two states the traced rows act on (the Jacobian layout holds two partials per row)
+            mi355x::Trace& tr = mi355x::Trace::active();
+            std::vector<int> used;
+            for (int n : path_nodes)
+                for (int v : tr.dependencies(n, (int)getNStates(), (int)getNControls()))
+                    if (std::find(used.begin(), used.end(), v) == used.end()) used.push_back(v);
+            std::sort(used.begin(), used.end());
+            for (int v : used)
+                if (v >= (int)getNStates()) die("traced constraint rows may depend on states (and time), not on controls");
+            if (have_xy) {
+                for (int v : used)
+                    if (v != (int)P.px && v != (int)P.py) die("traced constraint rows must act on the states of the keep-out rows");
+            } else {
+                if (used.size() > 2) die("traced constraint rows may depend on two states; they use " + std::to_string(used.size()));
+                P.px = used.empty() ? 0 : used[0];
+                P.py = used.size() > 1 ? used[1] : (P.px + 1 < getNStates() ? P.px + 1 : (P.px > 0 ? P.px - 1 : 0));
+                if (P.py == P.px) die("a problem with one state cannot carry traced path rows");
+            }
+            // row normalisation (the iteration works on sigma_j c_j): largest value along the straight line between
+            // the boundary states, which for a keep-out row is reached where the line passes closest to its centre
+            std::vector<double> xs(getNStates()), us(getNControls(), 0.0);
+            for (int n : path_nodes) {
+                double ref = 0;
+                for (int q = 0; q <= 32; ++q) {
+                    for (size_t i = 0; i < getNStates(); ++i) xs[i] = getX0()[i] + (getXf()[i] - getX0()[i]) * q / 32.0;
+                    ref = std::max(ref, std::fabs(tr.eval(n, xs, us, P.tf * q / 32.0)));
+                }
+                P.traced_scale.push_back(ref > 0 && std::isfinite(ref) ? 1.0 / ref : 1.0);
+            }
+        }
+        if (traced) {
+            // derivatives and code for the device, once (ePSOPT: ADOL-C tape re-interpreted per evaluation)
+            P.model = EMI_MODEL_SOURCE;
+            P.model_params.clear();
+            std::string gerr;
+            P.model_source = mi355x::Trace::active().generate_model("TracedModel", (int)getNStates(), (int)getNControls(), f_nodes,
+                                                                     cost_node, path_nodes, (int)P.px, (int)P.py, &gerr);
+            if (P.model_source.empty()) die(gerr);
+        }
+        // rows are evaluated table rows first, traced rows after them; bounds arrive in callback order
+        P.row_order = table_pos;
+        P.row_order.insert(P.row_order.end(), traced_pos.begin(), traced_pos.end());
     } catch (std::bad_any_cast& e) {
         _eAny = &e;
         std::cout << "Error in eMI355X callback trace" << std::endl;
         errorHandler();
     }
-    P.npath = P.path_records.size() / EMI_PATH_REC;
+    P.npath = P.path_records.size() / EMI_PATH_REC + P.npath_traced;
 }
 
 // ETOL bounds -> NLP bounds, as ePSOPT::addBounds (reference :125-155): state/control
@@ -245,12 +298,20 @@ void eMI355X::addBounds() {
         P.event_lower[i + ns] = getXf()[i] - getXtol()[i];
         P.event_upper[i + ns] = getXf()[i] + getXtol()[i];
     }
-    P.path_lower.clear();
-    P.path_upper.clear();
+    // one [lbnd, ubnd] pair per path row, taken from _parameters in map order for the rows in callback order
+    // (ePSOPT.cpp:144-149), then put into evaluation order (table rows first, traced rows after them)
+    std::vector<double> lo, up;
     for (const auto& kv : _parameters) {
-        P.path_lower.push_back(kv.second.lbnd);
-        P.path_upper.push_back(kv.second.ubnd);
+        lo.push_back(kv.second.lbnd);
+        up.push_back(kv.second.ubnd);
     }
+    P.path_lower = lo;
+    P.path_upper = up;
+    if (P.row_order.size() == lo.size())
+        for (size_t q = 0; q < lo.size(); ++q) {
+            P.path_lower[q] = lo[P.row_order[q]];
+            P.path_upper[q] = up[P.row_order[q]];
+        }
 }
 
 void eMI355X::setup() {
@@ -325,7 +386,7 @@ void eMI355X::configureDevice(Device* dev) {
     if (P.model == EMI_MODEL_SOURCE) {
         if (!dev->source_installed)      // compiled for gfx950 once per context; meshes come and go
             must(emi_set_model_source(c, "TracedModel", P.model_source.c_str(), (int)P.nstates, (int)P.ncontrols,
-                                      nullptr, 0, isMaximized() ? 1 : 0), c, "emi_set_model_source");
+                                      (int)P.npath_traced, nullptr, 0, isMaximized() ? 1 : 0), c, "emi_set_model_source");
         dev->source_installed = true;
     } else {
         must(emi_set_model(c, P.model, P.model_params.data(), (int)P.model_params.size(), isMaximized() ? 1 : 0), c,
@@ -334,7 +395,7 @@ void eMI355X::configureDevice(Device* dev) {
     must(emi_set_batch(c, 1), c, "emi_set_batch");
     if (P.ntracks)
         must(emi_set_tracks(c, (int)P.ntracks, 1, P.track_x.data(), P.track_y.data()), c, "emi_set_tracks");
-    must(emi_set_path(c, (int)P.npath, 1, P.path_records.data(), (int)P.px, (int)P.py), c, "emi_set_path");
+    must(emi_set_path(c, (int)(P.npath - P.npath_traced), 1, P.path_records.data(), (int)P.px, (int)P.py), c, "emi_set_path");
 }
 
 namespace {
@@ -424,7 +485,9 @@ NlpProblem make_nlp(const Prob& P, NlpEvaluator* ev) {
     nlp.cu = P.path_upper;
     // keep-out rows are iterated on normalised: ellipse / (a^2 b^2), disc / r^2
     nlp.cscale.assign(P.npath, 1.0);
-    for (size_t j = 0; j < P.npath; ++j) {
+    for (size_t j = 0; j < P.npath_traced && j < P.traced_scale.size(); ++j)
+        nlp.cscale[P.npath - P.npath_traced + j] = P.traced_scale[j];
+    for (size_t j = 0; j < P.npath - P.npath_traced; ++j) {
         const double* r = &P.path_records[j * EMI_PATH_REC];
         const int kind = (int)r[0];
         const double ref = kind == EMI_PATH_ELLIPSE ? r[5] * r[6] : (kind == EMI_PATH_DISC ? r[3] : r[2]);
@@ -456,7 +519,7 @@ std::vector<double> initial_guess(const Prob& P) {
         for (int sweep = 0; sweep < 50; ++sweep) {
             bool moved = false;
             for (size_t k = 1; k + 1 < M; ++k) {
-                for (size_t j = 0; j < P.npath; ++j) {
+                for (size_t j = 0; j < P.npath - P.npath_traced; ++j) {       // rows of the record table (traced rows: no geometry known)
                     const double* r = &P.path_records[j * EMI_PATH_REC];
                     const int kind = (int)r[0];
                     double xc, yc, ct = 1, st = 0, asq, bsq;

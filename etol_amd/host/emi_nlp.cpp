@@ -905,7 +905,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             factored = true;
             break;
         }
-        if (!factored) { R.msg = "KKT matrix could not be regularised to the right inertia"; break; }
+        if (!factored) { R.msg = "KKT matrix could not be factorised (still singular after dual regularisation)"; break; }
         dw_used = dw;
 
         // the step in the eliminated quantities

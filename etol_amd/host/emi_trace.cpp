@@ -1,6 +1,8 @@
 // emi_trace.cpp -- see emi_trace.hpp.
 #include "emi_trace.hpp"
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -224,9 +226,69 @@ std::string Trace::emit(const std::vector<int>& outs, const std::vector<std::str
     return o.str();
 }
 
-std::string Trace::generate_model(const std::string& name, int ns, int nc, const std::vector<int>& f, int L) {
+std::vector<int> Trace::dependencies(int out, int ns, int nc) {
+    std::vector<int> deps;
+    std::set<int> seen;
+    std::vector<int> stack = {out};
+    while (!stack.empty()) {
+        const int n = stack.back();
+        stack.pop_back();
+        if (n < 0 || seen.count(n)) continue;
+        seen.insert(n);
+        const Node& nd = _nodes[n];
+        if (nd.op == IN_STATE && nd.a < ns) deps.push_back(nd.a);
+        else if (nd.op == IN_CONTROL && nd.a < nc) deps.push_back(ns + nd.a);
+        else if (nd.op >= ADD) {
+            stack.push_back(nd.a);
+            if (nd.b >= 0) stack.push_back(nd.b);
+        }
+    }
+    std::sort(deps.begin(), deps.end());
+    return deps;
+}
+
+std::string Trace::generate_model(const std::string& name, int ns, int nc, const std::vector<int>& f, int L,
+                                  const std::vector<int>& paths, int px, int py, std::string* err) {
     const int nv = ns + nc;
     auto in_node = [&](int v) { return v < ns ? input(IN_STATE, v) : input(IN_CONTROL, v - ns); };
+    // path rows: first and second derivatives w.r.t. the two path states
+    const int npath = (int)paths.size();
+    std::vector<int> cx(npath, -1), cy(npath, -1);
+    int hxx = -1, hxy = -1, hyy = -1;
+    if (npath > 0) {
+        for (int j = 0; j < npath; ++j) {
+            for (int v : dependencies(paths[j], ns, nc))
+                if (v != px && v != py) {
+                    if (err) *err = "traced constraint row " + std::to_string(j) + " depends on variable " + std::to_string(v) +
+                                    "; rows may depend on the two path states (" + std::to_string(px) + ", " + std::to_string(py) +
+                                    ") and on time";
+                    return std::string();
+                }
+            const std::vector<int> adj = adjoints(paths[j]);
+            const int nx = in_node(px), ny = in_node(py);
+            cx[j] = nx < (int)adj.size() ? adj[nx] : -1;
+            cy[j] = ny < (int)adj.size() ? adj[ny] : -1;
+        }
+        // psi = sum_j mu_j c_j  (mu_j = coefficient input j), second derivatives w.r.t. (px, py)
+        int psi = -1;
+        for (int j = 0; j < npath; ++j) {
+            const int term = binary(MUL, input(IN_COEF, j), paths[j]);
+            psi = psi < 0 ? term : binary(ADD, psi, term);
+        }
+        const std::vector<int> a1 = adjoints(psi);
+        const int nx = in_node(px), ny = in_node(py);
+        const int gx = nx < (int)a1.size() ? a1[nx] : -1, gy = ny < (int)a1.size() ? a1[ny] : -1;
+        if (gx >= 0) {
+            const std::vector<int> a2 = adjoints(gx);
+            hxx = nx < (int)a2.size() ? a2[nx] : -1;
+            hxy = ny < (int)a2.size() ? a2[ny] : -1;
+        }
+        if (gy >= 0) {
+            const std::vector<int> a2 = adjoints(gy);
+            hyy = ny < (int)a2.size() ? a2[ny] : -1;
+            if (hxy < 0) hxy = nx < (int)a2.size() ? a2[nx] : -1;
+        }
+    }
     // first derivatives
     std::vector<std::vector<int>> J(ns, std::vector<int>(nv, -1));
     for (int i = 0; i < ns; ++i) {
@@ -272,7 +334,7 @@ std::string Trace::generate_model(const std::string& name, int ns, int nc, const
 
     std::ostringstream o;
     o << "template <typename T> struct " << name << " {\n";
-    o << "    static constexpr int NS = " << ns << ", NC = " << nc << ", NV = " << nv << ", NPARAM = 0;\n";
+    o << "    static constexpr int NS = " << ns << ", NC = " << nc << ", NV = " << nv << ", NPARAM = 0, NPATH = " << npath << ";\n";
     // f
     o << "    EMI_DEV static void f(const ModelParams<T>&, const T* z, T tk, T* fo) {\n";
     {
@@ -320,6 +382,37 @@ std::string Trace::generate_model(const std::string& name, int ns, int nc, const
     o << "        T cc[NS + 1];\n        cc[0] = cL;\n        for (int i = 0; i < NS; ++i) cc[1 + i] = cf[i];\n";
     o << emit(H, Ht, true, "        ");
     o << "        (void)tk; (void)z; (void)cc;\n    }\n";
+    if (npath > 0) {
+        // path rows: values and partials w.r.t. the two path states
+        o << "    EMI_DEV static void path(const ModelParams<T>&, const T* z, T tk, T* c, T* cx, T* cy) {\n";
+        o << "        for (int j = 0; j < NPATH; ++j) { cx[j] = T(0); cy[j] = T(0); }\n";
+        {
+            std::vector<int> outs;
+            std::vector<std::string> t;
+            for (int j = 0; j < npath; ++j) {
+                outs.push_back(paths[j]);
+                t.push_back("c[" + std::to_string(j) + "]");
+                if (cx[j] >= 0) { outs.push_back(cx[j]); t.push_back("cx[" + std::to_string(j) + "]"); }
+                if (cy[j] >= 0) { outs.push_back(cy[j]); t.push_back("cy[" + std::to_string(j) + "]"); }
+            }
+            o << emit(outs, t, false, "        ");
+        }
+        o << "        (void)tk; (void)z;\n    }\n";
+        o << "    EMI_DEV static void path_hess(const ModelParams<T>&, const T* z, T tk, const T* cc, T* h) {\n";
+        {
+            std::vector<int> outs;
+            std::vector<std::string> t;
+            const int hs[3] = {hxx, hxy, hyy};
+            for (int e = 0; e < 3; ++e) {
+                double c;
+                if (hs[e] < 0 || (is_const(hs[e], &c) && c == 0.0)) continue;
+                outs.push_back(hs[e]);
+                t.push_back("h[" + std::to_string(e) + "]");
+            }
+            o << emit(outs, t, true, "        ");
+        }
+        o << "        (void)tk; (void)z; (void)cc; (void)h;\n    }\n";
+    }
     o << "};\n";
     return o.str();
 }

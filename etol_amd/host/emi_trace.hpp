@@ -40,7 +40,12 @@ class Trace {
 
     // C++ source of  `template <typename T> struct <name> {...}`  with the Model interface of
     // etol_amd/csrc/emi_models.hpp for dynamics f[0..ns), integrand cost L (already sign-free)
-    std::string generate_model(const std::string& name, int ns, int nc, const std::vector<int>& f, int L);
+    // `paths`: traced path rows c_j; they may depend on the two states px, py (and on time) only -- that is what
+    // the Jacobian layout of include/emi355x.h holds per row; generate_model fails (empty string, *err set) otherwise
+    std::string generate_model(const std::string& name, int ns, int nc, const std::vector<int>& f, int L,
+                               const std::vector<int>& paths = {}, int px = 0, int py = 1, std::string* err = nullptr);
+    // the state / control inputs node `out` depends on (indices v < ns: states, else controls)
+    std::vector<int> dependencies(int out, int ns, int nc);
 
     // numeric evaluation on the host (unit tests of the trace itself)
     double eval(int node, const std::vector<double>& x, const std::vector<double>& u, double t,

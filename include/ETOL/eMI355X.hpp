@@ -63,6 +63,9 @@ struct Sol {
 struct Prob {
     std::string name = "ETOL Problem";
     size_t nstates = 0, ncontrols = 0, nodes = 0, npath = 0;
+    std::vector<size_t> row_order;                 // evaluation-order row q is row row_order[q] of the callbacks
+    std::vector<double> traced_scale;              // normalisation of the traced rows inside the NLP iteration
+    size_t npath_traced = 0;                       // of npath: rows traced from constraint callbacks (they follow the table rows)
     int model = -1;
     std::vector<double> model_params;
     std::string model_source;                      // model == EMI_MODEL_SOURCE: struct generated from the traced callbacks

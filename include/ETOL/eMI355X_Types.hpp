@@ -17,7 +17,8 @@
 // and expects back
 //     objective      -> mi355x::ModelTerm with row == -1,  or the mi355x::Var of the integrand
 //     gradient[i]    -> mi355x::ModelTerm with row == i,   or the mi355x::Var of d x_i / dt
-//     constraints[c] -> fout_mi355x_t      (keep-out rows, in path-row order)
+//     constraints[c] -> fout_mi355x_t      (keep-out rows from the library's row kinds, in path-row order)
+//                       or fout_mi355x_vars_t  (rows computed with the handles, traced like the model)
 // A ModelTerm names one of the hand-written device models (include/emi355x.h,
 // EMI_MODEL_*) and its parameter block; Vars are traced expressions that are
 // differentiated and compiled into the same kernels at setup(); the rows of a
@@ -114,6 +115,10 @@ PathBlock track_rows(const std::list<track_t>& tracks, const Symbol& sx, const S
 }  // namespace mi355x
 
 typedef mi355x::PathBlock fout_mi355x_t;
+// Constraint rows computed with the handles, the counterpart of ePSOPT's fout_psopt_t (a vector of adoubles,
+// include/ETOL/ePSOPT_Types.hpp:20): every entry is one path row c(x, t); the rows of one problem may depend
+// on two of the states (and on time).
+typedef std::vector<mi355x::Var> fout_mi355x_vars_t;
 
 }  // namespace ETOL
 #endif

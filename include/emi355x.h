@@ -157,14 +157,17 @@ int emi_set_model(emi_ctx_t ctx, int model, const double* params, int nparams,
  * helpers).  It is compiled for gfx950 here (hiprtc) together with the
  * library's kernel templates; on a compile error the status is EMI_ERR_ARG and
  * emi_last_error() holds the compiler log.  params (<= 16) reach the struct as
- * ModelParams<T>.  Replaces a previous emi_set_model / emi_set_model_source.   */
+ * ModelParams<T>.  npath = number of path rows the struct computes itself
+ * (NPATH, with path() / path_hess(): constraint callbacks traced by the host);
+ * they follow the rows of emi_set_path in RES / VALS and act on its px, py.
+ * Replaces a previous emi_set_model / emi_set_model_source.                    */
 int emi_set_model_source(emi_ctx_t ctx, const char* struct_name, const char* source,
-                         int ns, int nc, const double* params, int nparams,
-                         int maximize);
+                         int ns, int nc, int npath, const double* params,
+                         int nparams, int maximize);
 /* Compile-only check of such a text (no device needed): EMI_OK or EMI_ERR_ARG
  * with up to log_len-1 characters of the compiler log in log (may be NULL).   */
 int emi_check_model_source(const char* struct_name, const char* source, int ns,
-                           int nc, int f32, char* log, size_t log_len);
+                           int nc, int npath, int f32, char* log, size_t log_len);
 int emi_set_batch(emi_ctx_t ctx, int B);
 /* recs: [nsets][np][EMI_PATH_REC]; nsets is 1 (shared) or B (per instance) */
 int emi_set_path(emi_ctx_t ctx, int np, int nsets, const double* recs,

@@ -11,6 +11,7 @@
 #include "emi_nlp.hpp"
 #include "emi_transcribe.hpp"
 #include "emi_trace.hpp"
+#include <cmath>
 
 namespace mx = ETOL::mi355x;
 
@@ -420,6 +421,42 @@ extern "C" const char* harness_traced_model_source(int which) {
         std::vector<int> f;
         for (int i = 0; i < 6; ++i) f.push_back(traced_quad_rhs(x, u, i).node);
         g_out = tr.generate_model("TracedModel", 6, 2, f, traced_quad_cost(u).node);
+    } else if (which == 3) {
+        // a row that uses a third variable: must be refused with a message
+        std::vector<mx::Var> x, u;
+        for (size_t i = 0; i < 6; ++i) x.push_back(mx::Var(mx::Var::STATE, i));
+        for (size_t j = 0; j < 2; ++j) u.push_back(mx::Var(mx::Var::CONTROL, j));
+        std::vector<int> f;
+        for (int i = 0; i < 6; ++i) f.push_back(traced_quad_rhs(x, u, i).node);
+        std::string err;
+        g_out = tr.generate_model("TracedModel", 6, 2, f, traced_quad_cost(u).node, {(x[0] * x[1] + x[2]).node}, 0, 1, &err);
+        if (g_out.empty()) g_out = "ERROR: " + err;
+    } else if (which == 2) {
+        // quadrotor + path rows written as arithmetic: a disc (etol_psopt_example1.cpp:243-247) and the ellipse of the
+        // polygon edge (3.2,2.5)-(3.4,2.6) with the reference's own operations (:163-182); both act on states 0, 1
+        std::vector<mx::Var> x, u;
+        for (size_t i = 0; i < 6; ++i) x.push_back(mx::Var(mx::Var::STATE, i));
+        for (size_t j = 0; j < 2; ++j) u.push_back(mx::Var(mx::Var::CONTROL, j));
+        std::vector<int> f;
+        for (int i = 0; i < 6; ++i) f.push_back(traced_quad_rhs(x, u, i).node);
+        std::vector<int> rows;
+        {
+            const double xc = 4.0, yc = 3.2, r = 0.8;
+            const mx::Var dx = x[0] - xc, dy = x[1] - yc;
+            rows.push_back((r * r - (dx * dx + dy * dy)).node);
+        }
+        {
+            const double xa = 3.2, ya = 2.5, xb = 3.4, yb = 2.6;
+            const double xc = (xb + xa) / 2., m = (yb - ya) / (xb - xa), yc = ya + m * (xc - xa);
+            const double radsq = std::pow(xc - xa, 2.0) + std::pow(yc - ya, 2.0), tt = -1.0 * std::atan2(yc - ya, xc - xa);
+            const mx::Var dx = x[0] - xc, dy = x[1] - yc;
+            const mx::Var delx = std::cos(tt) * dx - std::sin(tt) * dy, dely = std::sin(tt) * dx + std::cos(tt) * dy;
+            const double asq = radsq, bsq = .2 * radsq;
+            rows.push_back((asq * bsq - (bsq * mx::pow(delx, 2.) + asq * mx::pow(dely, 2.))).node);
+        }
+        std::string err;
+        g_out = tr.generate_model("TracedModel", 6, 2, f, traced_quad_cost(u).node, rows, 0, 1, &err);
+        if (g_out.empty()) g_out = "ERROR: " + err;
     } else {
         mx::Var a(mx::Var::STATE, 0), b(mx::Var::STATE, 1), c(mx::Var::CONTROL, 0), t(mx::Var::TIME, 0);
         std::vector<int> f;
@@ -516,8 +553,31 @@ int harness_solve_example1(const char* xml, int with_obstacles, double tol, int 
         for (size_t k = 0; k < tracks->size(); ++k)
             t->addParams({std::pair<PARAM_PAIR>("ball_" + std::to_string(k) + "_0_0",
                                                 {ETOL::var_t::CONTINUOUS, -1000., 0., 0., tspan})});
-        e.obs = [zones](F_ARGS) -> ETOL::scalar_t {
-            return mx::ellipse_rows(*zones, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+        const bool traced_rows = g_traced >= 2;
+        e.obs = [zones, traced_rows](F_ARGS) -> ETOL::scalar_t {
+            if (!traced_rows)
+                return mx::ellipse_rows(*zones, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+            // the reference's own callback body (etol_psopt_example1.cpp:153-190), mx::Var in place of adouble
+            ETOL::fout_mi355x_vars_t fout;
+            const mx::Var xk = std::any_cast<mx::Var>(x.at(0)), yk = std::any_cast<mx::Var>(x.at(1));
+            for (const auto& bd : *zones) {
+                auto curr = bd.begin();
+                auto next = std::next(curr, 1);
+                for (size_t i = 0; i < bd.size(); i++) {
+                    const double xa = curr->at(0), ya = curr->at(1), xb = next->at(0), yb = next->at(1);
+                    const double xc = (xb + xa) / 2., m = (yb - ya) / (xb - xa), yc = ya + m * (xc - xa);
+                    const double radsq = std::pow(xc - xa, 2.0) + std::pow(yc - ya, 2.0);
+                    const double tt = -1.0 * std::atan2(yc - ya, xc - xa);
+                    const mx::Var dx = xk - xc, dy = yk - yc;
+                    const mx::Var delx = std::cos(tt) * dx - std::sin(tt) * dy, dely = std::sin(tt) * dx + std::cos(tt) * dy;
+                    const double asq = radsq, bsq = .2 * radsq;
+                    fout.push_back(asq * bsq - (bsq * mx::pow(delx, 2.) + asq * mx::pow(dely, 2.)));
+                    curr++;
+                    next++;
+                    if (next == bd.end()) next = bd.begin();
+                }
+            }
+            return fout;
         };
         e.saa = [tracks](F_ARGS) -> ETOL::scalar_t {
             return mx::track_rows(*tracks, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));

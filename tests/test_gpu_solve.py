@@ -278,3 +278,27 @@ def test_montecarlo_example_shards_scenarios_over_ranks_and_threads(built):
     for s, c in {**c0, **c1}.items():
         assert abs(c - c_all[s]) < 1e-6 * c_all[s]
     assert len(set(round(c, 3) for c in c_all.values())) > 1          # the scenarios really differ
+
+
+def test_shipped_example_with_the_reference_callbacks_verbatim(H, xmls):
+    """The obstacle callback of src/Examples/PSOPT/etol_psopt_example1.cpp:153-190, typed on mi355x::Var
+    instead of adouble (nine ellipse rows computed with cos/sin/pow arithmetic), traced and compiled into
+    the kernels, next to the moving-disc rows from the record table: same problem, same answer as with
+    the library's ellipse row kind."""
+    base = solve(H, xmls["ocp_2d_ex1.xml"], 1)
+    H.harness_set_traced.argtypes = [C.c_int]
+    H.harness_set_traced(2)
+    try:
+        tr = solve(H, xmls["ocp_2d_ex1.xml"], 1)
+    finally:
+        H.harness_set_traced(0)
+    # the traced rows are normalised differently inside the iteration, so the two runs may pass through different
+    # iterates and stop the mesh refinement at different node counts: compare what is mesh-independent
+    print(f"table rows: cost {base[0]:.8f} on {base[1].shape[1]} nodes; traced rows: cost {tr[0]:.8f} on {tr[1].shape[1]} nodes")
+    g = json.load(open(os.path.join(GOLD, "ocp2d.json")))
+    assert g["cost"] < tr[0] < 1.05 * base[0]          # above the obstacle-free optimum, not worse than the other local solution
+    M = tr[1].shape[1]
+    mesh = O.lgl(M)
+    recs, tx, ty = cases.ocp2d_tables(O.edge_ellipse, O.track_centres, 8.0 * (mesh[0] + 1))
+    RES, _, COST = O.evaluate(0, [], M, mesh, 0.0, 16.0, tr[1][None], tr[2][None], recs, (tx, ty))
+    assert np.abs(RES[0, :2]).max() < 1e-7 and RES[0, 2:].max() < 1e-7 and abs(COST[0] - tr[0]) < 1e-9

@@ -184,3 +184,45 @@ def test_model_source_replaces_and_is_replaced(built):
         assert np.array_equal(p, q)
     for p, q in zip(a, b):
         assert np.abs(p - q).max() / (np.abs(p).max() + 1.0) < 1e-13
+
+
+def test_traced_path_rows_match_the_table_rows(built):
+    """Constraint rows traced from callbacks (a disc and the ellipse of one polygon edge, written with the
+    reference's own operations) against the same rows from the record table of the hand-written path: values,
+    Jacobian entries, Hessian blocks; and mixed with a table row in front of them."""
+    import etol_amd as E
+    from etol_amd import _lib as L
+    from etol_amd import workloads as W
+    M, B = 256, 3
+    X, U, _ = W.quadrotor_batch(5, B, M, 0)
+    disc = np.zeros(L.PATH_REC); disc[:4] = [L.PATH_DISC, 4.0, 3.2, 0.64]
+    ell = E.edge_ellipse(3.2, 2.5, 3.4, 2.6)
+    extra = np.zeros(L.PATH_REC); extra[:4] = [L.PATH_DISC, 6.3, 4.4, 0.49]
+    src = traced_source(2)
+    rng = np.random.default_rng(9)
+    for front in ([], [extra]):
+        tr = E.Evaluator(0)
+        tr.set_mesh(M, 0.0, W.TF)
+        tr.set_model_source("TracedModel", src, 6, 2, npath=2)
+        tr.set_batch(B)
+        tr.set_path(np.array(front).reshape(len(front), L.PATH_REC), 0, 1)
+        bi = E.Evaluator(0)
+        bi.set_mesh(M, 0.0, W.TF)
+        bi.set_model(E.MODEL_QUADROTOR2D, W.QUAD_PARAMS)
+        bi.set_batch(B)
+        bi.set_path(np.array(front + [disc, ell]), 0, 1)
+        assert tr.layout.np == bi.layout.np == len(front) + 2 and tr.layout.nvals == bi.layout.nvals
+        a, b = tr.eval_host(X, U), bi.eval_host(X, U)
+        for p, q in zip(a, b):
+            assert p.shape == q.shape
+            for e in range(p.shape[1]) if p.ndim == 3 else [None]:
+                pe, qe = (p[:, e], q[:, e]) if e is not None else (p, q)
+                assert np.abs(pe - qe).max() <= 1e-13 * (np.abs(qe).max() + 1e-300) + 1e-18, e
+        ref = O.evaluate(E.MODEL_QUADROTOR2D, W.QUAD_PARAMS, M, (tr.tau, tr.w, tr.D), 0.0, W.TF, X, U, np.array(front + [disc, ell]))
+        check(dict(X=X), tr, a, ref)
+        lamF = rng.standard_normal((B, 6, M))
+        lamC = rng.standard_normal((B, len(front) + 2, M))
+        H, Hb = tr.hess_host(X, U, lamF, lamC, 0.8), bi.hess_host(X, U, lamF, lamC, 0.8)
+        assert np.abs(H - Hb).max() / (np.abs(Hb).max() + 1.0) < 1e-13
+        # structure of the Jacobian values is the same object for both
+        assert all(np.array_equal(p, q) for p, q in zip(tr.jac_structure(), bi.jac_structure()))

@@ -108,17 +108,17 @@ def test_traced_every_operation_against_sympy(built, tmp_path):
         assert abs(L - ev(Lc)) < 1e-13 * (abs(ev(Lc)) + 1)
 
 
-def _check_source(src, ns, nc, f32=0, name="TracedModel"):
+def _check_source(src, ns, nc, f32=0, name="TracedModel", npath=0):
     import torch  # noqa: F401
     from etol_amd import _lib
     lib = _lib.load()
     log = C.create_string_buffer(1 << 16)
-    st = lib.emi_check_model_source(name.encode(), src.encode(), ns, nc, f32, log, len(log))
+    st = lib.emi_check_model_source(name.encode(), src.encode(), ns, nc, npath, f32, log, len(log))
     return st, log.value.decode(errors="replace")
 
 
-@pytest.mark.parametrize("which,ns,nc", [(0, 6, 2), (1, 2, 1)])
-def test_generated_model_compiles_against_the_kernel_templates(built, which, ns, nc):
+@pytest.mark.parametrize("which,ns,nc,npath", [(0, 6, 2, 0), (1, 2, 1, 0), (2, 6, 2, 2)])
+def test_generated_model_compiles_against_the_kernel_templates(built, which, ns, nc, npath):
     """hiprtc cross-compiles for gfx950 without a GPU: the generated struct must instantiate the node,
     Hessian and even/odd MFMA defect kernels the library itself is built from."""
     import torch  # noqa: F401
@@ -126,8 +126,11 @@ def test_generated_model_compiles_against_the_kernel_templates(built, which, ns,
     lib.harness_traced_model_source.restype = C.c_char_p
     src = lib.harness_traced_model_source(which).decode()
     for f32 in (0, 1):
-        st, log = _check_source(src, ns, nc, f32)
+        st, log = _check_source(src, ns, nc, f32, npath=npath)
         assert st == 0, log
+    if npath:       # the number of traced rows is part of the contract
+        st, log = _check_source(src, ns, nc, 0, npath=npath + 1)
+        assert st == 1 and "dimensions differ" in log
 
 
 def test_model_source_errors_are_reported(built):
@@ -141,3 +144,74 @@ def test_model_source_errors_are_reported(built):
     assert st == 1 and "dimensions differ" in log
     st, log = _check_source(src, 2, 1, name="not a name")
     assert st == 1
+
+
+PATH_POSTLUDE = r"""
+typedef TracedModel<double> TM;
+extern "C" void traced_path(const double* z, double t, const double* mu, double* c, double* cx, double* cy, double* h) {
+    ModelParams<double> P = {};
+    TM::path(P, z, t, c, cx, cy);
+    h[0] = h[1] = h[2] = 0;
+    TM::path_hess(P, z, t, mu, h);
+}
+"""
+
+
+def test_traced_path_rows_against_the_reference_formulas(built, tmp_path):
+    """Constraint rows written with Var arithmetic exactly as the reference's obstacle callbacks
+    (src/Examples/PSOPT/etol_psopt_example1.cpp:163-182 ellipse per edge, :243-247 disc): values, the two
+    partials per row and the multiplier-weighted second derivatives of the generated code."""
+    import torch  # noqa: F401
+    lib = C.CDLL(os.path.join(HERE, "harness", "libetol_harness.so"))
+    lib.harness_traced_model_source.restype = C.c_char_p
+    src = lib.harness_traced_model_source(2).decode()
+    assert "NPATH = 2" in src and not src.startswith("ERROR")
+    cpp = tmp_path / "path.cpp"
+    cpp.write_text(PRELUDE + src + PATH_POSTLUDE)
+    so = tmp_path / "path.so"
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-o", str(so), str(cpp)])
+    t = C.CDLL(str(so))
+    dp = C.POINTER(C.c_double)
+    t.traced_path.argtypes = [dp, C.c_double, dp, dp, dp, dp, dp]
+    p = lambda a: a.ctypes.data_as(dp)
+
+    def ref(x, y):
+        disc = 0.8 ** 2 - ((x - 4.0) ** 2 + (y - 3.2) ** 2)
+        xa, ya, xb, yb = 3.2, 2.5, 3.4, 2.6
+        xc = (xb + xa) / 2
+        m = (yb - ya) / (xb - xa)
+        yc = ya + m * (xc - xa)
+        radsq = (xc - xa) ** 2 + (yc - ya) ** 2
+        tt = -np.arctan2(yc - ya, xc - xa)
+        dx, dy = x - xc, y - yc
+        delx, dely = np.cos(tt) * dx - np.sin(tt) * dy, np.sin(tt) * dx + np.cos(tt) * dy
+        asq, bsq = radsq, .2 * radsq
+        return np.array([disc, asq * bsq - (bsq * delx ** 2 + asq * dely ** 2)])
+
+    rng = np.random.default_rng(2)
+    for _ in range(5):
+        z = rng.uniform(0, 6, 8)
+        mu = rng.standard_normal(2)
+        c, cx, cy, h = np.zeros(2), np.zeros(2), np.zeros(2), np.zeros(3)
+        t.traced_path(p(z), 0.3, p(mu), p(c), p(cx), p(cy), p(h))
+        assert np.abs(c - ref(z[0], z[1])).max() < 1e-14 * (np.abs(c).max() + 1)
+        e = 1e-6
+        fx = (ref(z[0] + e, z[1]) - ref(z[0] - e, z[1])) / (2 * e)
+        fy = (ref(z[0], z[1] + e) - ref(z[0], z[1] - e)) / (2 * e)
+        assert np.abs(cx - fx).max() < 1e-8 and np.abs(cy - fy).max() < 1e-8
+        # both rows are quadratics: second derivatives are constants, the weighted sum is exact by differences of cx, cy
+        c2, cx2, cy2, h2 = np.zeros(2), np.zeros(2), np.zeros(2), np.zeros(3)
+        zp = z.copy(); zp[0] += 1.0
+        t.traced_path(p(zp), 0.3, p(mu), p(c2), p(cx2), p(cy2), p(h2))
+        zq = z.copy(); zq[1] += 1.0
+        c3, cx3, cy3, h3 = np.zeros(2), np.zeros(2), np.zeros(2), np.zeros(3)
+        t.traced_path(p(zq), 0.3, p(mu), p(c3), p(cx3), p(cy3), p(h3))
+        assert abs(h[0] - mu @ (cx2 - cx)) < 1e-12 and abs(h[1] - mu @ (cy2 - cy)) < 1e-12 and abs(h[2] - mu @ (cy3 - cy)) < 1e-12
+
+
+def test_traced_rows_may_only_depend_on_two_states(built):
+    import torch  # noqa: F401
+    lib = C.CDLL(os.path.join(HERE, "harness", "libetol_harness.so"))
+    lib.harness_traced_model_source.restype = C.c_char_p
+    msg = lib.harness_traced_model_source(3).decode()
+    assert msg.startswith("ERROR") and "depends on variable" in msg
