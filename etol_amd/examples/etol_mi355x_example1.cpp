@@ -93,9 +93,26 @@ ETOL::f_t obsConstraint(ETOL::TrajectoryOptimizer* t) {
                                                 {ETOL::var_t::CONTINUOUS, -1000., 0., 0., tspan})});
         ++i;
     }
+    // One row per polygon edge, computed with the handles like the reference's callback computes it with adoubles
+    // (etol_psopt_example1.cpp:153-190): eMI355X traces the arithmetic, differentiates it and compiles it into the
+    // kernels.  (mx::ellipse_rows(*zones, x0, x1) would hand the same rows to the library's built-in row kind.)
     return [zones](F_ARGS) -> ETOL::scalar_t {
         try {
-            return mx::ellipse_rows(*zones, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+            ETOL::fout_mi355x_vars_t rows;
+            const mx::Var px = std::any_cast<mx::Var>(x.at(0)), py = std::any_cast<mx::Var>(x.at(1));
+            for (const ETOL::border_t& zone : *zones) {
+                const std::vector<ETOL::corner_t> corner(zone.begin(), zone.end());
+                for (size_t i = 0; i < corner.size(); ++i) {
+                    const ETOL::corner_t& p0 = corner[i];
+                    const ETOL::corner_t& p1 = corner[(i + 1) % corner.size()];
+                    double e[EMI_PATH_REC];          // {kind, xc, yc, cos, sin, a^2, b^2, -} of the edge's ellipse
+                    emi_edge_ellipse(p0.at(0), p0.at(1), p1.at(0), p1.at(1), e);
+                    const mx::Var ox = px - e[1], oy = py - e[2];
+                    const mx::Var delx = e[3] * ox - e[4] * oy, dely = e[4] * ox + e[3] * oy;
+                    rows.push_back(e[5] * e[6] - (e[6] * mx::pow(delx, 2.) + e[5] * mx::pow(dely, 2.)));
+                }
+            }
+            return rows;
         } catch (std::bad_any_cast& e) {
             std::cout << "Error in obs" << std::endl << e.what() << std::endl;
             exit(EXIT_FAILURE);

@@ -433,7 +433,7 @@ extern "C" const char* harness_traced_model_source(int which) {
         if (g_out.empty()) g_out = "ERROR: " + err;
     } else if (which == 2) {
         // quadrotor + path rows written as arithmetic: a disc (etol_psopt_example1.cpp:243-247) and the ellipse of the
-        // polygon edge (3.2,2.5)-(3.4,2.6) with the reference's own operations (:163-182); both act on states 0, 1
+        // polygon edge (3.2,2.5)-(3.4,2.6) (:163-182, constants from emi_edge_ellipse); both act on states 0, 1
         std::vector<mx::Var> x, u;
         for (size_t i = 0; i < 6; ++i) x.push_back(mx::Var(mx::Var::STATE, i));
         for (size_t j = 0; j < 2; ++j) u.push_back(mx::Var(mx::Var::CONTROL, j));
@@ -446,13 +446,11 @@ extern "C" const char* harness_traced_model_source(int which) {
             rows.push_back((r * r - (dx * dx + dy * dy)).node);
         }
         {
-            const double xa = 3.2, ya = 2.5, xb = 3.4, yb = 2.6;
-            const double xc = (xb + xa) / 2., m = (yb - ya) / (xb - xa), yc = ya + m * (xc - xa);
-            const double radsq = std::pow(xc - xa, 2.0) + std::pow(yc - ya, 2.0), tt = -1.0 * std::atan2(yc - ya, xc - xa);
-            const mx::Var dx = x[0] - xc, dy = x[1] - yc;
-            const mx::Var delx = std::cos(tt) * dx - std::sin(tt) * dy, dely = std::sin(tt) * dx + std::cos(tt) * dy;
-            const double asq = radsq, bsq = .2 * radsq;
-            rows.push_back((asq * bsq - (bsq * mx::pow(delx, 2.) + asq * mx::pow(dely, 2.))).node);
+            double rec[EMI_PATH_REC];
+            emi_edge_ellipse(3.2, 2.5, 3.4, 2.6, rec);
+            const mx::Var ox = x[0] - rec[1], oy = x[1] - rec[2];
+            const mx::Var delx = rec[3] * ox - rec[4] * oy, dely = rec[4] * ox + rec[3] * oy;
+            rows.push_back((rec[5] * rec[6] - (rec[6] * mx::pow(delx, 2.) + rec[5] * mx::pow(dely, 2.))).node);
         }
         std::string err;
         g_out = tr.generate_model("TracedModel", 6, 2, f, traced_quad_cost(u).node, rows, 0, 1, &err);
@@ -557,24 +555,22 @@ int harness_solve_example1(const char* xml, int with_obstacles, double tol, int 
         e.obs = [zones, traced_rows](F_ARGS) -> ETOL::scalar_t {
             if (!traced_rows)
                 return mx::ellipse_rows(*zones, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
-            // the reference's own callback body (etol_psopt_example1.cpp:153-190), mx::Var in place of adouble
+            // the rows of the reference's obstacle callback (etol_psopt_example1.cpp:153-190) as arithmetic on the
+            // handles: per polygon edge the ellipse constants (emi_edge_ellipse follows the reference term by term),
+            // then  a^2 b^2 - (b^2 delx^2 + a^2 dely^2)  with (delx, dely) the offset rotated into the edge frame
             ETOL::fout_mi355x_vars_t fout;
-            const mx::Var xk = std::any_cast<mx::Var>(x.at(0)), yk = std::any_cast<mx::Var>(x.at(1));
-            for (const auto& bd : *zones) {
-                auto curr = bd.begin();
-                auto next = std::next(curr, 1);
-                for (size_t i = 0; i < bd.size(); i++) {
-                    const double xa = curr->at(0), ya = curr->at(1), xb = next->at(0), yb = next->at(1);
-                    const double xc = (xb + xa) / 2., m = (yb - ya) / (xb - xa), yc = ya + m * (xc - xa);
-                    const double radsq = std::pow(xc - xa, 2.0) + std::pow(yc - ya, 2.0);
-                    const double tt = -1.0 * std::atan2(yc - ya, xc - xa);
-                    const mx::Var dx = xk - xc, dy = yk - yc;
-                    const mx::Var delx = std::cos(tt) * dx - std::sin(tt) * dy, dely = std::sin(tt) * dx + std::cos(tt) * dy;
-                    const double asq = radsq, bsq = .2 * radsq;
+            const mx::Var px = std::any_cast<mx::Var>(x.at(0)), py = std::any_cast<mx::Var>(x.at(1));
+            for (const auto& poly : *zones) {
+                std::vector<ETOL::corner_t> corner(poly.begin(), poly.end());
+                for (size_t i = 0; i < corner.size(); ++i) {
+                    const ETOL::corner_t& p0 = corner[i];
+                    const ETOL::corner_t& p1 = corner[(i + 1) % corner.size()];
+                    double rec[EMI_PATH_REC];
+                    emi_edge_ellipse(p0.at(0), p0.at(1), p1.at(0), p1.at(1), rec);
+                    const double ct = rec[3], st = rec[4], asq = rec[5], bsq = rec[6];
+                    const mx::Var ox = px - rec[1], oy = py - rec[2];
+                    const mx::Var delx = ct * ox - st * oy, dely = st * ox + ct * oy;
                     fout.push_back(asq * bsq - (bsq * mx::pow(delx, 2.) + asq * mx::pow(dely, 2.)));
-                    curr++;
-                    next++;
-                    if (next == bd.end()) next = bd.begin();
                 }
             }
             return fout;

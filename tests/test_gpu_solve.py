@@ -280,11 +280,10 @@ def test_montecarlo_example_shards_scenarios_over_ranks_and_threads(built):
     assert len(set(round(c, 3) for c in c_all.values())) > 1          # the scenarios really differ
 
 
-def test_shipped_example_with_the_reference_callbacks_verbatim(H, xmls):
-    """The obstacle callback of src/Examples/PSOPT/etol_psopt_example1.cpp:153-190, typed on mi355x::Var
-    instead of adouble (nine ellipse rows computed with cos/sin/pow arithmetic), traced and compiled into
-    the kernels, next to the moving-disc rows from the record table: same problem, same answer as with
-    the library's ellipse row kind."""
+def test_shipped_example_with_traced_obstacle_rows(H, xmls):
+    """The obstacle rows of src/Examples/PSOPT/etol_psopt_example1.cpp:153-190 computed with mi355x::Var
+    arithmetic in the callback (nine ellipse rows), traced and compiled into the kernels, next to the
+    moving-disc rows from the record table: a feasible solution of the same problem."""
     base = solve(H, xmls["ocp_2d_ex1.xml"], 1)
     H.harness_set_traced.argtypes = [C.c_int]
     H.harness_set_traced(2)

@@ -187,9 +187,9 @@ def test_model_source_replaces_and_is_replaced(built):
 
 
 def test_traced_path_rows_match_the_table_rows(built):
-    """Constraint rows traced from callbacks (a disc and the ellipse of one polygon edge, written with the
-    reference's own operations) against the same rows from the record table of the hand-written path: values,
-    Jacobian entries, Hessian blocks; and mixed with a table row in front of them."""
+    """Constraint rows traced from callbacks (a disc and the ellipse of one polygon edge, written as Var
+    arithmetic) against the same rows from the record table of the hand-written path: values, Jacobian entries,
+    Hessian blocks; and mixed with a table row in front of them."""
     import etol_amd as E
     from etol_amd import _lib as L
     from etol_amd import workloads as W

@@ -158,9 +158,9 @@ extern "C" void traced_path(const double* z, double t, const double* mu, double*
 
 
 def test_traced_path_rows_against_the_reference_formulas(built, tmp_path):
-    """Constraint rows written with Var arithmetic exactly as the reference's obstacle callbacks
-    (src/Examples/PSOPT/etol_psopt_example1.cpp:163-182 ellipse per edge, :243-247 disc): values, the two
-    partials per row and the multiplier-weighted second derivatives of the generated code."""
+    """Constraint rows written with Var arithmetic, the formulas of the reference's obstacle callbacks
+    (src/Examples/PSOPT/etol_psopt_example1.cpp:163-182 ellipse per edge, :243-247 disc), restated here in
+    numpy: values, the two partials per row and the multiplier-weighted second derivatives of the generated code."""
     import torch  # noqa: F401
     lib = C.CDLL(os.path.join(HERE, "harness", "libetol_harness.so"))
     lib.harness_traced_model_source.restype = C.c_char_p
