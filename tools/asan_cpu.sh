@@ -1,0 +1,44 @@
+#!/bin/bash
+# AddressSanitizer run of the host C++ (loader, trace/codegen, NLP iteration with both Newton-step backends) on the
+# CPU: builds instrumented copies of libetol_mi355x.so / the test harness under /tmp/asan and drives the oracle-backed
+# solves through them.  GPU sanitizers are not available on the pool; the device side is covered by the parity tests.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=/tmp/asan
+mkdir -p $OUT
+cd $ROOT
+FLAGS="-O1 -g -fsanitize=address -fno-omit-frame-pointer -std=c++17 -fPIC -Iinclude -Ietol_amd/host -fopenmp-simd"
+g++ $FLAGS -I/usr/include/libxml2 -shared -o $OUT/libetol_mi355x.so etol_amd/host/TrajectoryOptimizer.cpp etol_amd/host/eMI355X.cpp \
+    etol_amd/host/emi_nlp.cpp etol_amd/host/emi_trace.cpp -Letol_amd/lib -lemi355x -lxml2 -Wl,-rpath,$ROOT/etol_amd/lib
+g++ $FLAGS -shared -o $OUT/libetol_harness.so tests/harness/etol_harness.cpp -L$OUT -letol_mi355x -Letol_amd/lib -lemi355x -ldl \
+    -Wl,-rpath,$OUT -Wl,-rpath,$ROOT/etol_amd/lib
+cat > $OUT/run.py <<PY
+import ctypes as C, os, sys, tempfile
+import numpy as np
+ROOT = "$ROOT"
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import gen_xml_fixtures as G
+H = C.CDLL("$OUT/libetol_harness.so")
+D = C.POINTER(C.c_double)
+H.harness_last_message.restype = C.c_char_p
+H.harness_traced_model_source.restype = C.c_char_p
+for w in (0, 1, 2, 3):
+    print("traced source", w, len(H.harness_traced_model_source(w).decode()))
+xml = G.write_all(tempfile.mkdtemp())["ocp_2d_ex1.xml"]
+H.harness_solve_example1_oracle.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_int, D, C.POINTER(C.c_int), D, D, C.c_int, C.POINTER(C.c_int)]
+H.harness_solve_quadrotor_oracle.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, D, C.POINTER(C.c_int), D, D, C.c_int, C.POINTER(C.c_int)]
+H.harness_set_linear_solver.argtypes = [C.c_char_p]
+orc = (ROOT + "/oracle/liboracle.so").encode()
+for ls in (b"host", b"device"):
+    H.harness_set_linear_solver(ls)
+    for wo in (0, 1):
+        X, U = np.zeros(128), np.zeros(128); cost, M, it = C.c_double(), C.c_int(), C.c_int()
+        rc = H.harness_solve_example1_oracle(xml.encode(), orc, wo, 1e-9, 0, 300, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D), 64, C.byref(it))
+        print("example1", ls, wo, rc, cost.value, it.value)
+    for nd in (0, 2, 5):
+        X, U = np.zeros(6 * 64), np.zeros(2 * 64); cost, M, it = C.c_double(), C.c_int(), C.c_int()
+        rc = H.harness_solve_quadrotor_oracle(orc, 24, 0.16, nd, 1e-8, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D), 64, C.byref(it))
+        print("quadrotor", ls, nd, rc, cost.value, it.value, H.harness_last_message().decode())
+print("asan run complete")
+PY
+cd $OUT && ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python run.py
