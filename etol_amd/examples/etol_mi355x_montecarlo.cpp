@@ -141,6 +141,7 @@ int main(int argc, char** argv) {
     for (int th = 0; th < nthreads; ++th)
         pool.emplace_back([&] {
             for (int s = next++; s < hi; s = next++) results[s - lo] = solve_scenario(s, nsteps, ndiscs, device, traced);
+            ETOL::eMI355X::releaseDevices();     // this thread's idle device contexts
         });
     for (auto& th : pool) th.join();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -91,7 +91,8 @@ PathBlock track_rows(const std::list<track_t>& tracks, const Symbol& sx, const S
 // ---------------------------------------------------------------------------------------------
 struct eMI355X::Device : public mi355x::NlpEvaluator, public mi355x::KktBackend {
     emi_ctx_t ctx = nullptr;
-    bool source_installed = false;       // the traced model's code object is loaded in ctx
+    int device_id = -1;
+    std::string installed_source;        // text of the traced model whose code object is loaded in ctx ("" = none)
     ~Device() override {
         if (ctx) emi_destroy(ctx);
     }
@@ -341,7 +342,18 @@ void eMI355X::setup() {
             std::to_string(_parameters.size()) + " were registered with addParams");
     addBounds();
 
-    _dev.reset(new Device());
+    // a device context (stream, rocBLAS handle, workspaces, compiled model) is expensive to build and cheap to
+    // re-point at another problem: solvers of one thread hand theirs on (Monte-Carlo runs set up thousands)
+    _dev.reset();
+    std::vector<Device*>& pool = device_pool();
+    for (size_t i = 0; i < pool.size(); ++i)
+        if (pool[i]->device_id == _algorithm.device) {
+            _dev.reset(pool[i]);
+            pool.erase(pool.begin() + i);
+            break;
+        }
+    if (!_dev) _dev.reset(new Device());
+    _dev->device_id = _algorithm.device;
     configureDevice(_dev.get());
 
     // algorithm defaults of ePSOPT::setup (:62-72) that have a meaning here
@@ -384,13 +396,14 @@ void eMI355X::configureDevice(Device* dev) {
     emi_ctx_t c = dev->ctx;
     must(emi_set_mesh(c, (int)P.nodes, P.tau.data(), P.w.data(), P.D.data(), P.t0, P.tf), c, "emi_set_mesh");
     if (P.model == EMI_MODEL_SOURCE) {
-        if (!dev->source_installed)      // compiled for gfx950 once per context; meshes come and go
+        if (dev->installed_source != P.model_source)      // compiled for gfx950 once per context; meshes come and go
             must(emi_set_model_source(c, "TracedModel", P.model_source.c_str(), (int)P.nstates, (int)P.ncontrols,
                                       (int)P.npath_traced, nullptr, 0, isMaximized() ? 1 : 0), c, "emi_set_model_source");
-        dev->source_installed = true;
+        dev->installed_source = P.model_source;
     } else {
         must(emi_set_model(c, P.model, P.model_params.data(), (int)P.model_params.size(), isMaximized() ? 1 : 0), c,
              "emi_set_model");
+        dev->installed_source.clear();
     }
     must(emi_set_batch(c, 1), c, "emi_set_batch");
     if (P.ntracks)
@@ -730,6 +743,22 @@ void eMI355X::getTraj() {
 
 void eMI355X::debug() { _algorithm.print_level = 5; }
 
-void eMI355X::close() { _dev.reset(); }
+// per-thread pool of idle device contexts (raw pointers on purpose: nothing is torn down behind the back of the HIP
+// runtime at thread or process exit; releaseDevices() does it explicitly)
+std::vector<eMI355X::Device*>& eMI355X::device_pool() {
+    static thread_local std::vector<Device*> pool;
+    return pool;
+}
+
+void eMI355X::releaseDevices() {
+    std::vector<Device*>& pool = device_pool();
+    for (Device* d : pool) delete d;
+    pool.clear();
+}
+
+void eMI355X::close() {
+    if (_dev && _dev->ctx && device_pool().size() < 2) device_pool().push_back(_dev.release());
+    _dev.reset();
+}
 
 }  // namespace ETOL

@@ -92,7 +92,8 @@ class eMI355X : public TrajectoryOptimizer {
     void setup();    // ETOL configuration -> transcribed NLP on the device
     void solve();    // NLP iteration; fills score and trajectories on success
     void debug();    // per-iteration log (print_level 5), call after setup()
-    void close();    // releases the device context
+    void close();    // hands the device context to this thread's pool of idle contexts (the next setup() reuses it)
+    static void releaseDevices();   // destroys the calling thread's idle contexts (call before a worker thread ends)
 
     mi355x::Alg* getAlgorithm();
     mi355x::Sol* getSolution();
@@ -104,8 +105,9 @@ class eMI355X : public TrajectoryOptimizer {
     mi355x::Prob _problem;
 
  private:
-    struct Device;                       // emi_ctx_t + NlpEvaluator adapter
+    struct Device;                       // emi_ctx_t + NlpEvaluator / KktBackend adapter
     std::unique_ptr<Device> _dev;
+    static std::vector<Device*>& device_pool();
     void traceCallbacks();               // calls every f_t once (see eMI355X_Types.hpp)
     void addBounds();
     void getTraj();
