@@ -509,6 +509,39 @@ NlpProblem make_nlp(const Prob& P, NlpEvaluator* ev) {
     return nlp;
 }
 
+// Nodes of a guess that fall inside a keep-out of the record table are moved radially out of it (ellipse: offset
+// from the centre scaled until the quadratic form reaches 1+margin).  Inside a keep-out the row function is concave
+// with a vanishing gradient at the centre, which is the worst place to start a Newton-type iteration from.
+void repair_guess(const Prob& P, double* xs, double* ys) {
+    const size_t M = P.nodes;
+    if (P.npath - P.npath_traced == 0 || M <= 2) return;
+    const double margin = 0.05;
+    for (int sweep = 0; sweep < 50; ++sweep) {
+        bool moved = false;
+        for (size_t k = 1; k + 1 < M; ++k) {
+            for (size_t j = 0; j < P.npath - P.npath_traced; ++j) {       // rows of the record table (traced rows: no geometry known)
+                const double* r = &P.path_records[j * EMI_PATH_REC];
+                const int kind = (int)r[0];
+                double xc, yc, ct = 1, st = 0, asq, bsq;
+                if (kind == EMI_PATH_ELLIPSE) { xc = r[1]; yc = r[2]; ct = r[3]; st = r[4]; asq = r[5]; bsq = r[6]; }
+                else if (kind == EMI_PATH_DISC) { xc = r[1]; yc = r[2]; asq = bsq = r[3]; }
+                else { const size_t t = (size_t)r[1]; xc = P.track_x[t * M + k]; yc = P.track_y[t * M + k]; asq = bsq = r[2]; }
+                if (!(asq > 0) || !(bsq > 0)) continue;
+                const double dx = xs[k] - xc, dy = ys[k] - yc;
+                double ex = ct * dx - st * dy, ey = st * dx + ct * dy;
+                const double q = ex * ex / asq + ey * ey / bsq;
+                if (q >= 1.0 + 0.5 * margin) continue;
+                if (q < 1e-12) { ex = 0; ey = std::sqrt(bsq * (1.0 + margin)); }      // dead centre: minor axis
+                else { const double g = std::sqrt((1.0 + margin) / q); ex *= g; ey *= g; }
+                xs[k] = xc + ct * ex + st * ey;
+                ys[k] = yc - st * ex + ct * ey;
+                moved = true;
+            }
+        }
+        if (!moved) break;
+    }
+}
+
 std::vector<double> initial_guess(const Prob& P) {
     const size_t ns = P.nstates, nc = P.ncontrols, M = P.nodes;
     std::vector<double> z0((ns + nc) * M, 0.0);
@@ -521,39 +554,7 @@ std::vector<double> initial_guess(const Prob& P) {
         const double b = 0.5 * (P.event_lower[ns + i] + P.event_upper[ns + i]);
         for (size_t k = 0; k < M; ++k) z0[i * M + k] = a + (b - a) * 0.5 * (P.tau[k] + 1.0);
     }
-    // Nodes of the line that fall inside a keep-out are moved radially out of it (ellipse:
-    // offset from the centre scaled until the quadratic form reaches 1+margin).  Inside a
-    // keep-out the row function is concave with a vanishing gradient at the centre, which is
-    // the worst place to start a Newton-type iteration from.
-    if (P.npath > 0 && M > 2) {
-        const double margin = 0.05;
-        double* xs = &z0[P.px * M];
-        double* ys = &z0[P.py * M];
-        for (int sweep = 0; sweep < 50; ++sweep) {
-            bool moved = false;
-            for (size_t k = 1; k + 1 < M; ++k) {
-                for (size_t j = 0; j < P.npath - P.npath_traced; ++j) {       // rows of the record table (traced rows: no geometry known)
-                    const double* r = &P.path_records[j * EMI_PATH_REC];
-                    const int kind = (int)r[0];
-                    double xc, yc, ct = 1, st = 0, asq, bsq;
-                    if (kind == EMI_PATH_ELLIPSE) { xc = r[1]; yc = r[2]; ct = r[3]; st = r[4]; asq = r[5]; bsq = r[6]; }
-                    else if (kind == EMI_PATH_DISC) { xc = r[1]; yc = r[2]; asq = bsq = r[3]; }
-                    else { const size_t t = (size_t)r[1]; xc = P.track_x[t * M + k]; yc = P.track_y[t * M + k]; asq = bsq = r[2]; }
-                    if (!(asq > 0) || !(bsq > 0)) continue;
-                    const double dx = xs[k] - xc, dy = ys[k] - yc;
-                    double ex = ct * dx - st * dy, ey = st * dx + ct * dy;
-                    const double q = ex * ex / asq + ey * ey / bsq;
-                    if (q >= 1.0 + 0.5 * margin) continue;
-                    if (q < 1e-12) { ex = 0; ey = std::sqrt(bsq * (1.0 + margin)); }      // dead centre: minor axis
-                    else { const double g = std::sqrt((1.0 + margin) / q); ex *= g; ey *= g; }
-                    xs[k] = xc + ct * ex + st * ey;
-                    ys[k] = yc - st * ex + ct * ey;
-                    moved = true;
-                }
-            }
-            if (!moved) break;
-        }
-    }
+    repair_guess(P, &z0[P.px * M], &z0[P.py * M]);
     if (P.guess_states.size() == ns * M) std::copy(P.guess_states.begin(), P.guess_states.end(), z0.begin());
     if (P.guess_controls.size() == nc * M)
         std::copy(P.guess_controls.begin(), P.guess_controls.end(), z0.begin() + ns * M);
@@ -600,6 +601,8 @@ void eMI355X::solve() {
         P.guess_states.assign(ns * Mnew, 0.0);
         P.guess_controls.assign(nc * Mnew, 0.0);
         for (size_t i = 0; i < ns; ++i) interp_lgl(tau, w, &r.z[i * M], M, P.tau, &P.guess_states[i * Mnew]);
+        // the interpolant may cut through a keep-out between two old nodes
+        mi355x::repair_guess(P, &P.guess_states[P.px * Mnew], &P.guess_states[P.py * Mnew]);
         for (size_t j = 0; j < nc; ++j) {
             interp_lgl(tau, w, &r.z[(ns + j) * M], M, P.tau, &P.guess_controls[j * Mnew]);
             for (size_t k = 0; k < Mnew; ++k)
@@ -644,9 +647,35 @@ void eMI355X::solve() {
         const size_t target = P.nodes;
         std::vector<size_t> ladder;
         for (size_t m = 33; m < target; m = 2 * m - 1) ladder.push_back(m);
+        // Constraints hold at the nodes only, so a coarse mesh can step over a thin keep-out ("tunnelling") and leave
+        // the finer meshes a start on the wrong side of it.  On the ladder the keep-outs of the record table are
+        // therefore inflated by half the largest node spacing of the straight line between the boundary positions
+        // (LGL nodes are (pi/2) / (m-1) of the span apart at mid-horizon); the requested mesh gets the true sizes back.
+        const std::vector<double> true_records = P.path_records;
+        double span = 0;
+        if (P.event_lower.size() == 2 * ns) {
+            const double dx = 0.5 * (P.event_lower[ns + P.px] + P.event_upper[ns + P.px]) - 0.5 * (P.event_lower[P.px] + P.event_upper[P.px]);
+            const double dy = 0.5 * (P.event_lower[ns + P.py] + P.event_upper[ns + P.py]) - 0.5 * (P.event_lower[P.py] + P.event_upper[P.py]);
+            span = std::sqrt(dx * dx + dy * dy);
+        }
+        auto inflate_records = [&](size_t m) {
+            P.path_records = true_records;
+            if (!_algorithm.inflate_keepouts || !(span > 0)) return;
+            const double delta = 0.5 * span * 1.5707963267948966 / (double)(m - 1);
+            for (size_t j = 0; j < P.npath - P.npath_traced; ++j) {
+                double* rec = &P.path_records[j * EMI_PATH_REC];
+                const int kind = (int)rec[0];
+                auto grow = [&](double& sq) { const double r0 = std::sqrt(std::max(sq, 0.0)) + delta; sq = r0 * r0; };
+                if (kind == EMI_PATH_ELLIPSE) { grow(rec[5]); grow(rec[6]); }
+                else if (kind == EMI_PATH_DISC) grow(rec[3]);
+                else grow(rec[2]);
+            }
+        };
         bool chain_ok = true;
         for (size_t li = 0; li < ladder.size() && chain_ok; ++li) {
-            if (li == 0) { setMesh(ladder[0]); configureDevice(_dev.get()); }
+            inflate_records(ladder[li]);
+            if (li == 0) setMesh(ladder[0]);
+            configureDevice(_dev.get());
             mi355x::NlpOptions o = li == 0 ? opt : warm;
             o.tol = std::max(opt.tol, 1e-6);          // intermediate meshes only feed the next guess
             solve_current_mesh(o);
@@ -656,8 +685,12 @@ void eMI355X::solve() {
                        r.msg.c_str());
             chain_ok = r.ok;
             warm.rho_init = std::max(warm.rho_init, r.rho);     // a penalty weight found too small stays raised
-            if (chain_ok) remesh_with_guess(li + 1 < ladder.size() ? ladder[li + 1] : target);
+            if (chain_ok) {
+                if (li + 1 == ladder.size()) P.path_records = true_records;       // the guess repair below sees the true sizes
+                remesh_with_guess(li + 1 < ladder.size() ? ladder[li + 1] : target);
+            }
         }
+        P.path_records = true_records;
         if (chain_ok) {
             sequenced = true;
         } else {                                       // fall back to the cold start on the requested mesh

@@ -32,6 +32,9 @@ struct Alg {
     int mr_max_iterations = 10;                    // ePSOPT.cpp:70
     double ode_tolerance = 1.e-4;                  // ePSOPT.cpp:71
     int mr_max_nodes = 513;                        // refinement stops adding nodes here
+    bool inflate_keepouts = false;                 // on the sequencing ladder, grow the keep-outs by half the node spacing
+                                                   // (against stepping over thin obstacles; measured: no gain on the
+                                                   // Monte-Carlo sets, off by default)
     bool mesh_sequencing = true;                   // meshes above 80 nodes are reached through 33, 65, 129, ... nodes
     std::string linear_solver = "auto";            // Newton step: "host" (dense LDL^T), "device" (structured
                                                    // factorisation in HBM, emi_kkt_*), "auto" = device above 400 KKT rows
