@@ -126,9 +126,25 @@ ETOL::f_t saaConstraint(ETOL::TrajectoryOptimizer* t) {
     for (size_t i = 0; i < tracks->size(); ++i)
         t->addParams({std::pair<PARAM_PAIR>(paramName("ball", i, 0, 0),
                                             {ETOL::var_t::CONTINUOUS, -1000., 0., 0., tspan})});
+    // One row per moving zone, again as arithmetic on the handles: the zone's centre is its waypoint table
+    // interpolated at the node time k (reference etol_psopt_example1.cpp:233-247).
+    // (mx::track_rows(*tracks, x0, x1) would hand the zones to the library's built-in moving-disc row kind.)
     return [tracks](F_ARGS) -> ETOL::scalar_t {
         try {
-            return mx::track_rows(*tracks, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+            ETOL::fout_mi355x_vars_t rows;
+            const mx::Var px = std::any_cast<mx::Var>(x.at(0)), py = std::any_cast<mx::Var>(x.at(1));
+            const mx::Var time = std::any_cast<mx::Var>(k);
+            for (const ETOL::track_t& trk : *tracks) {
+                std::vector<double> tw, xw, yw;
+                for (const ETOL::traj_elem_t& wp : trk.trajectory) {
+                    tw.push_back(wp.first);
+                    xw.push_back(wp.second.at(0));
+                    yw.push_back(wp.second.at(1));
+                }
+                const mx::Var ox = px - mx::interp1(tw, xw, time), oy = py - mx::interp1(tw, yw, time);
+                rows.push_back(trk.radius * trk.radius - (ox * ox + oy * oy));
+            }
+            return rows;
         } catch (std::bad_any_cast& e) {
             std::cout << "Error in saa" << std::endl << e.what() << std::endl;
             exit(EXIT_FAILURE);

@@ -53,6 +53,8 @@ int Trace::unary(Op op, int a, double c) {
             case LOG: return constant(std::log(va));
             case SQRT: return constant(std::sqrt(va));
             case POWC: return constant(std::pow(va, c));
+            case ABS: return constant(std::fabs(va));
+            case STEP: return constant(va > 0.0 ? 1.0 : 0.0);
             default: break;
         }
     }
@@ -74,10 +76,17 @@ int Trace::binary(Op op, int a, int b) {
             case SUB: return constant(va - vb);
             case MUL: return constant(va * vb);
             case DIV: return constant(va / vb);
+            case MAX: return constant(va > vb ? va : vb);
+            case MIN: return constant(va < vb ? va : vb);
             default: break;
         }
     }
     switch (op) {
+        case MAX:
+        case MIN:
+            if (a == b) return a;
+            if (a > b) std::swap(a, b);
+            break;
         case ADD:
             if (ca && va == 0.0) return b;
             if (cb && vb == 0.0) return a;
@@ -133,6 +142,21 @@ std::vector<int> Trace::adjoints(int out) {
             case LOG: add(nd.a, binary(DIV, g, nd.a)); break;
             case SQRT: add(nd.a, binary(DIV, g, binary(MUL, constant(2.0), n))); break;
             case POWC: add(nd.a, binary(MUL, g, binary(MUL, constant(nd.c), unary(POWC, nd.a, nd.c - 1.0)))); break;
+            // piecewise-linear operations: the derivative of the active branch (a tie takes the second operand)
+            case MAX: {
+                const int sa = unary(STEP, binary(SUB, nd.a, nd.b));
+                add(nd.a, binary(MUL, g, sa));
+                add(nd.b, binary(MUL, g, binary(SUB, constant(1.0), sa)));
+                break;
+            }
+            case MIN: {
+                const int sb = unary(STEP, binary(SUB, nd.b, nd.a));
+                add(nd.a, binary(MUL, g, sb));
+                add(nd.b, binary(MUL, g, binary(SUB, constant(1.0), sb)));
+                break;
+            }
+            case ABS: add(nd.a, binary(MUL, g, binary(SUB, binary(MUL, constant(2.0), unary(STEP, nd.a)), constant(1.0)))); break;
+            case STEP: break;   // piecewise constant
             default: break;   // CONST and inputs: leaves
         }
     }
@@ -162,6 +186,10 @@ double Trace::eval(int node, const std::vector<double>& x, const std::vector<dou
             case LOG: v[n] = std::log(v[nd.a]); break;
             case SQRT: v[n] = std::sqrt(v[nd.a]); break;
             case POWC: v[n] = std::pow(v[nd.a], nd.c); break;
+            case MAX: v[n] = v[nd.a] > v[nd.b] ? v[nd.a] : v[nd.b]; break;
+            case MIN: v[n] = v[nd.a] < v[nd.b] ? v[nd.a] : v[nd.b]; break;
+            case ABS: v[n] = std::fabs(v[nd.a]); break;
+            case STEP: v[n] = v[nd.a] > 0.0 ? 1.0 : 0.0; break;
         }
     }
     return v[node];
@@ -215,6 +243,10 @@ std::string Trace::emit(const std::vector<int>& outs, const std::vector<std::str
             case LOG: o << "emi_log(" << ref(nd.a) << ")"; break;
             case SQRT: o << "emi_sqrt(" << ref(nd.a) << ")"; break;
             case POWC: o << "emi_pow(" << ref(nd.a) << ", T(" << std::scientific << nd.c << "))"; break;
+            case MAX: o << "(" << ref(nd.a) << " > " << ref(nd.b) << " ? " << ref(nd.a) << " : " << ref(nd.b) << ")"; break;
+            case MIN: o << "(" << ref(nd.a) << " < " << ref(nd.b) << " ? " << ref(nd.a) << " : " << ref(nd.b) << ")"; break;
+            case ABS: o << "(" << ref(nd.a) << " < T(0) ? -" << ref(nd.a) << " : " << ref(nd.a) << ")"; break;
+            case STEP: o << "(" << ref(nd.a) << " > T(0) ? T(1) : T(0))"; break;
             default: break;
         }
         o << ";\n";
@@ -450,6 +482,24 @@ Var tan(const Var& a) { return wrap(Trace::active().unary(Trace::TAN, node_of(a)
 Var exp(const Var& a) { return wrap(Trace::active().unary(Trace::EXP, node_of(a))); }
 Var log(const Var& a) { return wrap(Trace::active().unary(Trace::LOG, node_of(a))); }
 Var sqrt(const Var& a) { return wrap(Trace::active().unary(Trace::SQRT, node_of(a))); }
+Var max(const Var& a, const Var& b) { return wrap(Trace::active().binary(Trace::MAX, node_of(a), node_of(b))); }
+Var min(const Var& a, const Var& b) { return wrap(Trace::active().binary(Trace::MIN, node_of(a), node_of(b))); }
+Var abs(const Var& a) { return wrap(Trace::active().unary(Trace::ABS, node_of(a))); }
+// piecewise-linear interpolation of the table (tw, vw) at t, constant outside it:
+//   v_0 + sum_i slope_i * (clamp(t, tw_i, tw_{i+1}) - tw_i)
+Var interp1(const std::vector<double>& tw, const std::vector<double>& vw, const Var& t) {
+    if (tw.size() != vw.size() || tw.empty()) {
+        fprintf(stderr, "mi355x::interp1: table sizes differ or are empty\n");
+        exit(EXIT_FAILURE);
+    }
+    Var out(vw[0]);
+    for (size_t i = 0; i + 1 < tw.size(); ++i) {
+        if (!(tw[i + 1] > tw[i])) continue;
+        const double slope = (vw[i + 1] - vw[i]) / (tw[i + 1] - tw[i]);
+        out = out + slope * (min(max(t, Var(tw[i])), Var(tw[i + 1])) - tw[i]);
+    }
+    return out;
+}
 Var pow(const Var& a, double c) { return wrap(Trace::active().unary(Trace::POWC, node_of(a), c)); }
 
 }  // namespace mi355x

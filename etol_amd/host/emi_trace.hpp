@@ -21,7 +21,8 @@ namespace mi355x {
 
 class Trace {
  public:
-    enum Op { CONST, IN_STATE, IN_CONTROL, IN_TIME, IN_COEF, ADD, SUB, MUL, DIV, NEG, SIN, COS, TAN, EXP, LOG, SQRT, POWC };
+    enum Op { CONST, IN_STATE, IN_CONTROL, IN_TIME, IN_COEF, ADD, SUB, MUL, DIV, MAX, MIN, NEG, SIN, COS, TAN, EXP, LOG, SQRT, POWC,
+              ABS, STEP };    // MAX/MIN binary; STEP(a) = a > 0 ? 1 : 0 (the derivative of max / min / abs)
     struct Node {
         Op op;
         int a, b;        // operand nodes (or input index in a for IN_*)

@@ -41,7 +41,7 @@ namespace mi355x {
 // What x[i], u[j] and k hold when eMI355X calls a callback: a handle into the expression trace of
 // the current setup().  A callback may either ignore the arithmetic and return a descriptor of a
 // built-in device model (mi355x::objective / mi355x::derivative), or compute with the handles --
-// +, -, *, /, sin, cos, tan, exp, log, sqrt, pow(x, c) -- and return the resulting Var.  In the
+// +, -, *, /, sin, cos, tan, exp, log, sqrt, pow(x, c), max, min, abs, interp1 -- and return the resulting Var.  In the
 // second case eMI355X differentiates the recorded expressions symbolically (Jacobian, cost
 // gradient, Lagrangian Hessian), generates a model struct for the hand-written kernel templates
 // and compiles them for gfx950 at setup() (hiprtc): any smooth user model runs in the same
@@ -70,6 +70,12 @@ Var exp(const Var& a);
 Var log(const Var& a);
 Var sqrt(const Var& a);
 Var pow(const Var& a, double c);
+Var max(const Var& a, const Var& b);     // piecewise-linear operations: derivative of the active branch
+Var min(const Var& a, const Var& b);
+Var abs(const Var& a);
+// linear interpolation of a waypoint table at t (constant outside the table), e.g. the centre of a moving
+// exclusion zone at the node time (reference etol_psopt_example1.cpp:233-241)
+Var interp1(const std::vector<double>& t_table, const std::vector<double>& v_table, const Var& t);
 
 struct ModelTerm {
     int model = -1;                 // EMI_MODEL_*

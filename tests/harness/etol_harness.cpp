@@ -421,6 +421,24 @@ extern "C" const char* harness_traced_model_source(int which) {
         std::vector<int> f;
         for (int i = 0; i < 6; ++i) f.push_back(traced_quad_rhs(x, u, i).node);
         g_out = tr.generate_model("TracedModel", 6, 2, f, traced_quad_cost(u).node);
+    } else if (which == 4) {
+        // point mass + moving-disc rows whose centres are waypoint tables interpolated at the node time:
+        // the two tracks of the shipped problem (two waypoints each) and one with four waypoints
+        std::vector<mx::Var> x = {mx::Var(mx::Var::STATE, 0), mx::Var(mx::Var::STATE, 1)};
+        std::vector<mx::Var> u = {mx::Var(mx::Var::CONTROL, 0), mx::Var(mx::Var::CONTROL, 1)};
+        const mx::Var tk(mx::Var::TIME, 0);
+        struct Trk { double r; std::vector<double> t, x, y; };
+        const Trk trks[3] = {{0.5, {0.0, 32.0}, {1.51, 2.00}, {2.00, 2.00}},
+                             {0.5, {0.0, 32.0}, {1.00, 1.00}, {4.00, 3.00}},
+                             {0.4, {0.0, 4.0, 9.0, 16.0}, {3.0, 3.5, 2.5, 4.0}, {1.0, 2.5, 3.0, 2.0}}};
+        std::vector<int> rows;
+        for (const Trk& k : trks) {
+            const mx::Var ox = x[0] - mx::interp1(k.t, k.x, tk), oy = x[1] - mx::interp1(k.t, k.y, tk);
+            rows.push_back((k.r * k.r - (ox * ox + oy * oy)).node);
+        }
+        std::string err;
+        g_out = tr.generate_model("TracedModel", 2, 2, {u[0].node, u[1].node}, (u[0] * u[0] + u[1] * u[1]).node, rows, 0, 1, &err);
+        if (g_out.empty()) g_out = "ERROR: " + err;
     } else if (which == 3) {
         // a row that uses a third variable: must be refused with a message
         std::vector<mx::Var> x, u;
@@ -575,8 +593,26 @@ int harness_solve_example1(const char* xml, int with_obstacles, double tol, int 
             }
             return fout;
         };
-        e.saa = [tracks](F_ARGS) -> ETOL::scalar_t {
-            return mx::track_rows(*tracks, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+        const bool traced_tracks = g_traced >= 3;
+        e.saa = [tracks, traced_tracks](F_ARGS) -> ETOL::scalar_t {
+            if (!traced_tracks)
+                return mx::track_rows(*tracks, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+            // moving discs as arithmetic on the handles: centre = waypoint table interpolated at the node time
+            // (etol_psopt_example1.cpp:233-247), row  r^2 - ((x - xc(t))^2 + (y - yc(t))^2)
+            ETOL::fout_mi355x_vars_t rows;
+            const mx::Var px = std::any_cast<mx::Var>(x.at(0)), py = std::any_cast<mx::Var>(x.at(1));
+            const mx::Var tk = std::any_cast<mx::Var>(k);
+            for (const ETOL::track_t& trk : *tracks) {
+                std::vector<double> tw, xw, yw;
+                for (const ETOL::traj_elem_t& wp : trk.trajectory) {
+                    tw.push_back(wp.first);
+                    xw.push_back(wp.second.at(0));
+                    yw.push_back(wp.second.at(1));
+                }
+                const mx::Var ox = px - mx::interp1(tw, xw, tk), oy = py - mx::interp1(tw, yw, tk);
+                rows.push_back(trk.radius * trk.radius - (ox * ox + oy * oy));
+            }
+            return rows;
         };
         t->setConstraints({&e.obs, &e.saa});
     }

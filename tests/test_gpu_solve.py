@@ -289,8 +289,16 @@ def test_shipped_example_with_traced_obstacle_rows(H, xmls):
     H.harness_set_traced(2)
     try:
         tr = solve(H, xmls["ocp_2d_ex1.xml"], 1)
+        H.harness_set_traced(3)           # the moving-disc rows traced too (waypoint tables through mx::interp1)
+        tr3 = solve(H, xmls["ocp_2d_ex1.xml"], 1)
     finally:
         H.harness_set_traced(0)
+    print(f"all rows traced: cost {tr3[0]:.8f} on {tr3[1].shape[1]} nodes")
+    M3 = tr3[1].shape[1]
+    mesh3 = O.lgl(M3)
+    recs3, tx3, ty3 = cases.ocp2d_tables(O.edge_ellipse, O.track_centres, 8.0 * (mesh3[0] + 1))
+    RES3, _, COST3 = O.evaluate(0, [], M3, mesh3, 0.0, 16.0, tr3[1][None], tr3[2][None], recs3, (tx3, ty3))
+    assert np.abs(RES3[0, :2]).max() < 1e-7 and RES3[0, 2:].max() < 1e-7 and abs(COST3[0] - tr3[0]) < 1e-9
     # the traced rows are normalised differently inside the iteration, so the two runs may pass through different
     # iterates and stop the mesh refinement at different node counts: compare what is mesh-independent
     print(f"table rows: cost {base[0]:.8f} on {base[1].shape[1]} nodes; traced rows: cost {tr[0]:.8f} on {tr[1].shape[1]} nodes")

@@ -226,3 +226,43 @@ def test_traced_path_rows_match_the_table_rows(built):
         assert np.abs(H - Hb).max() / (np.abs(Hb).max() + 1.0) < 1e-13
         # structure of the Jacobian values is the same object for both
         assert all(np.array_equal(p, q) for p, q in zip(tr.jac_structure(), bi.jac_structure()))
+
+
+def test_traced_moving_disc_rows_match_the_track_table(built):
+    """Rows whose centres are waypoint tables interpolated at the node time inside the traced arithmetic
+    (mx::interp1: piecewise linear through max/min) against the library's EMI_PATH_TRACK rows fed by
+    emi_track_centres -- two-waypoint tracks of the shipped problem and a four-waypoint one."""
+    import etol_amd as E
+    from etol_amd import _lib as L
+    from etol_amd import workloads as W
+    tracks = [dict(r=0.5, t=[0.0, 32.0], x=[1.51, 2.00], y=[2.00, 2.00]),
+              dict(r=0.5, t=[0.0, 32.0], x=[1.00, 1.00], y=[4.00, 3.00]),
+              dict(r=0.4, t=[0.0, 4.0, 9.0, 16.0], x=[3.0, 3.5, 2.5, 4.0], y=[1.0, 2.5, 3.0, 2.0])]
+    src = traced_source(4)
+    assert "NPATH = 3" in src
+    for M in (33, 128):
+        B = 2
+        X, U = W.pointmass_batch(3, B, M)
+        tr = E.Evaluator(0)
+        tr.set_mesh(M, 0.0, 16.0)
+        tr.set_model_source("TracedModel", src, 2, 2, npath=3)
+        tr.set_batch(B)
+        tr.set_path(np.zeros((0, L.PATH_REC)), 0, 1)
+        bi = E.Evaluator(0)
+        bi.set_mesh(M, 0.0, 16.0)
+        bi.set_model(E.MODEL_POINTMASS2D, [])
+        bi.set_batch(B)
+        tx, ty, recs = [], [], []
+        for i, k in enumerate(tracks):
+            xc, yc = E.track_centres(k["t"], k["x"], k["y"], bi.node_t)
+            tx.append(xc); ty.append(yc)
+            r = np.zeros(L.PATH_REC); r[0], r[1], r[2] = L.PATH_TRACK, i, k["r"] ** 2
+            recs.append(r)
+        bi.set_tracks(np.array(tx), np.array(ty))
+        bi.set_path(np.array(recs), 0, 1)
+        a, b = tr.eval_host(X, U), bi.eval_host(X, U)
+        for p, q in zip(a, b):
+            assert np.abs(p - q).max() <= 1e-13 * (np.abs(q).max() + 1)
+        lamF = np.random.default_rng(1).standard_normal((B, 2, M))
+        lamC = np.random.default_rng(2).standard_normal((B, 3, M))
+        assert np.abs(tr.hess_host(X, U, lamF, lamC, 0.6) - bi.hess_host(X, U, lamF, lamC, 0.6)).max() < 1e-13

@@ -215,3 +215,34 @@ def test_traced_rows_may_only_depend_on_two_states(built):
     lib.harness_traced_model_source.restype = C.c_char_p
     msg = lib.harness_traced_model_source(3).decode()
     assert msg.startswith("ERROR") and "depends on variable" in msg
+
+
+def test_traced_interp1_rows_against_numpy(built, tmp_path):
+    """mx::interp1 (piecewise linear through max / min) inside traced rows: values and partials of the generated
+    code against numpy.interp, at times inside, at the knots of and outside the waypoint tables."""
+    import torch  # noqa: F401
+    lib = C.CDLL(os.path.join(HERE, "harness", "libetol_harness.so"))
+    lib.harness_traced_model_source.restype = C.c_char_p
+    src = lib.harness_traced_model_source(4).decode()
+    assert "NPATH = 3" in src
+    cpp = tmp_path / "interp.cpp"
+    cpp.write_text(PRELUDE + src + PATH_POSTLUDE)
+    so = tmp_path / "interp.so"
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-o", str(so), str(cpp)])
+    t = C.CDLL(str(so))
+    dp = C.POINTER(C.c_double)
+    t.traced_path.argtypes = [dp, C.c_double, dp, dp, dp, dp, dp]
+    p = lambda a: a.ctypes.data_as(dp)
+    tracks = [(0.5, [0.0, 32.0], [1.51, 2.00], [2.00, 2.00]), (0.5, [0.0, 32.0], [1.00, 1.00], [4.00, 3.00]),
+              (0.4, [0.0, 4.0, 9.0, 16.0], [3.0, 3.5, 2.5, 4.0], [1.0, 2.5, 3.0, 2.0])]
+    rng = np.random.default_rng(4)
+    for tk in (-1.0, 0.0, 1.7, 4.0, 6.5, 9.0, 12.25, 16.0, 20.0, 40.0):
+        z = rng.uniform(0, 5, 4)
+        mu = rng.standard_normal(3)
+        c, cx, cy, h = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+        t.traced_path(p(z), tk, p(mu), p(c), p(cx), p(cy), p(h))
+        for j, (r, tw, xw, yw) in enumerate(tracks):
+            xc, yc = np.interp(tk, tw, xw), np.interp(tk, tw, yw)      # constant outside the table, like interp1
+            assert abs(c[j] - (r * r - ((z[0] - xc) ** 2 + (z[1] - yc) ** 2))) < 1e-13
+            assert abs(cx[j] + 2 * (z[0] - xc)) < 1e-13 and abs(cy[j] + 2 * (z[1] - yc)) < 1e-13
+        assert abs(h[0] + 2 * mu.sum()) < 1e-13 and abs(h[1]) < 1e-13 and abs(h[2] + 2 * mu.sum()) < 1e-13
