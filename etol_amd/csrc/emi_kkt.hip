@@ -45,7 +45,7 @@ struct KktWorkspace {
     double* rhs = nullptr;      // [N][nrhs] column-major
     size_t rhs_elems = 0;
     unsigned char* fixed = nullptr;   // [nv*M]
-    size_t cap_small = 0;       // elements the small buffers were sized for (N)
+    size_t cap_ipiv = 0, cap_Q = 0, cap_J = 0, cap_fixed = 0;     // bytes allocated (contexts are reused across problems)
     int N = 0;
     bool factored = false;
     // method 1 (Schur complement + Cholesky)
@@ -61,7 +61,7 @@ struct KktWorkspace {
     double* T = nullptr;        // [nz][nrhs] work
     double* Cb = nullptr;       // [md][nrhs] work
     size_t T_elems = 0, Cb_elems = 0;
-    size_t cap_schur = 0;
+    size_t cap_Pinv = 0, cap_G = 0, cap_Rk = 0, cap_Doff = 0, cap_W = 0;
     int* flag = nullptr;        // node kernel: a block was not positive definite
     // low-rank correction (kkt_lowrank)
     bool lr_active = false;
@@ -312,6 +312,16 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         hipError_t e_ = (call);                                                            \
         if (e_ != hipSuccess) { *err = std::string(#call) + ": " + hipGetErrorString(e_); return EMI_ERR_HIP; } \
     } while (0)
+#define KKT_ENSURE(ptr, cap, bytes)                                                        \
+    do {                                                                                   \
+        if ((cap) < (size_t)(bytes)) {                                                     \
+            if (ptr) KKT_HIP(hipFree(ptr));                                                \
+            (ptr) = nullptr;                                                               \
+            (cap) = 0;                                                                     \
+            KKT_HIP(hipMalloc((void**)&(ptr), (bytes)));                                   \
+            (cap) = (bytes);                                                               \
+        }                                                                                  \
+    } while (0)
 #define KKT_RB(call)                                                                       \
     do {                                                                                   \
         rocblas_status s_ = (call);                                                        \
@@ -324,18 +334,11 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         KKT_RB(rocblas_set_atomics_mode(w->handle, rocblas_atomics_not_allowed));
     }
     KKT_RB(rocblas_set_stream(w->handle, stream));
-    if (w->cap_small < (size_t)N) {
-        void** small[] = {(void**)&w->ipiv, (void**)&w->info, (void**)&w->Q, (void**)&w->J, (void**)&w->fixed};
-        for (void** b : small)
-            if (*b) { KKT_HIP(hipFree(*b)); *b = nullptr; }
-        w->cap_small = 0;
-        KKT_HIP(hipMalloc(&w->ipiv, (size_t)N * sizeof(rocblas_int)));
-        KKT_HIP(hipMalloc(&w->info, sizeof(rocblas_int)));
-        KKT_HIP(hipMalloc(&w->Q, (size_t)nh * M * sizeof(double)));
-        KKT_HIP(hipMalloc(&w->J, (size_t)ns * nv * M * sizeof(double)));
-        KKT_HIP(hipMalloc(&w->fixed, (size_t)nz));
-        w->cap_small = (size_t)N;
-    }
+    if (!w->info) KKT_HIP(hipMalloc(&w->info, sizeof(rocblas_int)));
+    KKT_ENSURE(w->ipiv, w->cap_ipiv, (size_t)N * sizeof(rocblas_int));
+    KKT_ENSURE(w->Q, w->cap_Q, (size_t)nh * M * sizeof(double));
+    KKT_ENSURE(w->J, w->cap_J, (size_t)ns * nv * M * sizeof(double));
+    KKT_ENSURE(w->fixed, w->cap_fixed, (size_t)nz);
     w->N = N;
     KKT_HIP(hipMemcpyAsync(w->Q, Qblk, (size_t)nh * M * sizeof(double), hipMemcpyHostToDevice, stream));
     KKT_HIP(hipMemcpyAsync(w->J, Jblk, (size_t)ns * nv * M * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -343,23 +346,19 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
     w->M = M; w->ns = ns; w->nv = nv;
     if (method == 1 && nv <= KKT_NV_MAX) {
         const size_t md = (size_t)ns * M;
-        if (w->cap_schur < (size_t)N || w->S_elems < md * md) {
-            void** bufs[] = {(void**)&w->S, (void**)&w->Pinv, (void**)&w->G, (void**)&w->Rk, (void**)&w->Doff, (void**)&w->W,
-                             (void**)&w->flag};
-            for (void** b : bufs)
-                if (*b) { KKT_HIP(hipFree(*b)); *b = nullptr; }
-            w->cap_schur = 0;
+        if (w->S_elems < md * md) {
+            if (w->S) KKT_HIP(hipFree(w->S));
+            w->S = nullptr;
             w->S_elems = 0;
             KKT_HIP(hipMalloc(&w->S, md * md * sizeof(double)));
-            KKT_HIP(hipMalloc(&w->Pinv, (size_t)nv * nv * M * sizeof(double)));
-            KKT_HIP(hipMalloc(&w->G, (size_t)ns * ns * M * sizeof(double)));
-            KKT_HIP(hipMalloc(&w->Rk, (size_t)ns * ns * M * sizeof(double)));
-            KKT_HIP(hipMalloc(&w->Doff, (size_t)M * M * sizeof(double)));
-            KKT_HIP(hipMalloc(&w->W, (size_t)M * M * sizeof(double)));
-            KKT_HIP(hipMalloc(&w->flag, sizeof(int)));
             w->S_elems = md * md;
-            w->cap_schur = (size_t)N;
         }
+        KKT_ENSURE(w->Pinv, w->cap_Pinv, (size_t)nv * nv * M * sizeof(double));
+        KKT_ENSURE(w->G, w->cap_G, (size_t)ns * ns * M * sizeof(double));
+        KKT_ENSURE(w->Rk, w->cap_Rk, (size_t)ns * ns * M * sizeof(double));
+        KKT_ENSURE(w->Doff, w->cap_Doff, (size_t)M * M * sizeof(double));
+        KKT_ENSURE(w->W, w->cap_W, (size_t)M * M * sizeof(double));
+        if (!w->flag) KKT_HIP(hipMalloc(&w->flag, sizeof(int)));
         // S = J Q^-1 J^T squares the conditioning of J; late interior-point iterations (barrier terms of 1e10 in Q)
         // leave it numerically semidefinite.  A dual regularisation of IPOPT's size (its delta_c is 1e-8 mu^1/4),
         // raised x1000 on a failed Cholesky, keeps the factorisation alive; the caller's iterative refinement
@@ -564,6 +563,7 @@ int kkt_solve(KktWorkspace* w, hipStream_t stream, int nz, double* rhs, int nrhs
     KKT_HIP(hipMemcpyAsync(rhs, w->rhs, elems * sizeof(double), hipMemcpyDeviceToHost, stream));
     KKT_HIP(hipStreamSynchronize(stream));
     return EMI_OK;
+#undef KKT_ENSURE
 #undef KKT_HIP
 #undef KKT_RB
 }
