@@ -630,9 +630,8 @@ void eMI355X::solve() {
         }
     };
     mi355x::NlpOptions warm = opt;      // started from an interpolated solution: stay close to it
-    warm.mu_init = 1e-3;
-    warm.bound_push = 1e-4;
-    warm.bound_frac = 1e-4;
+    warm.mu_init = getenv("EMI_WARM_MU") ? atof(getenv("EMI_WARM_MU")) : 1e-5;   // (env: tuning; 1e-3 .. 1e-5 measured, profiles/r01_notes.md)
+    warm.bound_push = warm.bound_frac = getenv("EMI_WARM_PUSH") ? atof(getenv("EMI_WARM_PUSH")) : 1e-4;
     _solution.mesh_iterations = 0;
     _solution.nlp_iterations_total = 0;
     _solution.ode_error = 0;
