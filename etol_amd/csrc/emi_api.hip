@@ -53,6 +53,8 @@ struct emi_ctx_s {
     int sym_ct = 3;               // MFMA kernel variant (emi_symdefect.hip): 3 = LDS-DMA ring, 1/2 = register-staged
     int sym_order = 1;
     int sym_ablate = 0;
+    int small_rows = 24;          // "small_rows": up to this many rows B*ns the skinny defect kernel replaces the MFMA ones
+                                  // (measured at 1024 nodes, 6 states: B = 1 / 2 / 4: 26 / 40 / 68 us per pass against 83 us)
     int overlap_mode = 2;         // 2: two streams; 1: same stream, node kernel then MFMA kernel
     unsigned fused_attr_mask = 0;
     std::vector<double> h_tau, h_w;
@@ -556,7 +558,9 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         HIP_TRY(c, emi::defect_f64_set_attr());
         c->attr_set = true;
     }
-    const bool fused = nodes && defect && overlapped_path(c);
+    // a handful of instances: the MFMA kernels would have a few workgroups to run; a skinny streaming product wins
+    const bool small = defect && !c->f32 && c->B * c->ns <= c->small_rows && emi::defect_small_supported(c->B * c->ns);
+    const bool fused = nodes && defect && !small && overlapped_path(c);
     ProfEvents* pe = nullptr;
     if (c->profile) {
         if (c->prof_used == c->prof.size()) {
@@ -649,7 +653,8 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         } else {
             emi::DefectArgs a{(const double*)dX, (const double*)c->d_D.p, (double*)dRES, c->B * c->ns,
                               c->M, c->ns, nres_of(c)};
-            HIP_TRY(c, emi::launch_defect_f64(a, c->stream));
+            if (small) HIP_TRY(c, emi::launch_defect_small_f64(a, c->stream));
+            else HIP_TRY(c, emi::launch_defect_f64(a, c->stream));
         }
     }
     if (pe) HIP_TRY(c, hipEventRecord(pe->e[2], c->stream));
@@ -866,6 +871,11 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         c->kkt_method = value;
         return EMI_OK;
     }
+    if (strcmp(name, "small_rows") == 0) {
+        if (value < 0) return fail(c, EMI_ERR_ARG, "small_rows must be >= 0 (0 disables the skinny defect kernel)");
+        c->small_rows = value;
+        return EMI_OK;
+    }
     if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }
     if (strcmp(name, "sym_ablate") == 0) { c->sym_ablate = value; return EMI_OK; }   // diagnostics only
     if (strcmp(name, "overlap_mode") == 0) {
@@ -878,7 +888,8 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
 
 int emi_last_path(emi_ctx_t c, int* fused) {
     if (!c || !fused) return EMI_ERR_ARG;
-    *fused = overlapped_path(c) ? 1 : 0;
+    const bool small = !c->f32 && c->B > 0 && c->B * c->ns <= c->small_rows && emi::defect_small_supported(c->B * c->ns);
+    *fused = (!small && overlapped_path(c)) ? 1 : 0;
     return EMI_OK;
 }
 

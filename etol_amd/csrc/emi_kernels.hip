@@ -220,6 +220,56 @@ __global__ __launch_bounds__(256) void emi_defect_f32_kernel(DefectArgsF32 a) {
 }
 
 // ---------------------------------------------------------------------------
+// K4 (fp64, few instances): defect rows += X . D^T as a skinny product.
+// With one or a handful of instances (the single solve of eMI355X::solve, B*ns <= 96 rows) a tiled MFMA kernel
+// has 8 workgroups to run and walks K serially; here the 8 MB of D are simply streamed once by every CU:
+// one wave per output node n reads row n of D coalesced (64 lanes x 8 B per step), multiplies it with the same
+// stretch of every X row (12-96 KB, cache-resident) and wave-reduces the R sums.  No LDS, no barrier.
+// ---------------------------------------------------------------------------
+template <int RC>
+__global__ __launch_bounds__(256) void emi_defect_small_f64_kernel(DefectArgs a) {
+    const int M = a.M, R = a.R;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wid;                 // output node of this wave
+    if (n >= M) return;
+    const double* __restrict__ Dn = a.D + (size_t)n * M;
+    for (int r0 = 0; r0 < R; r0 += RC) {                // row chunks (one chunk for B*ns <= RC)
+        double acc[RC];
+#pragma unroll
+        for (int r = 0; r < RC; ++r) acc[r] = 0.0;
+        for (int j0 = 0; j0 < M; j0 += 256) {           // 4 loads of D in flight per lane
+            double d[4];
+            int jj[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                jj[q] = j0 + q * 64 + lane;
+                d[q] = jj[q] < M ? Dn[jj[q]] : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < RC; ++r) {
+                if (r0 + r < R) {
+                    const double* __restrict__ xr = a.X + (size_t)(r0 + r) * M;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (jj[q] < M) acc[r] += d[q] * xr[jj[q]];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RC; ++r) {
+            double v = acc[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && r0 + r < R) {
+                const int row = r0 + r, inst = row / a.ns, st = row - inst * a.ns;
+                double* o = a.RES + ((size_t)inst * a.nres + st) * M + n;
+                *o += v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------
 template <typename T, class Model, bool DEFROWS>
@@ -291,6 +341,15 @@ hipError_t launch_defect_f64(const DefectArgs& a, hipStream_t s) {
     dim3 grid(mtiles * ntiles), block(256);
     if (a.M % 2 == 0) hipLaunchKernelGGL((emi_defect_f64_kernel<true>), grid, block, lds, s, a);
     else              hipLaunchKernelGGL((emi_defect_f64_kernel<false>), grid, block, lds, s, a);
+    return hipGetLastError();
+}
+
+bool defect_small_supported(int R) { return R <= 96; }
+hipError_t launch_defect_small_f64(const DefectArgs& a, hipStream_t s) {
+    dim3 grid((a.M + 3) / 4), block(256);
+    if (a.R <= 6) hipLaunchKernelGGL((emi_defect_small_f64_kernel<6>), grid, block, 0, s, a);
+    else if (a.R <= 12) hipLaunchKernelGGL((emi_defect_small_f64_kernel<12>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((emi_defect_small_f64_kernel<24>), grid, block, 0, s, a);
     return hipGetLastError();
 }
 

@@ -20,6 +20,8 @@ template <typename T>
 hipError_t launch_nodes(int model, const NodeArgs<T>& a, bool jac, bool defect_rows, hipStream_t s);
 template <typename T> hipError_t launch_hess(int model, const HessArgs<T>& a, hipStream_t s);
 hipError_t launch_defect_f64(const DefectArgs& a, hipStream_t s);
+bool defect_small_supported(int R);
+hipError_t launch_defect_small_f64(const DefectArgs& a, hipStream_t s);
 hipError_t launch_defect_f32(const DefectArgsF32& a, hipStream_t s);
 bool defect_f32_mfma_supported(int M);
 hipError_t launch_defect_f32_mfma(const DefectArgsF32& a, hipStream_t s);

@@ -197,7 +197,7 @@ def test_fused_and_general_kernels_agree(built):
     """The fused kernel (even/odd MFMA split + interleaved node work) and the general two-kernel
     path are two implementations of the same pass; also B off the 16-instance tile."""
     import etol_amd as E
-    for model, M, B, nobs in ((E.MODEL_QUADROTOR2D, 256, 21, 3), (E.MODEL_QUADROTOR2D, 1024, 5, 20),
+    for model, M, B, nobs in ((E.MODEL_QUADROTOR2D, 256, 21, 3), (E.MODEL_QUADROTOR2D, 1024, 3, 20),
                               (E.MODEL_POINTMASS2D, 512, 33, 2)):
         ev = E.Evaluator(0)
         ev.set_mesh(M, 0.0, 12.0)
@@ -213,6 +213,10 @@ def test_fused_and_general_kernels_agree(built):
             recs[:, :, 1:4] = np.random.default_rng(2).uniform(0.5, 3, (B, nobs, 3))
         ev.set_batch(B)
         ev.set_path(recs, 0, 1)
+        small_rows = B * X.shape[1] <= 24          # few instances: the skinny streaming defect kernel is the default
+        assert ev.uses_fused_kernel == (not small_rows)
+        by_default = ev.eval_host(X, U)
+        ev.set_option("small_rows", 0)             # the MFMA paths, whatever the batch
         assert ev.uses_fused_kernel
         fused = ev.eval_host(X, U)
         fused_nojac = ev.eval_host(X, U, flags=E.EVAL_ALL | E.EVAL_NOJAC)
@@ -239,6 +243,8 @@ def test_fused_and_general_kernels_agree(built):
         c = dict(X=X, U=U)
         check(c, ev, fused, ref)
         check(c, ev, general, ref)
+        check(c, ev, by_default, ref)
+        assert np.array_equal(by_default[1], fused[1]) and np.array_equal(by_default[2], fused[2])
         assert np.array_equal(fused[1], general[1])            # node work is the same arithmetic
         assert np.array_equal(fused_nojac[0], fused[0]) and np.array_equal(fused_nojac[2], fused[2])
 

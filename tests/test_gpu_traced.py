@@ -48,6 +48,10 @@ def test_traced_quadrotor_matches_oracle_and_builtin_kernel(built, name, ring):
     import etol_amd as E
     c, tr, bi = _quad_evaluators(name)
     assert tr.layout.model == E.MODEL_SOURCE
+    ref0 = O.evaluate(c["model"], c["params"], c["M"], (tr.tau, tr.w, tr.D), c["t0"], c["tf"], c["X"], c["U"], c.get("recs"))
+    check(c, tr, tr.eval_host(c["X"], c["U"]), ref0)      # default dispatch (few instances: skinny defect kernel)
+    tr.set_option("small_rows", 0)
+    bi.set_option("small_rows", 0)
     assert tr.uses_fused_kernel == ring          # even/odd MFMA kernel instantiated for the traced struct
     got = tr.eval_host(c["X"], c["U"])
     ref = O.evaluate(c["model"], c["params"], c["M"], (tr.tau, tr.w, tr.D), c["t0"], c["tf"], c["X"], c["U"],
@@ -111,8 +115,11 @@ def test_custom_traced_model_against_numpy(built, M, B, ring):
     ev.set_mesh(M, t0, tf)
     ev.set_model_source("TracedModel", traced_source(1), 2, 1)
     ev.set_batch(B)
+    RES0 = ev.eval_host(X, U)[0]                 # default dispatch (skinny defect kernel for B * ns <= 24 rows)
+    ev.set_option("small_rows", 0)
     assert ev.uses_fused_kernel == ring
     RES, VALS, COST = ev.eval_host(X, U)
+    assert (np.abs(RES0 - RES) / (np.einsum("kj,bij->bik", np.abs(ev.D), np.abs(X)) + np.abs(RES) + 1.0)).max() < TOL_DEFECT
     h = (tf - t0) / 2
     rRES, J, g, rcost = _custom_reference(X, U, ev.node_t, ev.D, ev.w, h)
     scale = np.einsum("kj,bij->bik", np.abs(ev.D), np.abs(X)) + np.abs(rRES) + 1.0

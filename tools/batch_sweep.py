@@ -40,7 +40,7 @@ def run(name, model, params, M, B, n_obs, f32=False, overlap=True, steps=None):
     RES, VALS, COST = ev.alloc_outputs()
     work = B * M
     steps = steps or max(20, min(2000, int(2e8 / work)))
-    for _ in range(5):
+    for _ in range(15):
         ev.eval_dev(dX, dU, RES, VALS, COST)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -72,7 +72,7 @@ def main():
     print(json.dumps(rows[-1]), flush=True)
     for B in (16, 256):
         rows.append(run("c5 fixed wing N=4096 (f32, shifted-difference D.X on f32 MFMA)", E.MODEL_FIXEDWING12,
-                        W.FW_PARAMS, 4096, B, 0, f32=True, steps=5))
+                        W.FW_PARAMS, 4096, B, 0, f32=True, steps=40))
         print(json.dumps(rows[-1]), flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "batch_sweep.json"), "w"), indent=1)
