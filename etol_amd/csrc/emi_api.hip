@@ -54,7 +54,7 @@ struct emi_ctx_s {
     int sym_order = 1;
     int sym_ablate = 0;
     int small_rows = 24;          // "small_rows": up to this many rows B*ns the skinny defect kernel replaces the MFMA ones
-                                  // (measured at 1024 nodes, 6 states: B = 1 / 2 / 4: 26 / 40 / 68 us per pass against 83 us)
+                                  // (measured at 1024 nodes, 6 states: B = 1 / 2 / 4: 21 / 29 / 53 us per pass against 83 us)
     int overlap_mode = 2;         // 2: two streams; 1: same stream, node kernel then MFMA kernel
     unsigned fused_attr_mask = 0;
     std::vector<double> h_tau, h_w;

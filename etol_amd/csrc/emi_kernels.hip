@@ -224,46 +224,62 @@ __global__ __launch_bounds__(256) void emi_defect_f32_kernel(DefectArgsF32 a) {
 // With one or a handful of instances (the single solve of eMI355X::solve, B*ns <= 96 rows) a tiled MFMA kernel
 // has 8 workgroups to run and walks K serially; here the 8 MB of D are simply streamed once by every CU:
 // one wave per output node n reads row n of D coalesced (64 lanes x 8 B per step), multiplies it with the same
-// stretch of every X row (12-96 KB, cache-resident) and wave-reduces the R sums.  No LDS, no barrier.
+// stretch of every X row and wave-reduces the R sums.  The X rows go through LDS one K tile at a time (48 KB,
+// shared by the 8 nodes of a workgroup): read straight from L2 they cost 18 us per launch at one instance of 1024 nodes.
 // ---------------------------------------------------------------------------
-template <int RC>
+template <int RC, int KT, int NW>                        // NW nodes per wave, 4 NW per workgroup
 __global__ __launch_bounds__(256) void emi_defect_small_f64_kernel(DefectArgs a) {
+    __shared__ double xs[RC][KT];                        // the X rows of this chunk, one K tile (48 KB)
     const int M = a.M, R = a.R;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int n = blockIdx.x * 4 + wid;                 // output node of this wave
-    if (n >= M) return;
-    const double* __restrict__ Dn = a.D + (size_t)n * M;
+    const int nbase = blockIdx.x * (4 * NW) + wid * NW;
     for (int r0 = 0; r0 < R; r0 += RC) {                // row chunks (one chunk for B*ns <= RC)
-        double acc[RC];
+        double acc[NW][RC];
 #pragma unroll
-        for (int r = 0; r < RC; ++r) acc[r] = 0.0;
-        for (int j0 = 0; j0 < M; j0 += 256) {           // 4 loads of D in flight per lane
-            double d[4];
-            int jj[4];
+        for (int nn = 0; nn < NW; ++nn)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                jj[q] = j0 + q * 64 + lane;
-                d[q] = jj[q] < M ? Dn[jj[q]] : 0.0;
+            for (int r = 0; r < RC; ++r) acc[nn][r] = 0.0;
+        for (int k0 = 0; k0 < M; k0 += KT) {
+            __syncthreads();                             // the previous tile has been consumed
+            for (int idx = threadIdx.x; idx < RC * KT; idx += 256) {
+                const int r = idx / KT, j = idx - r * KT;
+                xs[r][j] = (r0 + r < R && k0 + j < M) ? a.X[(size_t)(r0 + r) * M + k0 + j] : 0.0;
             }
+            __syncthreads();
 #pragma unroll
-            for (int r = 0; r < RC; ++r) {
-                if (r0 + r < R) {
-                    const double* __restrict__ xr = a.X + (size_t)(r0 + r) * M;
+            for (int nn = 0; nn < NW; ++nn) {
+                const int n = nbase + nn;
+                if (n >= M) continue;
+                const double* __restrict__ Dn = a.D + (size_t)n * M + k0;
+                constexpr int NQ = KT / 64 < 8 ? KT / 64 : 8;      // loads of D in flight per lane
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (jj[q] < M) acc[r] += d[q] * xr[jj[q]];
+                for (int s0 = 0; s0 < KT / 64; s0 += NQ) {
+                    double d[NQ];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const int j = (s0 + q) * 64 + lane;
+                        d[q] = k0 + j < M ? Dn[j] : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                        for (int r = 0; r < RC; ++r) acc[nn][r] += d[q] * xs[r][(s0 + q) * 64 + lane];
                 }
             }
         }
 #pragma unroll
-        for (int r = 0; r < RC; ++r) {
-            double v = acc[r];
+        for (int nn = 0; nn < NW; ++nn) {
+            const int n = nbase + nn;
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && r0 + r < R) {
-                const int row = r0 + r, inst = row / a.ns, st = row - inst * a.ns;
-                double* o = a.RES + ((size_t)inst * a.nres + st) * M + n;
-                *o += v;
+            for (int r = 0; r < RC; ++r) {
+                double v = acc[nn][r];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+                if (lane == 0 && n < M && r0 + r < R) {
+                    const int row = r0 + r, inst = row / a.ns, st = row - inst * a.ns;
+                    double* o = a.RES + ((size_t)inst * a.nres + st) * M + n;
+                    *o += v;
+                }
             }
         }
     }
@@ -346,10 +362,10 @@ hipError_t launch_defect_f64(const DefectArgs& a, hipStream_t s) {
 
 bool defect_small_supported(int R) { return R <= 96; }
 hipError_t launch_defect_small_f64(const DefectArgs& a, hipStream_t s) {
-    dim3 grid((a.M + 3) / 4), block(256);
-    if (a.R <= 6) hipLaunchKernelGGL((emi_defect_small_f64_kernel<6>), grid, block, 0, s, a);
-    else if (a.R <= 12) hipLaunchKernelGGL((emi_defect_small_f64_kernel<12>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((emi_defect_small_f64_kernel<24>), grid, block, 0, s, a);
+    dim3 g1((a.M + 3) / 4), g2((a.M + 7) / 8), block(256);
+    if (a.R <= 6) hipLaunchKernelGGL((emi_defect_small_f64_kernel<6, 1024, 1>), g1, block, 0, s, a);
+    else if (a.R <= 12) hipLaunchKernelGGL((emi_defect_small_f64_kernel<12, 512, 1>), g1, block, 0, s, a);
+    else hipLaunchKernelGGL((emi_defect_small_f64_kernel<24, 256, 2>), g2, block, 0, s, a);
     return hipGetLastError();
 }
 
