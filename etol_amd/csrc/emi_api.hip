@@ -693,8 +693,6 @@ int emi_hess_dev(emi_ctx_t c, const void* dX, const void* dU, const void* dLamF,
                  double sigma, void* dH) {
     int st = ready(c);
     if (st) return st;
-    if (c->model == EMI_MODEL_FIXEDWING12)
-        return fail(c, EMI_ERR_UNSUPPORTED, "no second-derivative kernel for the fixed-wing model yet");
     if (!dX || !dU || !dLamF || !dH || (np_total(c) > 0 && !dLamC))
         return fail(c, EMI_ERR_ARG, "emi_hess: null device pointer");
     HIP_TRY(c, hipSetDevice(c->device));

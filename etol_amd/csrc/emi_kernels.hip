@@ -344,6 +344,7 @@ hipError_t launch_hess(int model, const HessArgs<T>& a, hipStream_t s) {
     switch (model) {
         case 0: hipLaunchKernelGGL((emi_hess_kernel<T, PointMass2D<T>>), grid, block, 0, s, a); break;
         case 1: hipLaunchKernelGGL((emi_hess_kernel<T, Quadrotor2D<T>>), grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((emi_hess_kernel<T, FixedWing12<T>>), grid, block, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -263,9 +263,367 @@ template <typename T> struct FixedWing12 {
         for (int v = 0; v < 12; ++v) g[v] = T(0);
         for (int v = 12; v < 16; ++v) g[v] = T(2) * P.p[15] * z[v];
     }
-    // Second derivatives of the fixed-wing model are not hand-written yet; the
-    // host refuses emi_hess_* for this model (EMI_ERR_UNSUPPORTED).
-    EMI_DEV static void hess(const ModelParams<T>&, const T*, T, T, const T*, T*) {}
+    // Second derivatives: GENERATED, not hand-written -- the equations of f() above written once more on the
+    // expression trace of etol_amd/host/emi_trace.cpp with the parameter block as inputs, differentiated twice
+    // (tests/harness/etol_harness.cpp harness_fixedwing_hess_body; tests/test_trace.py checks that this text is
+    // what the generator emits and compares it with the sympy Hessian of tests/golden/models.json).
+    EMI_DEV static void hess(const ModelParams<T>& P, const T* z, T, T cL, const T* cf, T* H) {
+        T cc[NS + 1];
+        cc[0] = cL;
+        for (int i = 0; i < NS; ++i) cc[1 + i] = cf[i];
+        // ---- generated body begin ----
+        const T v16 = emi_sin(z[3]);
+        const T v17 = emi_cos(z[3]);
+        const T v18 = emi_sin(z[4]);
+        const T v19 = emi_cos(z[4]);
+        const T v20 = emi_sin(z[5]);
+        const T v21 = emi_cos(z[5]);
+        const T v23 = T(1.00000000000000000e+00) / v19;
+        const T v24 = v18 * v23;
+        const T v32 = T(1.00000000000000000e+00) / P.p[13];
+        const T v35 = v17 * v18;
+        const T v40 = v16 * v18;
+        const T v64 = -v18;
+        const T v68 = z[11] * v17;
+        const T v69 = z[10] * v16;
+        const T v70 = v68 + v69;
+        const T v101 = v16 * P.p[4];
+        const T v109 = v17 * P.p[4];
+        const T v131 = P.p[2] - P.p[3];
+        const T v136 = P.p[3] - P.p[1];
+        const T v141 = P.p[1] - P.p[2];
+        const T v193 = P.p[15] * cc[0];
+        const T v203 = cc[12] / P.p[3];
+        const T v211 = cc[11] / P.p[2];
+        const T v223 = cc[10] / P.p[1];
+        const T v267 = -cc[9];
+        const T v274 = v109 * cc[9];
+        const T v275 = v19 * cc[9];
+        const T v276 = P.p[4] * v275;
+        const T v282 = -cc[8];
+        const T v290 = v101 * cc[8];
+        const T v291 = v274 + v290;
+        const T v292 = v19 * cc[8];
+        const T v293 = P.p[4] * v292;
+        const T v301 = -cc[7];
+        const T v310 = P.p[4] * v301;
+        const T v313 = cc[7] / P.p[0];
+        const T v328 = -v313;
+        const T v331 = P.p[5] * v328;
+        const T v343 = v70 * cc[6];
+        const T v344 = v23 * cc[6];
+        const T v345 = -cc[5];
+        const T v348 = z[10] * cc[5];
+        const T v349 = v276 + v348;
+        const T v352 = z[11] * v345;
+        const T v353 = v293 + v352;
+        const T v355 = v70 * cc[4];
+        const T v356 = v24 * cc[4];
+        const T v357 = v344 + v356;
+        const T v358 = v16 * v357;
+        const T v360 = z[10] * v357;
+        const T v361 = v353 + v360;
+        const T v362 = v17 * v357;
+        const T v364 = z[11] * v357;
+        const T v365 = v349 + v364;
+        const T v368 = z[6] * cc[3];
+        const T v369 = -v368;
+        const T v370 = v310 + v369;
+        const T v373 = z[7] * cc[3];
+        const T v374 = v19 * v373;
+        const T v375 = v361 + v374;
+        const T v376 = v16 * v373;
+        const T v377 = v291 + v376;
+        const T v380 = z[8] * cc[3];
+        const T v381 = v19 * v380;
+        const T v382 = v365 + v381;
+        const T v383 = v17 * v380;
+        const T v384 = v377 + v383;
+        const T v387 = z[6] * cc[2];
+        const T v388 = v20 * v387;
+        const T v389 = v384 + v388;
+        const T v390 = v19 * v387;
+        const T v393 = z[7] * cc[2];
+        const T v394 = v40 * v393;
+        const T v395 = v390 + v394;
+        const T v396 = v20 * v393;
+        const T v397 = v21 * v393;
+        const T v398 = v382 + v397;
+        const T v399 = v17 * v393;
+        const T v402 = z[8] * cc[2];
+        const T v403 = -v402;
+        const T v404 = v35 * v402;
+        const T v405 = v395 + v404;
+        const T v406 = v20 * v402;
+        const T v407 = v21 * v403;
+        const T v408 = v375 + v407;
+        const T v409 = v16 * v403;
+        const T v410 = v399 + v409;
+        const T v413 = z[6] * cc[1];
+        const T v414 = v21 * v413;
+        const T v415 = v389 + v414;
+        const T v416 = v19 * v413;
+        const T v417 = v410 + v416;
+        const T v420 = z[7] * cc[1];
+        const T v421 = -v420;
+        const T v422 = v40 * v420;
+        const T v423 = v417 + v422;
+        const T v424 = v21 * v420;
+        const T v425 = v396 + v424;
+        const T v426 = v18 * v425;
+        const T v427 = v408 + v426;
+        const T v428 = v16 * v425;
+        const T v429 = v370 + v428;
+        const T v430 = v20 * v421;
+        const T v431 = v398 + v430;
+        const T v432 = v17 * v421;
+        const T v433 = v405 + v432;
+        const T v436 = z[8] * cc[1];
+        const T v437 = v35 * v436;
+        const T v438 = v423 + v437;
+        const T v439 = v21 * v436;
+        const T v440 = v406 + v439;
+        const T v441 = v18 * v440;
+        const T v442 = v431 + v441;
+        const T v443 = v17 * v440;
+        const T v444 = v429 + v443;
+        const T v445 = v20 * v436;
+        const T v446 = v427 + v445;
+        const T v447 = v16 * v436;
+        const T v448 = v433 + v447;
+        const T v453 = v23 * v355;
+        const T v454 = v444 + v453;
+        const T v455 = v18 * v355;
+        const T v456 = v343 + v455;
+        const T v459 = v23 * v456;
+        const T v460 = v459 / v19;
+        const T v461 = -v460;
+        const T v462 = v415 + v461;
+        const T v476 = -v442;
+        const T v533 = v17 * v345;
+        const T v568 = v16 * v446;
+        const T v569 = -v568;
+        const T v570 = v17 * v476;
+        const T v571 = v569 + v570;
+        const T v572 = -v462;
+        const T v573 = v18 / v19;
+        const T v574 = v18 * v460;
+        const T v575 = v574 / v19;
+        const T v576 = -v575;
+        const T v577 = v454 + v576;
+        const T v578 = v456 * v573;
+        const T v579 = v23 * v573;
+        const T v580 = v355 * v579;
+        const T v581 = v572 + v580;
+        const T v582 = v18 * v579;
+        const T v583 = v19 * v355;
+        const T v584 = v578 + v583;
+        const T v585 = v19 * v23;
+        const T v586 = v582 + v585;
+        const T v587 = v19 * v440;
+        const T v592 = v19 * v425;
+        const T v624 = v64 * v380;
+        const T v625 = v587 + v624;
+        const T v630 = v64 * v373;
+        const T v631 = v592 + v630;
+        const T v642 = cc[4] * v586;
+        const T v644 = cc[6] * v579;
+        const T v645 = v642 + v644;
+        const T v650 = v64 * cc[8];
+        const T v652 = v64 * cc[9];
+        const T v654 = P.p[4] * v652;
+        const T v655 = v625 + v654;
+        const T v658 = P.p[4] * v650;
+        const T v659 = v631 + v658;
+        const T v663 = z[10] * v645;
+        const T v664 = v659 + v663;
+        const T v666 = z[11] * v645;
+        const T v667 = v655 + v666;
+        const T v669 = v23 * v584;
+        const T v670 = v669 / v19;
+        const T v671 = -v670;
+        const T v672 = v577 + v671;
+        const T v677 = v18 * v672;
+        const T v678 = -v677;
+        const T v679 = v19 * v581;
+        const T v680 = v678 + v679;
+        const T v681 = v16 * v667;
+        const T v682 = -v681;
+        const T v683 = v17 * v664;
+        const T v684 = v682 + v683;
+        const T v685 = -v438;
+        const T v686 = -v20;
+        const T v687 = v436 * v686;
+        const T v692 = v21 * v421;
+        const T v693 = v420 * v686;
+        const T v699 = v413 * v686;
+        const T v704 = v403 * v686;
+        const T v705 = v439 + v704;
+        const T v707 = v21 * v402;
+        const T v708 = v687 + v707;
+        const T v714 = v393 * v686;
+        const T v715 = v692 + v714;
+        const T v717 = v397 + v693;
+        const T v723 = v21 * v387;
+        const T v724 = v699 + v723;
+        const T v728 = v18 * v717;
+        const T v729 = v705 + v728;
+        const T v730 = v16 * v717;
+        const T v731 = v18 * v708;
+        const T v732 = v715 + v731;
+        const T v733 = v17 * v708;
+        const T v734 = v730 + v733;
+        const T v735 = v20 * v448;
+        const T v736 = -v735;
+        const T v737 = v21 * v685;
+        const T v738 = v736 + v737;
+        const T v739 = v18 * v724;
+        const T v740 = -v739;
+        const T v741 = v19 * v734;
+        const T v742 = v740 + v741;
+        const T v743 = v16 * v732;
+        const T v744 = -v743;
+        const T v745 = v17 * v729;
+        const T v746 = v744 + v745;
+        const T v748 = -cc[3];
+        const T v749 = v20 * cc[2];
+        const T v750 = v19 * cc[2];
+        const T v751 = v21 * cc[1];
+        const T v752 = v749 + v751;
+        const T v753 = v19 * cc[1];
+        const T v754 = v20 * v753;
+        const T v755 = -v754;
+        const T v756 = v21 * v750;
+        const T v757 = v755 + v756;
+        const T v758 = v18 * v752;
+        const T v759 = -v758;
+        const T v760 = v19 * v748;
+        const T v761 = v759 + v760;
+        const T v767 = v19 * cc[3];
+        const T v768 = v16 * cc[3];
+        const T v769 = v40 * cc[2];
+        const T v770 = v21 * cc[2];
+        const T v771 = v17 * cc[2];
+        const T v772 = -cc[1];
+        const T v773 = v40 * cc[1];
+        const T v774 = v771 + v773;
+        const T v775 = v758 + v767;
+        const T v776 = v16 * v752;
+        const T v777 = v20 * v772;
+        const T v778 = v770 + v777;
+        const T v779 = v17 * v772;
+        const T v780 = v769 + v779;
+        const T v781 = v20 * v774;
+        const T v782 = -v781;
+        const T v783 = v21 * v780;
+        const T v784 = v782 + v783;
+        const T v785 = v18 * v768;
+        const T v786 = -v785;
+        const T v787 = v19 * v776;
+        const T v788 = v786 + v787;
+        const T v789 = v16 * v778;
+        const T v790 = -v789;
+        const T v791 = v17 * v775;
+        const T v792 = v790 + v791;
+        const T v794 = v32 * P.p[7];
+        const T v796 = P.p[9] * v794;
+        const T v797 = v331 * v796;
+        const T v799 = v331 * v794;
+        const T v820 = P.p[9] * v799;
+        const T v821 = v797 + v820;
+        const T v824 = P.p[7] * v821;
+        const T v827 = v32 * v824;
+        const T v830 = v17 * cc[3];
+        const T v831 = -cc[2];
+        const T v832 = v35 * cc[2];
+        const T v833 = v21 * v831;
+        const T v834 = v16 * v831;
+        const T v835 = v35 * cc[1];
+        const T v836 = v834 + v835;
+        const T v837 = v17 * v752;
+        const T v838 = v20 * cc[1];
+        const T v839 = v833 + v838;
+        const T v840 = v16 * cc[1];
+        const T v841 = v832 + v840;
+        const T v846 = v20 * v836;
+        const T v847 = -v846;
+        const T v848 = v21 * v841;
+        const T v849 = v847 + v848;
+        const T v850 = v18 * v830;
+        const T v851 = -v850;
+        const T v852 = v19 * v837;
+        const T v853 = v851 + v852;
+        const T v854 = v16 * v775;
+        const T v855 = -v854;
+        const T v856 = v17 * v839;
+        const T v857 = v855 + v856;
+        const T v863 = v136 * v211;
+        const T v869 = v141 * v203;
+        const T v881 = v16 * cc[4];
+        const T v883 = v16 * cc[6];
+        const T v886 = v131 * v223;
+        const T v906 = v23 * v881;
+        const T v907 = v18 * v881;
+        const T v908 = v883 + v907;
+        const T v910 = v23 * v908;
+        const T v911 = v910 / v19;
+        const T v912 = -v911;
+        const T v913 = v18 * v912;
+        const T v914 = -v913;
+        const T v915 = v19 * v906;
+        const T v916 = v914 + v915;
+        const T v917 = v16 * cc[5];
+        const T v918 = -v917;
+        const T v919 = v362 + v918;
+        const T v920 = v17 * cc[4];
+        const T v922 = v17 * cc[6];
+        const T v943 = v23 * v920;
+        const T v944 = v18 * v920;
+        const T v945 = v922 + v944;
+        const T v947 = v23 * v945;
+        const T v948 = v947 / v19;
+        const T v949 = -v948;
+        const T v950 = v18 * v949;
+        const T v951 = -v950;
+        const T v952 = v19 * v943;
+        const T v953 = v951 + v952;
+        const T v954 = -v358;
+        const T v955 = v533 + v954;
+        const T v960 = v193 * T(2.00000000000000000e+00);
+        H[9] += v571;
+        H[13] += v684;
+        H[14] += v680;
+        H[18] += v746;
+        H[19] += v742;
+        H[20] += v738;
+        H[25] += v761;
+        H[26] += v757;
+        H[31] += v792;
+        H[32] += v788;
+        H[33] += v784;
+        H[39] += v857;
+        H[40] += v853;
+        H[41] += v849;
+        H[44] += v827;
+        H[52] += v267;
+        H[53] += cc[8];
+        H[58] += v919;
+        H[59] += v916;
+        H[61] += cc[9];
+        H[63] += v301;
+        H[64] += v869;
+        H[69] += v955;
+        H[70] += v953;
+        H[72] += v282;
+        H[73] += cc[7];
+        H[75] += v863;
+        H[76] += v886;
+        H[90] += v960;
+        H[104] += v960;
+        H[119] += v960;
+        H[135] += v960;
+        // ---- generated body end ----
+    }
 };
 
 }  // namespace emi

@@ -174,6 +174,7 @@ double Trace::eval(int node, const std::vector<double>& x, const std::vector<dou
             case IN_CONTROL: v[n] = u.at(nd.a); break;
             case IN_TIME: v[n] = t; break;
             case IN_COEF: v[n] = coef.at(nd.a); break;
+            case IN_PARAM: v[n] = param_values.at(nd.a); break;
             case ADD: v[n] = v[nd.a] + v[nd.b]; break;
             case SUB: v[n] = v[nd.a] - v[nd.b]; break;
             case MUL: v[n] = v[nd.a] * v[nd.b]; break;
@@ -223,6 +224,7 @@ std::string Trace::emit(const std::vector<int>& outs, const std::vector<std::str
             case IN_CONTROL: r << "z[NS + " << nd.a << "]"; return r.str();
             case IN_TIME: return "tk";
             case IN_COEF: r << "cc[" << nd.a << "]"; return r.str();
+            case IN_PARAM: r << "P.p[" << nd.a << "]"; return r.str();
             default: r << "v" << n; return r.str();
         }
     };
@@ -447,6 +449,37 @@ std::string Trace::generate_model(const std::string& name, int ns, int nc, const
     }
     o << "};\n";
     return o.str();
+}
+
+std::string Trace::generate_hess_body(int ns, int nc, const std::vector<int>& f, int L) {
+    const int nv = ns + nc;
+    auto in_node = [&](int v) { return v < ns ? input(IN_STATE, v) : input(IN_CONTROL, v - ns); };
+    int phi = binary(MUL, input(IN_COEF, 0), L);
+    for (int i = 0; i < ns; ++i) phi = binary(ADD, phi, binary(MUL, input(IN_COEF, 1 + i), f[i]));
+    std::vector<int> g(nv, -1);
+    {
+        const std::vector<int> adj = adjoints(phi);
+        for (int v = 0; v < nv; ++v) {
+            const int n = in_node(v);
+            g[v] = n < (int)adj.size() ? adj[n] : -1;
+        }
+    }
+    std::vector<int> H;
+    std::vector<std::string> Ht;
+    for (int v = 0; v < nv; ++v) {
+        std::vector<int> adj;
+        if (g[v] >= 0) adj = adjoints(g[v]);
+        for (int q = 0; q <= v; ++q) {
+            const int n = in_node(q);
+            int h = (g[v] >= 0 && n < (int)adj.size()) ? adj[n] : -1;
+            double c;
+            if (h >= 0 && is_const(h, &c) && c == 0.0) h = -1;
+            if (h < 0) continue;
+            H.push_back(h);
+            Ht.push_back("H[" + std::to_string(v * (v + 1) / 2 + q) + "]");
+        }
+    }
+    return emit(H, Ht, true, "        ");
 }
 
 // ---- Var arithmetic (declared in include/ETOL/eMI355X_Types.hpp) -------------------------------

@@ -21,8 +21,9 @@ namespace mi355x {
 
 class Trace {
  public:
-    enum Op { CONST, IN_STATE, IN_CONTROL, IN_TIME, IN_COEF, ADD, SUB, MUL, DIV, MAX, MIN, NEG, SIN, COS, TAN, EXP, LOG, SQRT, POWC,
-              ABS, STEP };    // MAX/MIN binary; STEP(a) = a > 0 ? 1 : 0 (the derivative of max / min / abs)
+    enum Op { CONST, IN_STATE, IN_CONTROL, IN_TIME, IN_COEF, IN_PARAM, ADD, SUB, MUL, DIV, MAX, MIN, NEG, SIN, COS, TAN, EXP, LOG, SQRT, POWC,
+              ABS, STEP };    // MAX/MIN binary; STEP(a) = a > 0 ? 1 : 0 (the derivative of max / min / abs);
+                              // IN_PARAM a: entry a of the model's parameter block (P.p[a] in generated code)
     struct Node {
         Op op;
         int a, b;        // operand nodes (or input index in a for IN_*)
@@ -51,6 +52,11 @@ class Trace {
     // numeric evaluation on the host (unit tests of the trace itself)
     double eval(int node, const std::vector<double>& x, const std::vector<double>& u, double t,
                 const std::vector<double>& coef = {}) const;
+
+    // C++ statements adding the Lagrangian Hessian  cL*L_zz + sum_i cf[i]*f_i,zz  into H (packed lower triangle): the body of
+    // a model's hess(); used to generate the second derivatives of hand-written models (parameters as IN_PARAM inputs)
+    std::string generate_hess_body(int ns, int nc, const std::vector<int>& f, int L);
+    std::vector<double> param_values;    // values of the IN_PARAM inputs for eval()
 
     static Trace& active();
 

@@ -409,6 +409,44 @@ extern "C" int harness_solve_quadrotor_oracle(const char* oracle_so, int nsteps,
     return 0;
 }
 
+// Body of FixedWing12::hess (etol_amd/csrc/emi_models.hpp), generated: the model's equations written once more on
+// mx::Var with the parameter block as IN_PARAM inputs, second derivatives by the trace.  The text is pasted into
+// emi_models.hpp; tests/test_trace.py checks that what is checked in there is what this generates.
+extern "C" const char* harness_fixedwing_hess_body(void) {
+    mx::Trace& tr = mx::Trace::active();
+    tr.clear();
+    auto par = [&](int i) { mx::Var v; v.kind = mx::Var::EXPR; v.node = tr.input(mx::Trace::IN_PARAM, i); return v; };
+    std::vector<mx::Var> z;
+    for (size_t i = 0; i < 12; ++i) z.push_back(mx::Var(mx::Var::STATE, i));
+    for (size_t j = 0; j < 4; ++j) z.push_back(mx::Var(mx::Var::CONTROL, j));
+    const mx::Var sph = mx::sin(z[3]), cph = mx::cos(z[3]), sth = mx::sin(z[4]), cth = mx::cos(z[4]);
+    const mx::Var sps = mx::sin(z[5]), cps = mx::cos(z[5]);
+    const mx::Var icth = 1.0 / cth, tth = sth * icth;
+    const mx::Var u = z[6], v = z[7], w = z[8], p = z[9], qq = z[10], r = z[11];
+    const mx::Var m = par(0), Ixx = par(1), Iyy = par(2), Izz = par(3), g = par(4), qS = par(5), iV = 1.0 / par(13), damp = par(14);
+    std::vector<mx::Var> f(12);
+    f[0] = cth * cps * u + (sph * sth * cps - cph * sps) * v + (cph * sth * cps + sph * sps) * w;
+    f[1] = cth * sps * u + (sph * sth * sps + cph * cps) * v + (cph * sth * sps - sph * cps) * w;
+    f[2] = -sth * u + sph * cth * v + cph * cth * w;
+    f[3] = p + tth * (sph * qq + cph * r);
+    f[4] = cph * qq - sph * r;
+    f[5] = (sph * qq + cph * r) * icth;
+    const mx::Var al = w * iV, CL = par(6) + par(7) * al, CD = par(8) + par(9) * CL * CL;
+    const mx::Var X = z[12] - qS * CD, Y = -damp * v, Z = -qS * CL;
+    f[6] = r * v - qq * w - g * sth + X / m;
+    f[7] = p * w - r * u + g * sph * cth + Y / m;
+    f[8] = qq * u - p * v + g * cph * cth + Z / m;
+    const mx::Var Lm = qS * par(10) * z[13] - damp * p, Mm = qS * par(11) * z[14] - damp * qq, Nm = qS * par(12) * z[15] - damp * r;
+    f[9] = ((Iyy - Izz) * qq * r + Lm) / Ixx;
+    f[10] = ((Izz - Ixx) * p * r + Mm) / Iyy;
+    f[11] = ((Ixx - Iyy) * p * qq + Nm) / Izz;
+    const mx::Var L = par(15) * (z[12] * z[12] + z[13] * z[13] + z[14] * z[14] + z[15] * z[15]);
+    std::vector<int> fn;
+    for (const mx::Var& fi : f) fn.push_back(fi.node);
+    g_out = tr.generate_hess_body(12, 4, fn, L.node);
+    return g_out.c_str();
+}
+
 // Source of the generated model struct for the traced quadrotor (or, with which=1, a model that
 // exercises every traced operation).  Host-only: used to check trace + derivatives + code generation.
 extern "C" const char* harness_traced_model_source(int which) {

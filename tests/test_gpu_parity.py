@@ -119,7 +119,7 @@ def test_linearity_of_defect_operator(built):
 
 
 def test_hessian_blocks(built):
-    for name in ("pointmass_xml", "quad_ragged"):
+    for name in ("pointmass_xml", "quad_ragged", "fixedwing_64"):
         c, ev, _, _ = run_case(name)
         lay = ev.layout
         rng = np.random.default_rng(11)

@@ -246,3 +246,55 @@ def test_traced_interp1_rows_against_numpy(built, tmp_path):
             assert abs(c[j] - (r * r - ((z[0] - xc) ** 2 + (z[1] - yc) ** 2))) < 1e-13
             assert abs(cx[j] + 2 * (z[0] - xc)) < 1e-13 and abs(cy[j] + 2 * (z[1] - yc)) < 1e-13
         assert abs(h[0] + 2 * mu.sum()) < 1e-13 and abs(h[1]) < 1e-13 and abs(h[2] + 2 * mu.sum()) < 1e-13
+
+
+def _fixedwing_struct_text():
+    src = open(os.path.join(os.path.dirname(HERE), "etol_amd", "csrc", "emi_models.hpp")).read()
+    a = src.index("template <typename T> struct FixedWing12 {")
+    b = src.index("};", src.index("// ---- generated body end ----")) + 2
+    return src[a:b]
+
+
+def test_fixedwing_hessian_is_the_generated_one_and_matches_sympy(built, tmp_path):
+    """FixedWing12::hess in emi_models.hpp is machine-generated (the model written once more on the expression
+    trace, differentiated twice).  The checked-in text must be what the generator emits today, and the struct,
+    compiled for the host, must reproduce the sympy Hessian of tests/golden/models.json."""
+    import torch  # noqa: F401
+    lib = C.CDLL(os.path.join(HERE, "harness", "libetol_harness.so"))
+    lib.harness_fixedwing_hess_body.restype = C.c_char_p
+    body = lib.harness_fixedwing_hess_body().decode()
+    text = _fixedwing_struct_text()
+    checked_in = text[text.index("// ---- generated body begin ----\n") + len("// ---- generated body begin ----\n"):
+                      text.index("        // ---- generated body end ----")]
+    assert checked_in == body, "regenerate FixedWing12::hess (harness_fixedwing_hess_body) and paste it into emi_models.hpp"
+    prelude = PRELUDE + "inline void emi_sincos(double a, double* s, double* c) { *s = std::sin(a); *c = std::cos(a); }\n"
+    post = r"""
+typedef FixedWing12<double> FW;
+extern "C" void fw_eval(const double* p, const double* z, double cL, const double* cf, double* f, double* J, double* g, double* H) {
+    ModelParams<double> P = {};
+    for (int i = 0; i < 16; ++i) P.p[i] = p[i];
+    FW::f(P, z, 0.0, f);
+    double Jm[FW::NS][FW::NV];
+    FW::jac(P, z, 0.0, Jm);
+    for (int i = 0; i < FW::NS; ++i) for (int v = 0; v < FW::NV; ++v) J[i * FW::NV + v] = Jm[i][v];
+    FW::grad(P, z, 0.0, g);
+    for (int k = 0; k < 136; ++k) H[k] = 0;
+    FW::hess(P, z, 0.0, cL, cf, H);
+}
+"""
+    cpp = tmp_path / "fw.cpp"
+    cpp.write_text(prelude + text + post)
+    so = tmp_path / "fw.so"
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-o", str(so), str(cpp)])
+    t = C.CDLL(str(so))
+    dp = C.POINTER(C.c_double)
+    t.fw_eval.argtypes = [dp, dp, C.c_double, dp, dp, dp, dp, dp]
+    p = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+    params = np.array(MODELS["2"]["params"], dtype=np.float64)
+    for pt in MODELS["2"]["points"]:
+        z, cf = np.array(pt["z"]), np.array(pt["cf"])
+        f, J, g, H = np.zeros(12), np.zeros(12 * 16), np.zeros(16), np.zeros(136)
+        t.fw_eval(p(params), p(z), pt["cL"], p(cf), p(f), p(J), p(g), p(H))
+        assert np.abs(f - pt["f"]).max() < 1e-12 * (np.abs(pt["f"]).max() + 1)
+        assert np.abs(J.reshape(12, 16) - np.array(pt["J"])).max() < 1e-12 * (np.abs(pt["J"]).max() + 1)
+        assert np.abs(H - np.array(pt["H"])).max() < 1e-11 * (np.abs(pt["H"]).max() + 1)
