@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -57,6 +58,7 @@ int env_int(const char* name, int dflt) {
 struct Result {
     int scenario = -1, rc = 0, nodes = 0, iterations = 0;
     double cost = 0, seconds = 0;
+    std::string message;
 };
 
 Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
@@ -112,6 +114,7 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
     t->solve();
     const mx::Sol* sol = solver.getSolution();
     R.rc = sol->error_flag;
+    R.message = sol->error_msg;
     R.nodes = (int)sol->nodes;
     R.iterations = sol->nlp_iterations_total;
     R.cost = sol->error_flag ? 0.0 : t->getScore();
@@ -149,8 +152,8 @@ int main(int argc, char** argv) {
     int ok = 0;
     double iters = 0;
     for (const Result& r : results) {
-        printf("scenario %4d  rank %d  rc %d  nodes %d  iterations %4d  cost %.8f  %.2f s\n", r.scenario, rank, r.rc, r.nodes,
-               r.iterations, r.cost, r.seconds);
+        printf("scenario %4d  rank %d  rc %d  nodes %d  iterations %4d  cost %.8f  %.2f s%s%s\n", r.scenario, rank, r.rc, r.nodes,
+               r.iterations, r.cost, r.seconds, r.rc ? "  " : "", r.rc ? r.message.c_str() : "");
         ok += r.rc == 0;
         iters += r.iterations;
     }

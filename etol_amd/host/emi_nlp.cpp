@@ -22,6 +22,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace ETOL {
@@ -516,7 +517,8 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     for (int r = 0; r < mc; ++r) { if (shasL(r)) it.vL[r] = 1.0; if (shasU(r)) it.vU[r] = 1.0; }
 
     double mu = opt.mu_init, nu = 1.0;
-    double dw_used = 0.0;   // largest eigenvalue shift of the last step taken with modified blocks (log only)
+    double dw_used = 0.0;   // delta_w of the last exact step, or the largest reflected eigenvalue shift (log only)
+    double dw_last_ok = 0.0;   // last nonzero delta_w that gave the right inertia
     const double tau_min = 0.99, kappa_eps = 10.0, kappa_mu = 0.2, theta_mu = 1.5, kappa_sigma = 1e10;
     std::vector<double> y_unscaled(mc);
 
@@ -734,6 +736,13 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     grad_and_jt(it);
     int n_acceptable = 0;
     bool force_modified = false;
+    bool search_on = false, last_step_reflected = false;
+    int stagn = 0, crawl = 0;
+    // (env: experiments, profiles/r01_notes.md) EMI_SHIFT_TRIALS=0 switches the inertia search off, EMI_CRAWL=1000 the crawl rule
+    const int max_shift_trials = getenv("EMI_SHIFT_TRIALS") ? atoi(getenv("EMI_SHIFT_TRIALS")) : opt.max_shift_trials;
+    const int stagn_limit = getenv("EMI_STAGN") ? atoi(getenv("EMI_STAGN")) : 12;
+    const int crawl_limit = getenv("EMI_CRAWL") ? atoi(getenv("EMI_CRAWL")) : 3;
+    double stagn_ref = 1e300;
     for (int iter = 0;; ++iter) {
         R.iterations = iter;
         double viol = 0, emax = 0;
@@ -756,6 +765,18 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             if (++n_acceptable >= opt.acceptable_iter) { R.ok = true; R.msg = "converged to acceptable level"; break; }
         } else {
             n_acceptable = 0;
+        }
+        // reflected steps that have not reduced the KKT residual of the barrier problem by 10 % over `stagn_limit` iterations:
+        // switch the inertia search on (measured, profiles/r01_notes.md: 4 costs the keep-out Monte-Carlo sets half their
+        // throughput in trial factorisations, 12 keeps it and still rescues the fixed-wing problems)
+        {
+            const double err_mu_now = kkt_error(it, mu, nullptr, nullptr);
+            if (last_step_reflected && err_mu_now > 0.9 * stagn_ref) {
+                if (++stagn >= stagn_limit) search_on = true;
+            } else {
+                stagn = 0;
+                stagn_ref = err_mu_now;
+            }
         }
         if (iter >= opt.max_iter) { R.msg = "maximum number of iterations exceeded"; break; }
         if (std::chrono::duration<double>(std::chrono::steady_clock::now() - tstart).count() > opt.max_cpu_time) {
@@ -803,7 +824,9 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         // factor with inertia correction
         bool factored = false;
         double dw = 0.0, dc = 0.0;
-        for (int attempt = 0; attempt < 12; ++attempt) {
+        double dw_shift = 0.0;      // primal regularisation delta_w I of the inertia search (below)
+        int shift_trials = 0;
+        for (int attempt = 0; attempt < 24; ++attempt) {
             // The device factorisation is an LU and reports no inertia, so the matrix handed to the
             // backend has its inertia by construction: every node block
             //     Q_k = H_k + Sigma_k + sum_j sig_t g_j g_j^T
@@ -826,7 +849,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                         if (hasL(qq)) sg += it.zL[qq] / (it.z[qq] - P.zl[qq]);
                         if (hasU(qq)) sg += it.zU[qq] / (P.zu[qq] - it.z[qq]);
                     }
-                    Qblk[(size_t)(v * (v + 1) / 2 + v) * M + k] += sg;
+                    Qblk[(size_t)(v * (v + 1) / 2 + v) * M + k] += sg + (fidx[qq] >= 0 ? dw_shift : 0.0);
                 }
             {
                 const int hi = std::max(P.px, P.py), lo = std::min(P.px, P.py);
@@ -871,6 +894,18 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             }
             R.t_lowrank += secs(tl0, now());
             exact_step = !force_modified && lr_exact && r_mod == (int)mods.size();
+            // Inertia search (IPOPT's delta_w): the unmodified K has the wrong inertia.  The step of the reflected
+            // blocks is the cheap answer and usually a good one; where it stagnates (search_on, set below) look for
+            // the smallest shift K + delta_w I_z whose inertia is right instead -- the verdict for every trial comes
+            // from the same low-rank test, at the price of a factorisation each.
+            if (search_on && !exact_step && !force_modified && !mods.empty() && r_mod == (int)mods.size() &&
+                shift_trials < max_shift_trials) {
+                if (dw_shift == 0.0) dw_shift = dw_last_ok == 0.0 ? 1e-4 : std::max(1e-20, dw_last_ok / 3.0);
+                else dw_shift *= (dw_last_ok == 0.0 ? 100.0 : 8.0);
+                ++shift_trials;
+                continue;
+            }
+            if (exact_step && dw_shift > 0.0) dw_last_ok = dw_shift;
             build_rhs(rhs_full.data(), E.RES.data());
             std::copy(rhs_full.begin(), rhs_full.begin() + NN, rhs_keep.begin());
             const auto ts0 = now();
@@ -901,12 +936,14 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                     for (size_t r = 0; r < NN; ++r) rhs_full[r] += resid[r];
                 }
             }
-            if (exact_step) dw = 0.0;     // the log shows the shift only when the modified step was taken
+            if (exact_step) dw = dw_shift;     // the log shows delta_w of an exact step, else the largest reflected shift
             factored = true;
             break;
         }
         if (!factored) { R.msg = "KKT matrix could not be factorised (still singular after dual regularisation)"; break; }
         dw_used = dw;
+        last_step_reflected = !exact_step;
+        if (exact_step && dw_shift == 0.0) search_on = false;      // the plain Newton matrix is fine again
 
         // the step in the eliminated quantities
         for (int q = 0; q < nz; ++q) dz[q] = fidx[q] >= 0 ? rhs_full[q] : 0.0;
@@ -1085,9 +1122,11 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             }
             // Close to a solution the merit function stops resolving progress: the full Newton step changes it
             // by less than constraint curvature and round-off move it, and the backtracking then crawls with steps
-            // of 1e-6 for a hundred iterations.  There the KKT residual itself is the better judge: take the full
-            // step if it reduces the residual of the current barrier problem (else undo and backtrack as usual).
-            if (ls == 0 && err0 <= 1e-2) {
+            // of 1e-6 for a hundred iterations.  There -- and wherever the line search has just cut three steps in a
+            // row below 30 % of the longest admissible step (`crawl`: the same effect further out, with a penalty
+            // weight the far-from-feasible start left behind) -- the KKT residual itself is the better judge: take
+            // the full step if it reduces the residual of the current barrier problem (else undo and backtrack).
+            if (ls == 0 && (err0 <= 1e-2 || crawl >= crawl_limit)) {
                 const double err_mu = kkt_error(it, mu, nullptr, nullptr);
                 const Iterate it_keep = it;
                 const std::vector<double> gradf_keep = gradf, jtl_keep = jtl;
@@ -1116,6 +1155,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             printf("          apr %.3e  alpha %.3e  adu %.3e  dphi %.3e  infeas1 %.3e  slope %.3e\n", apr, alpha, adu, dphi,
                    infeas0, slope);
         if (newton_accepted) {       // the iterate is already updated and re-evaluated
+            crawl = 0;
             force_modified = false;
             continue;
         }
@@ -1132,6 +1172,8 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             break;
         }
         // accept
+        static const double crawl_frac = getenv("EMI_CRAWL_FRAC") ? atof(getenv("EMI_CRAWL_FRAC")) : 0.3;
+        crawl = alpha < crawl_frac * apr ? crawl + 1 : 0;
         if (!take_step(alpha, adu)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
     }
     R.cost = E.cost;

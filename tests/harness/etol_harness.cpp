@@ -447,6 +447,114 @@ extern "C" const char* harness_fixedwing_hess_body(void) {
     return g_out.c_str();
 }
 
+// ---- 12-state fixed wing (the config-5 model) as a guidance problem: level flight at trim, lateral offset ---------
+namespace {
+const std::vector<double> kFwParams = {10.0, 0.8, 1.1, 1.8, 9.81, 120.0, 0.3, 4.5, 0.03, 0.05, 0.08, -0.6, 0.06, 25.0, 0.9, 1.0};
+struct FwSetup {
+    ETOL::f_t obj;
+    std::vector<ETOL::f_t> grad;
+};
+// trim of the model at 25 m/s: lift = weight fixes alpha (w = alpha V), thrust = drag
+void fixedwing_trim(double* w_trim, double* theta_trim, double* thrust_trim) {
+    const std::vector<double>& p = kFwParams;
+    const double CL = p[0] * p[4] / p[5], alpha = (CL - p[6]) / p[7];
+    *w_trim = alpha * p[13];
+    *theta_trim = alpha;
+    *thrust_trim = p[5] * (p[8] + p[9] * CL * CL);
+}
+void configure_fixedwing(ETOL::TrajectoryOptimizer* t, FwSetup& q, int nsteps, double tf, double lateral) {
+    double wt, tht, thr;
+    fixedwing_trim(&wt, &tht, &thr);
+    const double V = kFwParams[13];
+    t->setNSteps(nsteps); t->setDt(tf / nsteps); t->setNStates(12); t->setNControls(4);
+    //            pn      pe       pd    phi  theta psi  ub  vb  wb  p  q  r
+    t->setX0({0.0, 0.0, -100.0, 0.0, tht, 0.0, V, 0.0, wt, 0, 0, 0});
+    t->setXf({V * tf, lateral, -100.0, 0.0, tht, 0.0, V, 0.0, wt, 0, 0, 0});
+    t->setXtol({5.0, 0.5, 2.0, 0.05, 0.05, 0.1, 2.0, 1.0, 1.0, 0.2, 0.2, 0.2});
+    t->setXlower({-50, -200, -200, -1.0, -0.6, -1.5, 10, -10, -10, -2, -2, -2});
+    t->setXupper({2000, 200, -10, 1.0, 0.6, 1.5, 40, 10, 10, 2, 2, 2});
+    t->setUlower({0, -0.5, -0.5, -0.5}); t->setUupper({60, 0.5, 0.5, 0.5});
+    t->setMaximize(false);
+    const std::vector<double> mp = kFwParams;
+    q.obj = [mp](F_ARGS) -> ETOL::scalar_t { return mx::objective(EMI_MODEL_FIXEDWING12, mp); };
+    t->setObjective(&q.obj);
+    q.grad.resize(12);
+    std::vector<ETOL::f_t*> gp;
+    for (int i = 0; i < 12; ++i) {
+        q.grad[i] = [mp, i](F_ARGS) -> ETOL::scalar_t { return mx::derivative(EMI_MODEL_FIXEDWING12, i, mp); };
+        gp.push_back(&q.grad[i]);
+    }
+    t->setGradient(gp);
+}
+}  // namespace
+
+// fixed-wing lateral-offset manoeuvre, NLP iteration driven by the CPU oracle (solver-logic test)
+extern "C" int harness_solve_fixedwing_oracle(const char* oracle_so, int nsteps, double tf, double lateral, double tol,
+                                              int print_level, double* cost, int* M, double* X, double* U, int cap, int* iters) {
+    void* h = dlopen(oracle_so, RTLD_NOW);
+    if (!h) { g_out = dlerror(); return 3; }
+    OracleEval oe;
+    oe.ev = (orc_eval_t)dlsym(h, "orc_eval");
+    oe.hs = (orc_hess_t)dlsym(h, "orc_hess");
+    Plain t;
+    FwSetup q;
+    configure_fixedwing(&t, q, nsteps, tf, lateral);
+    mx::Prob P;
+    P.nstates = 12; P.ncontrols = 4; P.nodes = nsteps + 1; P.t0 = 0; P.tf = tf;
+    P.model = EMI_MODEL_FIXEDWING12; P.model_params = kFwParams;
+    P.tau.resize(P.nodes); P.w.resize(P.nodes); P.D.resize(P.nodes * P.nodes);
+    emi_lgl((int)P.nodes, P.tau.data(), P.w.data(), P.D.data());
+    P.npath = 0;
+    P.state_lower = t.getXlower(); P.state_upper = t.getXupper();
+    P.control_lower = t.getUlower(); P.control_upper = t.getUupper();
+    for (int i = 0; i < 12; ++i) { P.event_lower.push_back(t.getX0()[i]); P.event_upper.push_back(t.getX0()[i]); }
+    for (int i = 0; i < 12; ++i) { P.event_lower.push_back(t.getXf()[i] - t.getXtol()[i]); P.event_upper.push_back(t.getXf()[i] + t.getXtol()[i]); }
+    oe.P = &P;
+    mx::NlpProblem nlp = mx::make_nlp(P, &oe);
+    mx::NlpOptions opt;
+    opt.tol = tol; opt.print_level = print_level; opt.max_iter = 300;
+    mx::NlpResult r = mx::solve_nlp(nlp, opt, mx::initial_guess(P));
+    *iters = r.iterations;
+    g_out = r.msg;
+    dlclose(h);
+    if (!r.ok) return 1;
+    const int m = (int)P.nodes;
+    if (m > cap) return 2;
+    *M = m; *cost = r.cost;
+    for (int i = 0; i < 12 * m; ++i) X[i] = r.z[i];
+    for (int i = 0; i < 4 * m; ++i) U[i] = r.z[12 * m + i];
+    return 0;
+}
+
+// the same problem through ETOL::eMI355X on the GPU
+extern "C" int harness_solve_fixedwing(int nsteps, double tf, double lateral, double tol, int print_level, double* cost, int* M,
+                                       double* X, double* U, int cap, int* iters) {
+    ETOL::eMI355X solver;
+    FwSetup q;
+    configure_fixedwing(&solver, q, nsteps, tf, lateral);
+    solver.setup();
+    solver.getAlgorithm()->nlp_tolerance = tol;
+    solver.getAlgorithm()->print_level = print_level;
+    solver.getAlgorithm()->nlp_iter_max = 300;
+    solver.getAlgorithm()->mesh_refinement = "none";
+    solver.getAlgorithm()->linear_solver = g_linear_solver;
+    solver.solve();
+    const mx::Sol* s = solver.getSolution();
+    *iters = s->nlp_iterations;
+    g_out = s->error_msg;
+    g_out2 = s->linear_solver;
+    if (s->error_flag) return 1;
+    const int m = (int)s->nodes;
+    if (m > cap) return 2;
+    *M = m; *cost = solver.getScore();
+    for (int k = 0; k < m; ++k) {
+        for (int i = 0; i < 12; ++i) X[i * m + k] = (*solver.getXtraj())[k].second[i];
+        for (int i = 0; i < 4; ++i) U[i * m + k] = (*solver.getUtraj())[k].second[i];
+    }
+    solver.close();
+    return 0;
+}
+
 // Source of the generated model struct for the traced quadrotor (or, with which=1, a model that
 // exercises every traced operation).  Host-only: used to check trace + derivatives + code generation.
 extern "C" const char* harness_traced_model_source(int which) {

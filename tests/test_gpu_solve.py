@@ -255,6 +255,32 @@ def test_device_newton_step_without_path_rows(H):
     assert np.abs(RES[0, :6]).max() < 1e-7 and abs(COST[0] - cost) < 1e-8 and iters < 100
 
 
+def test_fixedwing_lateral_offset_solves_on_the_gpu(H):
+    """12-state fixed-wing model (config 5's dynamics) through ETOL::eMI355X: generated Hessian, coupled nonconvex
+    16x16 node blocks, Newton step on the device.  Checked against the oracle's residuals at the returned point."""
+    from etol_amd import workloads as W
+    D = C.POINTER(C.c_double)
+    H.harness_solve_fixedwing.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, D, C.POINTER(C.c_int), D, D,
+                                          C.c_int, C.POINTER(C.c_int)]
+    _set_linear_solver(H, "device")
+    try:
+        n = 48
+        X, U = np.zeros(12 * (n + 1)), np.zeros(4 * (n + 1))
+        cost, M, it = C.c_double(), C.c_int(), C.c_int()
+        rc = H.harness_solve_fixedwing(n, 8.0, 10.0, 1e-7, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D),
+                                       U.ctypes.data_as(D), n + 1, C.byref(it))
+        assert rc == 0, H.harness_last_message().decode()
+    finally:
+        _set_linear_solver(H, "auto")
+    m = M.value
+    assert m == n + 1 and it.value < 150
+    X, U = X.reshape(12, m), U.reshape(4, m)
+    RES, _, COST = O.evaluate(2, W.FW_PARAMS, m, O.lgl(m), 0.0, 8.0, X[None], U[None])
+    assert np.abs(RES[0, :12]).max() < 1e-6 and abs(COST[0] - cost.value) < 1e-8 * abs(cost.value)
+    assert abs(X[1, -1] - 10.0) <= 0.5 + 1e-9 and np.abs(X[3]).max() > 0.02
+    assert U[0].min() >= -1e-9 and U[0].max() <= 60 + 1e-9 and np.abs(U[1:]).max() <= 0.5 + 1e-9
+
+
 def test_montecarlo_example_shards_scenarios_over_ranks_and_threads(built):
     """etol_mi355x_montecarlo: independent scenarios, static block partition over ranks (RANK / WORLD_SIZE /
     LOCAL_RANK), host threads inside a rank.  Two 'ranks' on the one GPU of the test box must solve, between

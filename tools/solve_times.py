@@ -54,6 +54,22 @@ def quadrotor(nsteps, ndiscs):
                 newton_step=H.harness_last_linear_solver().decode(), message=H.harness_last_message().decode())
 
 
+H.harness_solve_fixedwing.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, D, C.POINTER(C.c_int), D, D, C.c_int,
+                                      C.POINTER(C.c_int)]
+
+
+def fixedwing(nsteps, tf, lateral):
+    cap = nsteps + 1
+    X, U = np.zeros(12 * cap), np.zeros(4 * cap)
+    cost, M, it = C.c_double(), C.c_int(), C.c_int()
+    t0 = time.time()
+    rc = H.harness_solve_fixedwing(nsteps, tf, lateral, 1e-7, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D),
+                                   cap, C.byref(it))
+    return dict(problem=f"12-state fixed wing, {nsteps + 1} LGL nodes, {tf:g} s, {lateral:g} m lateral offset, fixed mesh", rc=rc,
+                seconds=time.time() - t0, cost=cost.value, nodes=M.value, last_solve_iterations=it.value,
+                newton_step=H.harness_last_linear_solver().decode(), message=H.harness_last_message().decode())
+
+
 def main():
     out = []
     example1()                      # first call pays context creation / library load
@@ -65,6 +81,8 @@ def main():
     r = quadrotor(40, 2)
     r["problem"] += " (linear_solver=device)"
     out.append(r)
+    for nsteps, tf, lat in ((48, 8.0, 10.0), (128, 12.0, 20.0)):
+        out.append(fixedwing(nsteps, tf, lat))
     H.harness_set_linear_solver(b"auto")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "solve_times.json"), "w") as f:
