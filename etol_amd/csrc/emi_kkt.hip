@@ -27,7 +27,9 @@
 #include <rocsolver/rocsolver.h>
 
 #include <cstdio>
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 
 #include "emi_kernels.hpp"
@@ -63,6 +65,8 @@ struct KktWorkspace {
     size_t T_elems = 0, Cb_elems = 0;
     size_t cap_Pinv = 0, cap_G = 0, cap_Rk = 0, cap_Doff = 0, cap_W = 0;
     int* flag = nullptr;        // node kernel: a block was not positive definite
+    double* chol_copy = nullptr;   // the matrix handed to dpotrf, kept until the factorisation is confirmed (potrf_checked)
+    size_t cap_chol_copy = 0;
     // low-rank correction (kkt_lowrank)
     bool lr_active = false;
     int lr_r = 0, lr_cap = 0, lr_n = 0;
@@ -287,26 +291,7 @@ __global__ void emi_kkt_lr_utx_kernel(double* __restrict__ T, const double* __re
 
 const char* rb(rocblas_status s) { return rocblas_status_to_string(s); }
 
-}  // namespace
-
-void kkt_destroy(KktWorkspace* w) {
-    if (!w) return;
-    if (w->handle) (void)rocblas_destroy_handle(w->handle);
-    void* bufs[] = {w->K, w->ipiv, w->info, w->Q, w->J, w->rhs, w->fixed, w->S, w->Pinv, w->G, w->Rk, w->Doff, w->W, w->T,
-                    w->Cb, w->flag, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
-    for (void* b : bufs)
-        if (b) (void)hipFree(b);
-    delete w;
-}
-
-// Returns an EMI_* status; *info = 0 factorised, > 0 exactly singular (zero pivot at that position).
-int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, int ns, int nv, const double* Qblk,
-               const double* Jblk, const unsigned char* fixed, double dc, int method, int* info, std::string* err) {
-    const int nh = nv * (nv + 1) / 2, N = (nv + ns) * M, nz = nv * M;
-    if (!*pw) *pw = new KktWorkspace();
-    KktWorkspace* w = *pw;
-    w->factored = false;
-    w->lr_active = false;
+// error plumbing of the host functions below: they have `std::string* err` in scope and return an EMI_* status
 #define KKT_HIP(call)                                                                      \
     do {                                                                                   \
         hipError_t e_ = (call);                                                            \
@@ -327,6 +312,74 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         rocblas_status s_ = (call);                                                        \
         if (s_ != rocblas_status_success) { *err = std::string(#call) + ": " + rb(s_); return EMI_ERR_HIP; } \
     } while (0)
+
+// rocsolver_dpotrf (ROCm 7.2) is not reliable while other host threads keep the GPU busy on their own handles and
+// streams: about 1 % of the calls (65-node problems, 6 threads) report a non-positive pivot in an odd 64-column block
+// of a matrix that factorises when the call is repeated on the same data (tools/scratch/race_probe.py,
+// profiles/r01_notes.md; dgetrf, dpotrs and the GEMMs showed no such effect).  The solver then took a more
+// regularised step than a single-threaded run, and iteration paths differed from run to run.  Two measures:
+// the calls are serialised across the process (the stream is drained first, so the lock covers the factorisation
+// alone; this alone removes the effect at 65 nodes and leaves 1 in 1000 at 257), and a reported failure is
+// confirmed on a kept copy of the matrix before it is believed.
+std::mutex g_potrf_mutex;
+std::atomic<long> g_potrf_spurious{0};
+
+// A (n x n, lda == n) <- its Cholesky factor; *hinfo = 0, or the position of the first non-positive pivot
+int potrf_checked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, rocblas_int* hinfo, std::string* err) {
+    const size_t bytes = (size_t)n * n * sizeof(double);
+    if (w->cap_chol_copy < bytes) {
+        if (w->chol_copy) KKT_HIP(hipFree(w->chol_copy));
+        w->chol_copy = nullptr;
+        w->cap_chol_copy = 0;
+        KKT_HIP(hipMalloc((void**)&w->chol_copy, bytes));
+        w->cap_chol_copy = bytes;
+    }
+    KKT_HIP(hipMemcpyAsync(w->chol_copy, A, bytes, hipMemcpyDeviceToDevice, stream));
+    rocblas_int first = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        if (attempt > 0) KKT_HIP(hipMemcpyAsync(A, w->chol_copy, bytes, hipMemcpyDeviceToDevice, stream));
+        KKT_HIP(hipStreamSynchronize(stream));
+        {
+            std::lock_guard<std::mutex> lk(g_potrf_mutex);
+            KKT_RB(rocsolver_dpotrf(w->handle, rocblas_fill_lower, n, A, n, w->info));
+            KKT_HIP(hipMemcpyAsync(hinfo, w->info, sizeof *hinfo, hipMemcpyDeviceToHost, stream));
+            KKT_HIP(hipStreamSynchronize(stream));
+        }
+        if (*hinfo == 0) {
+            if (attempt > 0) {
+                ++g_potrf_spurious;
+                if (getenv("EMI_KKT_DEBUG"))
+                    fprintf(stderr, "emi_kkt: dpotrf reported pivot %d of %d, the same matrix factorised on repeat %d\n", (int)first,
+                            (int)n, attempt);
+            }
+            return EMI_OK;
+        }
+        if (attempt > 0 && *hinfo == first) return EMI_OK;      // the same verdict twice: the matrix is not positive definite
+        first = *hinfo;
+    }
+    return EMI_OK;
+}
+
+}  // namespace
+
+void kkt_destroy(KktWorkspace* w) {
+    if (!w) return;
+    if (w->handle) (void)rocblas_destroy_handle(w->handle);
+    void* bufs[] = {w->K, w->ipiv, w->info, w->Q, w->J, w->rhs, w->fixed, w->S, w->Pinv, w->G, w->Rk, w->Doff, w->W, w->T,
+                    w->Cb, w->flag, w->chol_copy, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    delete w;
+}
+
+// Returns an EMI_* status; *info = 0 factorised, > 0 exactly singular (zero pivot at that position).
+int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, int ns, int nv, const double* Qblk,
+               const double* Jblk, const unsigned char* fixed, double dc, int method, int* info, std::string* err) {
+    const int nh = nv * (nv + 1) / 2, N = (nv + ns) * M, nz = nv * M;
+    if (!*pw) *pw = new KktWorkspace();
+    KktWorkspace* w = *pw;
+    w->factored = false;
+    w->lr_active = false;
     if (!w->handle) {
         KKT_RB(rocblas_create_handle(&w->handle));
         // split-K kernels that accumulate with atomics make the factorisation, and with it the iteration path of
@@ -386,8 +439,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
                                        ns, i, ip, dc_schur);
                 }
             KKT_HIP(hipGetLastError());
-            KKT_RB(rocsolver_dpotrf(w->handle, rocblas_fill_lower, (rocblas_int)md, w->S, (rocblas_int)md, w->info));
-            KKT_HIP(hipMemcpyAsync(&hinfo, w->info, sizeof hinfo, hipMemcpyDeviceToHost, stream));
+            if (int st = potrf_checked(w, stream, (rocblas_int)md, w->S, &hinfo, err)) return st;
             KKT_HIP(hipMemcpyAsync(&hflag, w->flag, sizeof hflag, hipMemcpyDeviceToHost, stream));
             KKT_HIP(hipStreamSynchronize(stream));
             if (hinfo == 0 || hflag != 0) break;      // factorised, or hopeless (a Q block is not positive definite)
@@ -522,10 +574,8 @@ int kkt_lowrank(KktWorkspace* w, hipStream_t stream, int nz, int r, const int* n
     hipLaunchKernelGGL(emi_kkt_lr_c_kernel, dim3((r + 15) / 16, (r + 15) / 16), dim3(16, 16), 0, stream, w->lrC, w->lrY, w->lr_node,
                        w->lr_vec, w->lr_delta, r, N, M, nv);
     KKT_HIP(hipGetLastError());
-    KKT_RB(rocsolver_dpotrf(w->handle, rocblas_fill_lower, r, w->lrC, r, w->info));
     rocblas_int hinfo = 0;
-    KKT_HIP(hipMemcpyAsync(&hinfo, w->info, sizeof hinfo, hipMemcpyDeviceToHost, stream));
-    KKT_HIP(hipStreamSynchronize(stream));
+    if (int st2 = potrf_checked(w, stream, r, w->lrC, &hinfo, err)) return st2;
     if (hinfo == 0) {
         w->lr_active = true;
         w->lr_r = r;

@@ -178,3 +178,66 @@ def test_lowrank_correction_gives_exact_solves_and_the_inertia_verdict(built, me
         assert ev.kkt_lowrank([], np.zeros((0, nv)), []) is True     # cleared: back to K~
         sol2 = ev.kkt_solve(rhs)
         assert np.abs(Kt @ sol2 - b).max() < 1e-9 * (np.abs(Kt).max() * np.abs(sol2).max() + 1)
+
+
+def test_concurrent_contexts_give_reproducible_factorisations(built):
+    """Monte-Carlo runs factorise from several host threads at once, one context (stream, rocBLAS handle) each.
+    rocsolver_dpotrf under such load now and then reports a non-positive pivot for a matrix that is positive
+    definite (tools/scratch/race_probe.py found ~1 % of the calls); emi_kkt_factor confirms a failure on a kept
+    copy before it raises the regularisation.  Here: 6 threads, the same data, every repeat of
+    factor / low-rank verdict / solve must be bit-identical to the thread's first."""
+    import threading
+
+    import etol_amd as E
+    from etol_amd import workloads as W
+    M, reps, nthreads = 65, 120, 6
+    ns, nc, _ = E.model_dims(1)
+    nv, nh = ns + nc, (ns + nc) * (ns + nc + 1) // 2
+    rng = np.random.default_rng(7)
+    Qblk = np.zeros((nh, M))
+    for k in range(M):
+        A = rng.standard_normal((nv, nv))
+        Qk = A @ A.T + nv * np.eye(nv)
+        for v in range(nv):
+            for q in range(v + 1):
+                Qblk[v * (v + 1) // 2 + q, k] = Qk[v, q]
+    Jnode = rng.standard_normal((ns * nv, M))
+    fixed = np.zeros(nv * M, dtype=np.uint8)
+    fixed[np.arange(ns) * M] = 1
+    r = 12
+    node = rng.integers(0, M, r).astype(np.int32)
+    vec = rng.standard_normal((r, nv))
+    delta = np.abs(rng.standard_normal(r)) * 0.1 + 0.01
+    rhs = rng.standard_normal((3, (nv + ns) * M))
+    bad, errors, firsts = [], [], [None] * nthreads
+
+    def work(tid):
+        try:
+            ev = E.Evaluator(0)
+            ev.set_mesh(M, 0.0, 4.0)
+            ev.set_model(1, W.QUAD_PARAMS)
+            ev.set_batch(1)
+            Jblk = Jnode.copy()
+            for i in range(ns):
+                Jblk[i * nv + i] += np.diag(ev.D)
+            for rep in range(reps):
+                assert ev.kkt_factor(Qblk, Jblk, fixed, 1e-9) == 0
+                exact = ev.kkt_lowrank(node, vec, delta)
+                sol = ev.kkt_solve(rhs)
+                if firsts[tid] is None:
+                    firsts[tid] = (exact, sol.copy())
+                elif exact != firsts[tid][0] or not np.array_equal(sol, firsts[tid][1]):
+                    bad.append((tid, rep, float(np.abs(sol - firsts[tid][1]).max())))
+            ev.close()
+        except Exception as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert not bad, bad[:5]
+    for tid in range(1, nthreads):           # and the threads agree with each other
+        assert firsts[tid][0] == firsts[0][0] and np.array_equal(firsts[tid][1], firsts[0][1])

@@ -10,6 +10,7 @@ from etol_amd import workloads as W
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 65
+MODE = sys.argv[4] if len(sys.argv) > 4 else "full"      # full | nolr | lu | solve2
 bad = {}
 
 def work(tid):
@@ -39,9 +40,14 @@ def work(tid):
         RES, VALS, COST = ev.eval_host(X, U)
         out["RES"], out["VALS"], out["COST"] = RES.copy(), VALS.copy(), COST.copy()
         out["H"] = np.array(ev.hess_host(X, U, lamF, lamC, 1.0)).copy()
+        if MODE == "lu": ev.set_option("kkt_method", 0)
         assert ev.kkt_factor(Qblk, Jblk, fixed, 1e-9) == 0
-        out["exact"] = np.array([ev.kkt_lowrank(node, vec, delta)])
+        if MODE != "nolr": out["exact"] = np.array([ev.kkt_lowrank(node, vec, delta)])
         out["sol"] = np.array(ev.kkt_solve(rhs)).copy()
+        if MODE == "solve2":
+            for again in range(3):
+                s2 = np.array(ev.kkt_solve(rhs))
+                if not np.array_equal(s2, out["sol"]): bad.setdefault((tid, "same-factor"), []).append((rep, float(np.abs(s2 - out["sol"]).max())))
         if ref is None: ref = out
         else:
             for k in out:
@@ -52,5 +58,5 @@ def work(tid):
 t0 = time.time()
 ths = [threading.Thread(target=work, args=(i,)) for i in range(T)]
 [t.start() for t in ths]; [t.join() for t in ths]
-print(f"threads {T} reps {REPS} M {M}: {time.time()-t0:.1f} s; mismatching (thread, output): {len(bad)}")
+print(f"{MODE} threads {T} reps {REPS} M {M}: {time.time()-t0:.1f} s; mismatching (thread, output): {len(bad)}")
 for k, v in sorted(bad.items())[:20]: print(k, len(v), v[:3])
