@@ -27,6 +27,7 @@
 #include <rocsolver/rocsolver.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
@@ -291,6 +292,74 @@ __global__ void emi_kkt_lr_utx_kernel(double* __restrict__ T, const double* __re
 
 const char* rb(rocblas_status s) { return rocblas_status_to_string(s); }
 
+// ---- blocked Cholesky (lower, column-major, in place) ---------------------------------------------------
+// Right-looking with 64-column blocks: the diagonal block is factorised by one workgroup in LDS, the panel below it
+// is solved one row per thread against the block held in LDS, the trailing matrix is updated by rocBLAS dsyrk.
+#define CHOL_NB 64
+// A[j0.., j0..] diagonal block of size nb <= 64; *info = first non-positive pivot (1-based, global), if none yet
+__global__ __launch_bounds__(256) void emi_chol_diag_kernel(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ info) {
+    __shared__ double L[CHOL_NB][CHOL_NB + 1];
+    __shared__ double piv;
+    const int tid = threadIdx.x;
+    double* blk = A + (size_t)j0 * lda + j0;
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+        const int c = idx / nb, r = idx - c * nb;          // r fast: coalesced down a column
+        L[r][c] = r >= c ? blk[(size_t)c * lda + r] : 0.0;
+    }
+    __syncthreads();
+    for (int c = 0; c < nb; ++c) {
+        if (tid == 0) {
+            double d = L[c][c];
+            if (!(d > 0.0)) {
+                if (*info == 0) *info = j0 + c + 1;
+                d = 1.0;
+            }
+            piv = sqrt(d);
+            L[c][c] = piv;
+        }
+        __syncthreads();
+        const double inv = 1.0 / piv;
+        for (int r = c + 1 + tid; r < nb; r += 256) L[r][c] *= inv;
+        __syncthreads();
+        // trailing update of the lower triangle: (r, cc), r >= cc > c
+        const int m = nb - c - 1;
+        for (int idx = tid; idx < m * m; idx += 256) {
+            const int cc = c + 1 + idx / m, r = c + 1 + idx % m;
+            if (r >= cc) L[r][cc] -= L[r][c] * L[cc][c];
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < nb * nb; idx += 256) {
+        const int c = idx / nb, r = idx - c * nb;
+        if (r >= c) blk[(size_t)c * lda + r] = L[r][c];
+    }
+}
+// rows i >= j0 + 64 of the block column j0: x <- x L^-T with L the factorised 64 x 64 diagonal block
+__global__ __launch_bounds__(64) void emi_chol_panel_kernel(double* __restrict__ A, int lda, int n, int j0) {
+    __shared__ double L[CHOL_NB][CHOL_NB + 1];
+    const double* blk = A + (size_t)j0 * lda + j0;
+    for (int idx = threadIdx.x; idx < CHOL_NB * CHOL_NB; idx += 64) {
+        const int c = idx / CHOL_NB, r = idx - c * CHOL_NB;
+        L[r][c] = r >= c ? blk[(size_t)c * lda + r] : 0.0;
+    }
+    __syncthreads();
+    const int row = j0 + CHOL_NB + blockIdx.x * 64 + threadIdx.x;
+    if (row >= n) return;
+    double y[CHOL_NB];
+    double* x = A + (size_t)j0 * lda + row;
+#pragma unroll
+    for (int c = 0; c < CHOL_NB; ++c) y[c] = x[(size_t)c * lda];
+#pragma unroll
+    for (int c = 0; c < CHOL_NB; ++c) {
+        double sum = y[c];
+#pragma unroll
+        for (int t = 0; t < c; ++t) sum -= y[t] * L[c][t];
+        y[c] = sum / L[c][c];
+    }
+#pragma unroll
+    for (int c = 0; c < CHOL_NB; ++c) x[(size_t)c * lda] = y[c];
+}
+
 // error plumbing of the host functions below: they have `std::string* err` in scope and return an EMI_* status
 #define KKT_HIP(call)                                                                      \
     do {                                                                                   \
@@ -338,13 +407,16 @@ int potrf_checked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A,
     rocblas_int first = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (attempt > 0) KKT_HIP(hipMemcpyAsync(A, w->chol_copy, bytes, hipMemcpyDeviceToDevice, stream));
-        KKT_HIP(hipStreamSynchronize(stream));
-        {
-            std::lock_guard<std::mutex> lk(g_potrf_mutex);
-            KKT_RB(rocsolver_dpotrf(w->handle, rocblas_fill_lower, n, A, n, w->info));
-            KKT_HIP(hipMemcpyAsync(hinfo, w->info, sizeof *hinfo, hipMemcpyDeviceToHost, stream));
+        static const bool serialise = getenv("EMI_POTRF_LOCK") ? atoi(getenv("EMI_POTRF_LOCK")) != 0 : false;
+        std::unique_lock<std::mutex> lk(g_potrf_mutex, std::defer_lock);
+        if (serialise) {
             KKT_HIP(hipStreamSynchronize(stream));
+            lk.lock();
         }
+        KKT_RB(rocsolver_dpotrf(w->handle, rocblas_fill_lower, n, A, n, w->info));
+        KKT_HIP(hipMemcpyAsync(hinfo, w->info, sizeof *hinfo, hipMemcpyDeviceToHost, stream));
+        KKT_HIP(hipStreamSynchronize(stream));
+        if (serialise) lk.unlock();
         if (*hinfo == 0) {
             if (attempt > 0) {
                 ++g_potrf_spurious;
@@ -358,6 +430,33 @@ int potrf_checked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A,
         first = *hinfo;
     }
     return EMI_OK;
+}
+
+// A (n x n, lda == n) <- its lower Cholesky factor with the kernels above; *hinfo as rocsolver_dpotrf reports it
+int chol_blocked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, rocblas_int* hinfo, std::string* err) {
+    KKT_HIP(hipMemsetAsync(w->info, 0, sizeof(rocblas_int), stream));
+    const double one = 1.0, mone = -1.0;
+    for (int j0 = 0; j0 < n; j0 += CHOL_NB) {
+        const int nb = std::min(CHOL_NB, (int)n - j0), rest = (int)n - j0 - nb;
+        hipLaunchKernelGGL(emi_chol_diag_kernel, dim3(1), dim3(256), 0, stream, A, (int)n, j0, nb, (int*)w->info);
+        if (rest > 0) {
+            hipLaunchKernelGGL(emi_chol_panel_kernel, dim3((rest + 63) / 64), dim3(64), 0, stream, A, (int)n, (int)n, j0);
+            KKT_HIP(hipGetLastError());
+            double* P = A + (size_t)j0 * n + j0 + nb;
+            double* A22 = A + (size_t)(j0 + nb) * n + j0 + nb;
+            KKT_RB(rocblas_dsyrk(w->handle, rocblas_fill_lower, rocblas_operation_none, rest, nb, &mone, P, n, &one, A22, n));
+        }
+    }
+    KKT_HIP(hipGetLastError());
+    KKT_HIP(hipMemcpyAsync(hinfo, w->info, sizeof *hinfo, hipMemcpyDeviceToHost, stream));
+    KKT_HIP(hipStreamSynchronize(stream));
+    return EMI_OK;
+}
+
+// which Cholesky: 1 (default) the blocked one above, 0 rocsolver_dpotrf with the confirmation on a copy
+int cholesky(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, rocblas_int* hinfo, std::string* err) {
+    static const int own = getenv("EMI_CHOLESKY") ? atoi(getenv("EMI_CHOLESKY")) : 1;
+    return own ? chol_blocked(w, stream, n, A, hinfo, err) : potrf_checked(w, stream, n, A, hinfo, err);
 }
 
 }  // namespace
@@ -439,7 +538,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
                                        ns, i, ip, dc_schur);
                 }
             KKT_HIP(hipGetLastError());
-            if (int st = potrf_checked(w, stream, (rocblas_int)md, w->S, &hinfo, err)) return st;
+            if (int st = cholesky(w, stream, (rocblas_int)md, w->S, &hinfo, err)) return st;
             KKT_HIP(hipMemcpyAsync(&hflag, w->flag, sizeof hflag, hipMemcpyDeviceToHost, stream));
             KKT_HIP(hipStreamSynchronize(stream));
             if (hinfo == 0 || hflag != 0) break;      // factorised, or hopeless (a Q block is not positive definite)
@@ -575,7 +674,7 @@ int kkt_lowrank(KktWorkspace* w, hipStream_t stream, int nz, int r, const int* n
                        w->lr_vec, w->lr_delta, r, N, M, nv);
     KKT_HIP(hipGetLastError());
     rocblas_int hinfo = 0;
-    if (int st2 = potrf_checked(w, stream, r, w->lrC, &hinfo, err)) return st2;
+    if (int st2 = cholesky(w, stream, r, w->lrC, &hinfo, err)) return st2;
     if (hinfo == 0) {
         w->lr_active = true;
         w->lr_r = r;
