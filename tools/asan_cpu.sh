@@ -39,6 +39,11 @@ for ls in (b"host", b"device"):
         X, U = np.zeros(6 * 64), np.zeros(2 * 64); cost, M, it = C.c_double(), C.c_int(), C.c_int()
         rc = H.harness_solve_quadrotor_oracle(orc, 24, 0.16, nd, 1e-8, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D), 64, C.byref(it))
         print("quadrotor", ls, nd, rc, cost.value, it.value, H.harness_last_message().decode())
+H.harness_solve_fixedwing_oracle.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, D, C.POINTER(C.c_int), D, D, C.c_int, C.POINTER(C.c_int)]
+H.harness_set_linear_solver(b"device")
+X, U = np.zeros(12 * 32), np.zeros(4 * 32); cost, M, it = C.c_double(), C.c_int(), C.c_int()
+rc = H.harness_solve_fixedwing_oracle(orc, 16, 6.0, 6.0, 1e-7, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D), 32, C.byref(it))
+print("fixedwing (inertia search)", rc, cost.value, it.value, H.harness_last_message().decode())
 print("asan run complete")
 PY
 cd $OUT && ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python run.py
