@@ -202,15 +202,17 @@ __global__ void emi_kkt_scale_kernel(const double* __restrict__ Doff, const doub
 // element-wise terms of one state-pair block of S (column-major big matrix, rows i*M+k, columns ip*M+kp)
 __global__ void emi_kkt_sblock_terms_kernel(double* __restrict__ S, const double* __restrict__ Doff,
                                             const double* __restrict__ G, const double* __restrict__ Rk, int M, int ns, int i,
-                                            int ip, double dc) {
+                                            int ip, double dc, double rel) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)M * M) return;
     const int kp = (int)(idx / M), k = (int)(idx - (size_t)kp * M);      // k fast: coalesced along a column of S
     const size_t md = (size_t)ns * M;
     double add = Doff[(size_t)k * M + kp] * G[(size_t)(i * ns + ip) * M + kp] +
                  Doff[(size_t)kp * M + k] * G[(size_t)(ip * ns + i) * M + k];
-    if (k == kp) add += Rk[(size_t)(i * ns + ip) * M + k] + (i == ip ? dc : 0.0);
-    S[((size_t)ip * M + kp) * md + (size_t)i * M + k] += add;
+    if (k == kp) add += Rk[(size_t)(i * ns + ip) * M + k];
+    double* dst = S + ((size_t)ip * M + kp) * md + (size_t)i * M + k;
+    const double val = *dst + add;
+    *dst = (k == kp && i == ip) ? val * (1.0 + rel) + dc : val;
 }
 // out[(v,k),c] = sum_q P_k[v][q] in[(q,k),c]      (in/out: column stride ld_in / ld_out, nz rows used)
 __global__ void emi_kkt_apply_p_kernel(const double* __restrict__ Pinv, const double* __restrict__ in, size_t ld_in,
@@ -299,39 +301,33 @@ const char* rb(rocblas_status s) { return rocblas_status_to_string(s); }
 // A[j0.., j0..] diagonal block of size nb <= 64; *info = first non-positive pivot (1-based, global), if none yet
 __global__ __launch_bounds__(256) void emi_chol_diag_kernel(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ info) {
     __shared__ double L[CHOL_NB][CHOL_NB + 1];
-    __shared__ double piv;
     const int tid = threadIdx.x;
     double* blk = A + (size_t)j0 * lda + j0;
-    for (int idx = tid; idx < nb * nb; idx += 256) {
-        const int c = idx / nb, r = idx - c * nb;          // r fast: coalesced down a column
-        L[r][c] = r >= c ? blk[(size_t)c * lda + r] : 0.0;
+    for (int idx = tid; idx < CHOL_NB * CHOL_NB; idx += 256) {
+        const int c = idx >> 6, r = idx & 63;              // r fast: coalesced down a column
+        L[r][c] = (r >= c && r < nb) ? blk[(size_t)c * lda + r] : (r == c ? 1.0 : 0.0);
     }
     __syncthreads();
+    // thread (r, g): row r, columns cc = c + 1 + g, c + 5 + g, ... of the trailing update -- one barrier per column
+    const int r = tid & 63, g = tid >> 6;
     for (int c = 0; c < nb; ++c) {
-        if (tid == 0) {
-            double d = L[c][c];
-            if (!(d > 0.0)) {
-                if (*info == 0) *info = j0 + c + 1;
-                d = 1.0;
-            }
-            piv = sqrt(d);
-            L[c][c] = piv;
+        double d = L[c][c];
+        if (!(d > 0.0)) {
+            if (tid == 0 && *info == 0) *info = j0 + c + 1;
+            d = 1.0;
         }
-        __syncthreads();
-        const double inv = 1.0 / piv;
-        for (int r = c + 1 + tid; r < nb; r += 256) L[r][c] *= inv;
-        __syncthreads();
-        // trailing update of the lower triangle: (r, cc), r >= cc > c
-        const int m = nb - c - 1;
-        for (int idx = tid; idx < m * m; idx += 256) {
-            const int cc = c + 1 + idx / m, r = c + 1 + idx % m;
-            if (r >= cc) L[r][cc] -= L[r][c] * L[cc][c];
-        }
-        __syncthreads();
+        const double piv = sqrt(d), inv = 1.0 / piv;
+        const double lrc = L[r][c] * inv;                  // own row's entry of the finished column
+        if (r > c)
+            for (int cc = c + 1 + g; cc <= r; cc += 4) L[r][cc] -= lrc * (L[cc][c] * inv);
+        __syncthreads();                                   // column c is no longer read unscaled
+        if (g == 0) L[r][c] = r == c ? piv : (r > c ? lrc : 0.0);
+        // the next column's reads touch column c+1.. only; the store above is to column c: no second barrier needed
     }
+    __syncthreads();
     for (int idx = tid; idx < nb * nb; idx += 256) {
-        const int c = idx / nb, r = idx - c * nb;
-        if (r >= c) blk[(size_t)c * lda + r] = L[r][c];
+        const int c = idx / nb, rr = idx - c * nb;
+        if (rr >= c) blk[(size_t)c * lda + rr] = L[rr][c];
     }
 }
 // rows i >= j0 + 64 of the block column j0: x <- x L^-T with L the factorised 64 x 64 diagonal block
@@ -440,9 +436,17 @@ int chol_blocked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, 
         const int nb = std::min(CHOL_NB, (int)n - j0), rest = (int)n - j0 - nb;
         hipLaunchKernelGGL(emi_chol_diag_kernel, dim3(1), dim3(256), 0, stream, A, (int)n, j0, nb, (int*)w->info);
         if (rest > 0) {
-            hipLaunchKernelGGL(emi_chol_panel_kernel, dim3((rest + 63) / 64), dim3(64), 0, stream, A, (int)n, (int)n, j0);
-            KKT_HIP(hipGetLastError());
             double* P = A + (size_t)j0 * n + j0 + nb;
+            // own kernel by default; rocblas_dtrsm (EMI_CHOL_PANEL=0) is 5 % faster on a single 1024-node solve and 20-40 %
+            // slower on eight concurrent 129-node solves (profiles/r01_notes.md)
+            static const int own_panel = getenv("EMI_CHOL_PANEL") ? atoi(getenv("EMI_CHOL_PANEL")) : 1;
+            if (own_panel) {
+                hipLaunchKernelGGL(emi_chol_panel_kernel, dim3((rest + 63) / 64), dim3(64), 0, stream, A, (int)n, (int)n, j0);
+                KKT_HIP(hipGetLastError());
+            } else {
+                KKT_RB(rocblas_dtrsm(w->handle, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose,
+                                     rocblas_diagonal_non_unit, rest, nb, &one, A + (size_t)j0 * n + j0, n, P, n));
+            }
             double* A22 = A + (size_t)(j0 + nb) * n + j0 + nb;
             KKT_RB(rocblas_dsyrk(w->handle, rocblas_fill_lower, rocblas_operation_none, rest, nb, &mone, P, n, &one, A22, n));
         }
@@ -525,6 +529,10 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         const double one = 1.0, zero = 0.0;
         rocblas_int hinfo = 0;
         int hflag = 0;
+        // (Tried: raising the diagonal relatively, S_ii (1 + 1e-12 .. 1e-6), on the retries.  At the clustered end nodes of
+        // a 1000-node mesh the entries of S reach 1e16 and an absolute 1e-3 no longer rescues the Cholesky -- the relative
+        // shift does, but the factor of such an S is too inaccurate for the refinement to repair: the 1024-node solve went
+        // from 12 to 174 iterations.  Those few matrices belong to the LU below.)
         double dc_schur = dc > 1e-9 ? dc : 1e-9;
         for (int attempt = 0; attempt < 3; ++attempt, dc_schur *= 1e3) {
             for (int i = 0; i < ns; ++i)
@@ -535,7 +543,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
                     KKT_RB(rocblas_dgemm(w->handle, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &one, w->Doff, M,
                                          w->W, M, &zero, Sblk, (rocblas_int)md));
                     hipLaunchKernelGGL(emi_kkt_sblock_terms_kernel, dim3(nb2), dim3(256), 0, stream, w->S, w->Doff, w->G, w->Rk, M,
-                                       ns, i, ip, dc_schur);
+                                       ns, i, ip, dc_schur, 0.0);
                 }
             KKT_HIP(hipGetLastError());
             if (int st = cholesky(w, stream, (rocblas_int)md, w->S, &hinfo, err)) return st;
