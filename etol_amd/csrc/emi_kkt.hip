@@ -333,11 +333,13 @@ __global__ __launch_bounds__(256) void emi_chol_diag_kernel(double* __restrict__
 // rows i >= j0 + 64 of the block column j0: x <- x L^-T with L the factorised 64 x 64 diagonal block
 __global__ __launch_bounds__(64) void emi_chol_panel_kernel(double* __restrict__ A, int lda, int n, int j0) {
     __shared__ double L[CHOL_NB][CHOL_NB + 1];
+    __shared__ double rdiag[CHOL_NB];
     const double* blk = A + (size_t)j0 * lda + j0;
     for (int idx = threadIdx.x; idx < CHOL_NB * CHOL_NB; idx += 64) {
         const int c = idx / CHOL_NB, r = idx - c * CHOL_NB;
         L[r][c] = r >= c ? blk[(size_t)c * lda + r] : 0.0;
     }
+    rdiag[threadIdx.x] = 1.0 / blk[(size_t)threadIdx.x * lda + threadIdx.x];
     __syncthreads();
     const int row = j0 + CHOL_NB + blockIdx.x * 64 + threadIdx.x;
     if (row >= n) return;
@@ -345,12 +347,12 @@ __global__ __launch_bounds__(64) void emi_chol_panel_kernel(double* __restrict__
     double* x = A + (size_t)j0 * lda + row;
 #pragma unroll
     for (int c = 0; c < CHOL_NB; ++c) y[c] = x[(size_t)c * lda];
+    // right-looking: once y_c is final it leaves every later column (independent FMAs, no dependent chain per column)
 #pragma unroll
     for (int c = 0; c < CHOL_NB; ++c) {
-        double sum = y[c];
+        y[c] *= rdiag[c];
 #pragma unroll
-        for (int t = 0; t < c; ++t) sum -= y[t] * L[c][t];
-        y[c] = sum / L[c][c];
+        for (int t = c + 1; t < CHOL_NB; ++t) y[t] -= y[c] * L[t][c];
     }
 #pragma unroll
     for (int c = 0; c < CHOL_NB; ++c) x[(size_t)c * lda] = y[c];
