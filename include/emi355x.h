@@ -45,6 +45,10 @@
  *
  * Threading: a context must be driven by one caller thread at a time
  * (the reference is single-threaded throughout).
+ * Different contexts may be driven by different threads concurrently (each
+ * owns its streams, rocBLAS handle and workspaces); results do not depend
+ * on what runs beside a context (tests/test_gpu_kkt.py,
+ * test_concurrent_contexts_give_reproducible_factorisations).
  *
  * Data layout (all arrays dense, real type = double unless the context was
  * created with emi_create_f32):
