@@ -737,6 +737,17 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     int n_acceptable = 0;
     bool force_modified = false;
     bool search_on = false, last_step_reflected = false;
+    // Raising the penalty weight is the answer to a relaxed path row only while it helps: beyond 1e5,
+    // `max_futile_escalations` tenfold raises in a row that have not halved the largest elastic variable end the solve (a keep-out that cannot be
+    // cleared from this side: the Monte-Carlo scenario of this kind used to burn 950 iterations up to rho = 1e11).
+    bool locally_infeasible = false;
+    int futile = 0;
+    double emax_ref = 1e300;
+    auto futile_escalation = [&](double emax_now) {
+        if (rho < 1e5) return false;         // weights a multiplier of a scaled row can plausibly need: keep raising
+        if (emax_now < 0.5 * emax_ref) { emax_ref = emax_now; futile = 0; return false; }
+        return ++futile >= opt.max_futile_escalations;
+    };
     int stagn = 0, crawl = 0;
     // (env: experiments, profiles/r01_notes.md) EMI_SHIFT_TRIALS=0 switches the inertia search off, EMI_CRAWL=1000 the crawl rule
     const int max_shift_trials = getenv("EMI_SHIFT_TRIALS") ? atoi(getenv("EMI_SHIFT_TRIALS")) : opt.max_shift_trials;
@@ -755,7 +766,10 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         if (err0 <= opt.tol) {
             if (emax <= std::max(opt.tol, 1e-9) * 10.0 || mc == 0) { R.ok = true; R.msg = "converged"; break; }
             // a path row is still relaxed: the penalty was too small for it
-            if (rho >= 1e12) { R.msg = "converged to a point that violates the path rows (locally infeasible)"; break; }
+            if (rho >= 1e12 || futile_escalation(emax)) {
+                R.msg = "converged to a point that violates the path rows (locally infeasible)";
+                break;
+            }
             rho *= 10.0;
             mu = std::max(mu, 1e-2);
             for (int r = 0; r < mc; ++r) { it.w1[r] = std::max(1e-8, rho - it.y[r]); it.w2[r] = std::max(1e-8, rho + it.y[r]); }
@@ -791,6 +805,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             double ymax = 0;
             for (int r = 0; r < mc; ++r) ymax = std::max(ymax, std::fabs(it.y[r]));
             if (mc > 0 && (emax > std::max(1e-6, 100.0 * mu) || ymax > 0.9 * rho) && rho < 1e12) {
+                if (futile_escalation(emax)) { locally_infeasible = true; break; }
                 rho *= 10.0;
                 mu = std::max(mu, 1e-2);
                 for (int r = 0; r < mc; ++r) { it.w1[r] = std::max(1e-8, rho - it.y[r]); it.w2[r] = std::max(1e-8, rho + it.y[r]); }
@@ -799,6 +814,10 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             }
             mu = std::max(opt.tol / 10.0, std::min(kappa_mu * mu, std::pow(mu, theta_mu)));
             nu = 1.0;    // a new barrier problem: the penalty weight is rebuilt from its multipliers, not inherited
+        }
+        if (locally_infeasible) {
+            R.msg = "the path rows stay violated while the penalty weight grows (locally infeasible)";
+            break;
         }
         const double tau = std::max(tau_min, 1.0 - mu);
 

@@ -71,6 +71,7 @@ struct NlpOptions {
     double mu_init = 0.1;
     double bound_push = 1e-2, bound_frac = 1e-2;
     double max_cpu_time = 1e9;          // seconds
+    int max_futile_escalations = 3;     // tenfold raises of the penalty weight beyond 1e5 without halving the largest elastic before giving up
     int max_shift_trials = 6;           // inertia search: trial shifts delta_w per iteration before the reflected step is taken
     double rho_init = 10.0;             // exact-penalty weight of the elastic path rows (escalated x10 as needed)
     double acceptable_factor = 100.0;   // "acceptable": KKT error <= acceptable_factor * tol ...
