@@ -310,6 +310,21 @@ def test_montecarlo_example_shards_scenarios_over_ranks_and_threads(built):
     assert len(set(round(c, 3) for c in c_all.values())) > 1          # the scenarios really differ
 
 
+def test_montecarlo_scenario_without_a_feasible_path_on_its_side_ends_early(built):
+    """Scenario 27 of the 257-node / 10 keep-out set cannot clear its keep-outs from the side the coarse meshes chose:
+    the largest elastic variable stays at 0.15 whatever the penalty weight.  The solve must say so (or, should a later
+    change find a way round, solve it) instead of raising the weight to 1e12 over a thousand iterations."""
+    exe = os.path.join(ROOT, "etol_amd", "lib", "etol_mi355x_montecarlo")
+    env = dict(os.environ, EMI_MC_ONLY="27", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([exe, "32", "256", "10", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.split("\n") if l.startswith("scenario")][0]
+    f = line.split()
+    rc, iters = int(f[f.index("rc") + 1]), int(f[f.index("iterations") + 1])
+    assert rc == 0 or "locally infeasible" in line, line
+    assert iters < 700, line
+
+
 def test_shipped_example_with_traced_obstacle_rows(H, xmls):
     """The obstacle rows of src/Examples/PSOPT/etol_psopt_example1.cpp:153-190 computed with mi355x::Var
     arithmetic in the callback (nine ellipse rows), traced and compiled into the kernels, next to the
