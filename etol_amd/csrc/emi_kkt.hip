@@ -70,6 +70,7 @@ struct KktWorkspace {
     size_t T_elems = 0, Cb_elems = 0;
     size_t cap_Pinv = 0, cap_G = 0, cap_Rk = 0, cap_Doff = 0, cap_W = 0;
     int* flag = nullptr;        // node kernel: a block was not positive definite
+    double* chol_blk = nullptr;    // [64][64] + [64]: factorised diagonal block and reciprocal diagonal of the current block column
     double* chol_copy = nullptr;   // the matrix handed to dpotrf, kept until the factorisation is confirmed (potrf_checked)
     size_t cap_chol_copy = 0;
     // low-rank correction (kkt_lowrank)
@@ -315,52 +316,60 @@ __global__ void emi_kkt_lr_utx_kernel(double* __restrict__ T, const double* __re
 const char* rb(rocblas_status s) { return rocblas_status_to_string(s); }
 
 // ---- blocked Cholesky (lower, column-major, in place) ---------------------------------------------------
-// Right-looking with 64-column blocks: the diagonal block is factorised by one workgroup in LDS, the panel below it
-// is solved one row per thread against the block held in LDS, the trailing matrix is updated by rocBLAS dsyrk.
+// Right-looking with 64-column blocks: the diagonal block is factorised by one workgroup with the rows in registers,
+// the panel below it is solved one row per thread against the block read through the scalar cache, the trailing
+// matrix is updated by rocBLAS dsyrk.
 #define CHOL_NB 64
-// A[j0.., j0..] diagonal block of size nb <= 64; *info = first non-positive pivot (1-based, global), if none yet
-__global__ __launch_bounds__(256) void emi_chol_diag_kernel(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ info) {
-    __shared__ double L[CHOL_NB][CHOL_NB + 1];
-    const int tid = threadIdx.x;
+// A[j0.., j0..] diagonal block of size nb <= 64; *info = first non-positive pivot (1-based, global), if none yet.
+// Thread (r, g) = (lane, wave) holds row r, columns g, g+4, ..: per column one LDS hand-over of the finished column
+// (double-buffered: one barrier), everything else is register arithmetic.  Lout: the factor once more, column-major
+// [64][64] with zeros above the diagonal, then the 64 reciprocals of its diagonal -- what the panel kernel reads.
+__global__ __launch_bounds__(256) void emi_chol_diag_kernel(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ info,
+                                                            double* __restrict__ Lout) {
+    __shared__ double col[2][CHOL_NB];
+    const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
     double* blk = A + (size_t)j0 * lda + j0;
-    for (int idx = tid; idx < CHOL_NB * CHOL_NB; idx += 256) {
-        const int c = idx >> 6, r = idx & 63;              // r fast: coalesced down a column
-        L[r][c] = (r >= c && r < nb) ? blk[(size_t)c * lda + r] : (r == c ? 1.0 : 0.0);
+    double a[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int cc = g + 4 * m;
+        a[m] = (r >= cc && r < nb) ? blk[(size_t)cc * lda + r] : (r == cc ? 1.0 : 0.0);
     }
-    __syncthreads();
-    // thread (r, g): row r, columns cc = c + 1 + g, c + 5 + g, ... of the trailing update -- one barrier per column
-    const int r = tid & 63, g = tid >> 6;
-    for (int c = 0; c < nb; ++c) {
-        double d = L[c][c];
-        if (!(d > 0.0)) {
-            if (tid == 0 && *info == 0) *info = j0 + c + 1;
-            d = 1.0;
+#pragma unroll
+    for (int c = 0; c < CHOL_NB; ++c) {
+        const int gc = c & 3, mc = c >> 2;
+        if (g == gc) col[c & 1][r] = a[mc];
+        __syncthreads();
+        if (c < nb) {
+            double d = col[c & 1][c];
+            if (!(d > 0.0)) {
+                if (tid == 0 && *info == 0) *info = j0 + c + 1;
+                d = 1.0;
+            }
+            const double piv = sqrt(d), inv = 1.0 / piv;
+            const double lrc = col[c & 1][r] * inv;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (4 * m + 3 <= c) continue;              // no column of this slot lies right of c
+                const int cc = g + 4 * m;
+                if (cc > c && cc <= r) a[m] -= lrc * (col[c & 1][cc] * inv);
+            }
+            if (g == gc) a[mc] = r == c ? piv : (r > c ? lrc : 0.0);
         }
-        const double piv = sqrt(d), inv = 1.0 / piv;
-        const double lrc = L[r][c] * inv;                  // own row's entry of the finished column
-        if (r > c)
-            for (int cc = c + 1 + g; cc <= r; cc += 4) L[r][cc] -= lrc * (L[cc][c] * inv);
-        __syncthreads();                                   // column c is no longer read unscaled
-        if (g == 0) L[r][c] = r == c ? piv : (r > c ? lrc : 0.0);
-        // the next column's reads touch column c+1.. only; the store above is to column c: no second barrier needed
     }
-    __syncthreads();
-    for (int idx = tid; idx < nb * nb; idx += 256) {
-        const int c = idx / nb, rr = idx - c * nb;
-        if (rr >= c) blk[(size_t)c * lda + rr] = L[rr][c];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        const int cc = g + 4 * m;
+        const double v = cc <= r ? a[m] : 0.0;
+        if (r < nb && cc <= r) blk[(size_t)cc * lda + r] = v;
+        Lout[cc * CHOL_NB + r] = v;
+        if (cc == r) Lout[CHOL_NB * CHOL_NB + r] = 1.0 / v;
     }
 }
-// rows i >= j0 + 64 of the block column j0: x <- x L^-T with L the factorised 64 x 64 diagonal block
-__global__ __launch_bounds__(64) void emi_chol_panel_kernel(double* __restrict__ A, int lda, int n, int j0) {
-    __shared__ double L[CHOL_NB][CHOL_NB + 1];
-    __shared__ double rdiag[CHOL_NB];
-    const double* blk = A + (size_t)j0 * lda + j0;
-    for (int idx = threadIdx.x; idx < CHOL_NB * CHOL_NB; idx += 64) {
-        const int c = idx / CHOL_NB, r = idx - c * CHOL_NB;
-        L[r][c] = r >= c ? blk[(size_t)c * lda + r] : 0.0;
-    }
-    rdiag[threadIdx.x] = 1.0 / blk[(size_t)threadIdx.x * lda + threadIdx.x];
-    __syncthreads();
+// rows i >= j0 + 64 of the block column j0: x <- x L^-T with L the factorised 64 x 64 diagonal block (Lb, wave-uniform
+// addresses: scalar loads, no LDS)
+__global__ __launch_bounds__(64) void emi_chol_panel_kernel(double* __restrict__ A, int lda, int n, int j0,
+                                                           const double* __restrict__ Lb) {
     const int row = j0 + CHOL_NB + blockIdx.x * 64 + threadIdx.x;
     if (row >= n) return;
     double y[CHOL_NB];
@@ -370,9 +379,9 @@ __global__ __launch_bounds__(64) void emi_chol_panel_kernel(double* __restrict__
     // right-looking: once y_c is final it leaves every later column (independent FMAs, no dependent chain per column)
 #pragma unroll
     for (int c = 0; c < CHOL_NB; ++c) {
-        y[c] *= rdiag[c];
+        y[c] *= Lb[CHOL_NB * CHOL_NB + c];
 #pragma unroll
-        for (int t = c + 1; t < CHOL_NB; ++t) y[t] -= y[c] * L[t][c];
+        for (int t = c + 1; t < CHOL_NB; ++t) y[t] -= y[c] * Lb[c * CHOL_NB + t];
     }
 #pragma unroll
     for (int c = 0; c < CHOL_NB; ++c) x[(size_t)c * lda] = y[c];
@@ -453,17 +462,19 @@ int potrf_checked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A,
 // A (n x n, lda == n) <- its lower Cholesky factor with the kernels above; *hinfo as rocsolver_dpotrf reports it
 int chol_blocked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, rocblas_int* hinfo, std::string* err) {
     KKT_HIP(hipMemsetAsync(w->info, 0, sizeof(rocblas_int), stream));
+    if (!w->chol_blk) KKT_HIP(hipMalloc((void**)&w->chol_blk, (CHOL_NB * CHOL_NB + CHOL_NB) * sizeof(double)));
     const double one = 1.0, mone = -1.0;
     for (int j0 = 0; j0 < n; j0 += CHOL_NB) {
         const int nb = std::min(CHOL_NB, (int)n - j0), rest = (int)n - j0 - nb;
-        hipLaunchKernelGGL(emi_chol_diag_kernel, dim3(1), dim3(256), 0, stream, A, (int)n, j0, nb, (int*)w->info);
+        hipLaunchKernelGGL(emi_chol_diag_kernel, dim3(1), dim3(256), 0, stream, A, (int)n, j0, nb, (int*)w->info, w->chol_blk);
         if (rest > 0) {
             double* P = A + (size_t)j0 * n + j0 + nb;
             // own kernel by default; rocblas_dtrsm (EMI_CHOL_PANEL=0) is 5 % faster on a single 1024-node solve and 20-40 %
             // slower on eight concurrent 129-node solves (profiles/r01_notes.md)
             static const int own_panel = getenv("EMI_CHOL_PANEL") ? atoi(getenv("EMI_CHOL_PANEL")) : 1;
             if (own_panel) {
-                hipLaunchKernelGGL(emi_chol_panel_kernel, dim3((rest + 63) / 64), dim3(64), 0, stream, A, (int)n, (int)n, j0);
+                hipLaunchKernelGGL(emi_chol_panel_kernel, dim3((rest + 63) / 64), dim3(64), 0, stream, A, (int)n, (int)n, j0,
+                                   (const double*)w->chol_blk);
                 KKT_HIP(hipGetLastError());
             } else {
                 KKT_RB(rocblas_dtrsm(w->handle, rocblas_side_right, rocblas_fill_lower, rocblas_operation_transpose,
@@ -491,7 +502,7 @@ void kkt_destroy(KktWorkspace* w) {
     if (!w) return;
     if (w->handle) (void)rocblas_destroy_handle(w->handle);
     void* bufs[] = {w->K, w->ipiv, w->info, w->Q, w->J, w->rhs, w->fixed, w->S, w->Pinv, w->G, w->Rk, w->Doff, w->W, w->gemm_ptrs, w->T,
-                    w->Cb, w->flag, w->chol_copy, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
+                    w->Cb, w->flag, w->chol_blk, w->chol_copy, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete w;

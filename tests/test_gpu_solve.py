@@ -317,7 +317,7 @@ def test_montecarlo_scenario_without_a_feasible_path_on_its_side_ends_early(buil
     exe = os.path.join(ROOT, "etol_amd", "lib", "etol_mi355x_montecarlo")
     env = dict(os.environ, EMI_MC_ONLY="27", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([exe, "32", "256", "10", "1"], capture_output=True, text=True, timeout=300, env=env)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode in (0, 2), r.stdout[-2000:] + r.stderr[-2000:]      # 2: not every scenario solved
     line = [l for l in r.stdout.split("\n") if l.startswith("scenario")][0]
     f = line.split()
     rc, iters = int(f[f.index("rc") + 1]), int(f[f.index("iterations") + 1])
