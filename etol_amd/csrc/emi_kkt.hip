@@ -623,6 +623,23 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
             return EMI_OK;
         }
         // a block was not positive definite or S is not: not the quasi-definite case -- general path below
+        if (getenv("EMI_KKT_DEBUG") && atoi(getenv("EMI_KKT_DEBUG")) >= 2 && hinfo > 0) {
+            // diagnosis: the node blocks around the failing pivot (diagonals of Q as uploaded and of P = Q^-1)
+            const int kf = ((int)hinfo - 1) % M, i_f = ((int)hinfo - 1) / M;
+            std::vector<double> hq((size_t)nh * M), hp((size_t)nv * nv * M);
+            std::vector<unsigned char> hf((size_t)nz);
+            (void)hipMemcpy(hq.data(), w->Q, hq.size() * sizeof(double), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hp.data(), w->Pinv, hp.size() * sizeof(double), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(hf.data(), w->fixed, hf.size(), hipMemcpyDeviceToHost);
+            fprintf(stderr, "  failing pivot: state row %d, node %d of %d\n", i_f, kf, M);
+            for (int k = std::max(0, kf - 2); k <= std::min(M - 1, kf + 2); ++k) {
+                fprintf(stderr, "  node %4d  Qdiag", k);
+                for (int v = 0; v < nv; ++v) fprintf(stderr, " %9.2e%s", hq[(size_t)(v * (v + 1) / 2 + v) * M + k], hf[(size_t)v * M + k] ? "f" : "");
+                fprintf(stderr, "   Pdiag");
+                for (int v = 0; v < nv; ++v) fprintf(stderr, " %9.2e", hp[(size_t)(v * nv + v) * M + k]);
+                fprintf(stderr, "\n");
+            }
+        }
         if (getenv("EMI_KKT_DEBUG"))
             fprintf(stderr, "emi_kkt_factor: Schur path gave up (block flag %d, potrf info %d, M %d, dc %.3g) -> LU\n", hflag,
                     (int)hinfo, M, dc);
