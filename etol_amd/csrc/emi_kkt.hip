@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void emi_chol_panel_kernel(double* __restrict__
 
 // rocsolver_dpotrf (ROCm 7.2) is not reliable while other host threads keep the GPU busy on their own handles and
 // streams: about 1 % of the calls (65-node problems, 6 threads) report a non-positive pivot in an odd 64-column block
-// of a matrix that factorises when the call is repeated on the same data (tools/scratch/race_probe.py,
+// of a matrix that factorises when the call is repeated on the same data (tools/race_probe.py,
 // profiles/r01_notes.md; dgetrf, dpotrs and the GEMMs showed no such effect).  The solver then took a more
 // regularised step than a single-threaded run, and iteration paths differed from run to run.  Two measures:
 // the calls are serialised across the process (the stream is drained first, so the lock covers the factorisation

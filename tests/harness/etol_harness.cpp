@@ -667,6 +667,26 @@ void harness_lin_interp(int n, const double* t, int nt, const double* tv, const 
     for (int i = 0; i < n; ++i) out[i] = ETOL::TrajectoryOptimizer::linear_interpolation<double>(t[i], a, b);
 }
 
+// template helpers extractTraj / scaleTraj / offsetTraj on an R x (1+C) row-major table (time first);
+// outputs: ext[R][1+nidx], sc[R][1+C], of[R][1+C]
+void harness_traj_templates(int R, int Cc, const double* tab, int nidx, const int* idxs, int nsc, const double* scv,
+                            int nof, const double* ofv, double* ext, double* sc, double* of) {
+    ETOL::traj_t tr;
+    for (int r = 0; r < R; ++r) tr.push_back({tab[r * (1 + Cc)], ETOL::state_t(tab + r * (1 + Cc) + 1, tab + (r + 1) * (1 + Cc))});
+    std::vector<size_t> ix(idxs, idxs + nidx);
+    ETOL::traj_t e = ETOL::TrajectoryOptimizer::extractTraj(tr, ix);
+    ETOL::traj_t s2 = tr, o2 = tr;
+    ETOL::TrajectoryOptimizer::scaleTraj(&s2, std::vector<double>(scv, scv + nsc));
+    ETOL::TrajectoryOptimizer::offsetTraj(&o2, std::vector<double>(ofv, ofv + nof));
+    for (int r = 0; r < R; ++r) {
+        ext[r * (1 + nidx)] = e[r].first;
+        for (int i = 0; i < nidx; ++i) ext[r * (1 + nidx) + 1 + i] = e[r].second[i];
+        sc[r * (1 + Cc)] = s2[r].first;
+        of[r * (1 + Cc)] = o2[r].first;
+        for (int c = 0; c < Cc; ++c) { sc[r * (1 + Cc) + 1 + c] = s2[r].second[c]; of[r * (1 + Cc) + 1 + c] = o2[r].second[c]; }
+    }
+}
+
 // dense LDL^T: factor + solve + inertia, for the unit test of the KKT factorisation
 int harness_ldlt(int n, const double* A, double* b, int* inertia) {
     mx::LdltFactor F;

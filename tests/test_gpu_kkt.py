@@ -183,7 +183,7 @@ def test_lowrank_correction_gives_exact_solves_and_the_inertia_verdict(built, me
 def test_concurrent_contexts_give_reproducible_factorisations(built):
     """Monte-Carlo runs factorise from several host threads at once, one context (stream, rocBLAS handle) each.
     rocsolver_dpotrf under such load now and then reports a non-positive pivot for a matrix that is positive
-    definite (tools/scratch/race_probe.py found ~1 % of the calls); emi_kkt_factor confirms a failure on a kept
+    definite (tools/race_probe.py found ~1 % of the calls); emi_kkt_factor confirms a failure on a kept
     copy before it raises the regularisation.  Here: 6 threads, the same data, every repeat of
     factor / low-rank verdict / solve must be bit-identical to the thread's first."""
     import threading

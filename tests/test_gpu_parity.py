@@ -437,3 +437,35 @@ def test_f32_defect_survives_single_precision_at_4096_nodes(built):
     err_plain = np.abs(RES_plain - ref) / (scale + np.abs(ref) + 1.0)
     assert err.max() < 2e-5, err.max()
     assert err_plain.max() > 10 * err.max()      # the unshifted form loses more than a digit on top
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_rows_match_reference_executed_callbacks(built, which):
+    """HIP path against vectors the REFERENCE's own code produced (tests/golden/ref_dymos_ex1.json:
+    src/Examples/Dymos/etol_dymos_example1.cpp callbacks run by oracle/_ref/ref_vectors on the shipped
+    ocp_2d_ex1.xml data and on a synthetic table set): the 9 ellipse rows and 2 moving-disc rows of config 1,
+    their partials, dynamics partials, cost and cost gradient; track centres bit for bit."""
+    import etol_amd as E
+    import test_ref_vectors as R
+    c = R._load("ref_dymos_ex1.json")["cases"][which]
+    M, node_t = c["M"], np.array(c["node_t"])
+    t0, tf = node_t[0], node_t[-1]
+    h = (tf - t0) / 2
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, t0, tf)
+    assert np.abs(ev.node_t - node_t).max() < 1e-14 * tf
+    ev.set_model(E.MODEL_POINTMASS2D, [])
+    X, U = np.array(c["X"]), np.array(c["U"])
+    ev.set_batch(X.shape[0])
+    recs, tx, ty = R.dymos_tables(c, E.edge_ellipse, E.track_centres)
+    ev.set_tracks(tx, ty)
+    ev.set_path(recs, 0, 1)
+    RES, VALS, COST = ev.eval_host(X, U)
+    ref = R.compare_with_reference(c, RES, VALS, h)
+    assert np.array_equal(tx, ref["centres_hdr"][:, 0]) and np.array_equal(ty, ref["centres_hdr"][:, 1])
+    assert np.abs(COST - h * (ref["L"] * ev.w).sum(axis=1)).max() < 1e-13 * np.abs(COST).max()
+    DX = np.einsum("kj,bij->bik", ev.D, X)
+    assert np.abs((DX - RES[:, :2]) / h - ref["F"]).max() < 1e-11
+    for v in range(4):
+        assert np.abs(VALS[:, 8 + 2 * recs.shape[0] + v] - h * ev.w * ref["L_p"][:, v]).max() < R.TOL * h
+    ev.close()
