@@ -367,6 +367,11 @@ int emi_set_mesh(emi_ctx_t c, int M, const double* tau, const double* w, const d
     // tables sized by M are stale now
     c->ntracks = 0;
     c->track_sets = 0;
+    // the per-block cost partials are sized B * node_chunks(M): keep them valid for the batch already set
+    if (c->B > 0) {
+        const size_t rb = c->f32 ? 4 : 8;
+        if ((st = ensure(c, c->d_cost_part, (size_t)c->B * emi::node_chunks(M) * rb))) return st;
+    }
     return EMI_OK;
 }
 
@@ -388,6 +393,9 @@ int emi_set_model(emi_ctx_t c, int model, const double* params, int nparams, int
     c->maximize = maximize ? 1 : 0;
     memset(c->params, 0, sizeof c->params);
     for (int i = 0; i < nparams; ++i) c->params[i] = params[i];
+    // path rows name states (px, py) of the previous model, which this one may not have
+    c->np = 0;
+    c->path_sets = 0;
     return EMI_OK;
 }
 

@@ -93,6 +93,7 @@ struct eMI355X::Device : public mi355x::NlpEvaluator, public mi355x::KktBackend 
     emi_ctx_t ctx = nullptr;
     int device_id = -1;
     std::string installed_source;        // text of the traced model whose code object is loaded in ctx ("" = none)
+    bool installed_maximize = false;     // ... and the objective sign it was installed with
     ~Device() override {
         if (ctx) emi_destroy(ctx);
     }
@@ -317,18 +318,18 @@ void eMI355X::addBounds() {
 
 void eMI355X::setup() {
     mi355x::Prob& P = _problem;
-    if (getXrhorizon() > 0 || getUrhorizon() > 0)
-        die("delayed states/controls (rhorizon > 0) are not supported by the device models yet");
+    // ePSOPT::dae appends delayed states for i = 1 .. Xrhorizon-1 and delayed controls for i = 1 .. Urhorizon
+    // (ePSOPT.cpp:231-248): a state horizon of 0 or 1 adds nothing (the shipped mip_2d_ex1.xml has rhorizon="1")
+    if (getXrhorizon() > 1 || getUrhorizon() > 0)
+        die("delayed states (rhorizon > 1) / delayed controls (rhorizon > 0) are not supported by the device models yet");
     P.nstates = getNStates();
     P.ncontrols = getNControls();
     P.nodes = getNSteps() + 1;                       // ePSOPT.cpp:44-45
     P.t0 = 0.;
     P.tf = getNSteps() * getDt();                    // fixed horizon, ePSOPT.cpp:151-154
     if (P.nodes < 2 || !(P.tf > 0)) die("nsteps and dt must be positive");
-    P.guess_states.clear();                          // a fresh transcription starts from the default guess
-    P.guess_controls.clear();
-    P.guess_lamF.clear();
-    P.guess_lamC.clear();
+    // a guess the user put into getProblem() before setup() is kept, as ePSOPT keeps a pre-filled
+    // phases(1).guess (ePSOPT.cpp:47-56); solve() uses it when it has the size of the first mesh
 
     traceCallbacks();
     setMesh(P.nodes);
@@ -396,10 +397,12 @@ void eMI355X::configureDevice(Device* dev) {
     emi_ctx_t c = dev->ctx;
     must(emi_set_mesh(c, (int)P.nodes, P.tau.data(), P.w.data(), P.D.data(), P.t0, P.tf), c, "emi_set_mesh");
     if (P.model == EMI_MODEL_SOURCE) {
-        if (dev->installed_source != P.model_source)      // compiled for gfx950 once per context; meshes come and go
+        // compiled for gfx950 once per context; meshes come and go.  The call also fixes the objective sign.
+        if (dev->installed_source != P.model_source || dev->installed_maximize != isMaximized())
             must(emi_set_model_source(c, "TracedModel", P.model_source.c_str(), (int)P.nstates, (int)P.ncontrols,
                                       (int)P.npath_traced, nullptr, 0, isMaximized() ? 1 : 0), c, "emi_set_model_source");
         dev->installed_source = P.model_source;
+        dev->installed_maximize = isMaximized();
     } else {
         must(emi_set_model(c, P.model, P.model_params.data(), (int)P.model_params.size(), isMaximized() ? 1 : 0), c,
              "emi_set_model");
@@ -574,6 +577,15 @@ void eMI355X::solve() {
     opt.print_level = _algorithm.print_level;
     opt.max_cpu_time = _algorithm.max_cpu_time;
 
+    // the guess vectors of the problem are working storage of the mesh loop below; the caller's own guess
+    // (ePSOPT.cpp:47-56) is put back when solve() returns, so that a second solve() starts from it again
+    struct KeepGuess {
+        mi355x::Prob& P;
+        std::vector<double> gs, gc, lf, lc;
+        explicit KeepGuess(mi355x::Prob& p) : P(p), gs(p.guess_states), gc(p.guess_controls), lf(p.guess_lamF), lc(p.guess_lamC) {}
+        ~KeepGuess() { P.guess_states = gs; P.guess_controls = gc; P.guess_lamF = lf; P.guess_lamC = lc; }
+    } keep_guess(P);
+
     mi355x::NlpResult r;
     auto solve_current_mesh = [&](const mi355x::NlpOptions& o) {
         mi355x::NlpProblem nlp = mi355x::make_nlp(P, _dev.get());
@@ -705,6 +717,8 @@ void eMI355X::solve() {
     // PSOPT's mesh refinement ("automatic", ePSOPT.cpp:69-71): solve, estimate the ODE error,
     // add nodes and re-solve from the interpolated solution until the tolerance is met.
     const bool refine = _algorithm.mesh_refinement == "automatic";
+    mi355x::NlpResult r_good;           // last converged solution and its mesh
+    size_t M_good = 0;
     for (int mr = 0;; ++mr) {
         solve_current_mesh(sequenced && mr == 0 ? warm : opt);
         ++_solution.mesh_iterations;
@@ -719,6 +733,14 @@ void eMI355X::solve() {
             solve_current_mesh(opt);
             ++_solution.mesh_iterations;
         }
+        if (!r.ok && mr > 0 && r_good.ok) {
+            // a refinement solve that fails does not take the converged coarser solution with it
+            if (_algorithm.print_level >= 5) printf("mesh iteration %d failed (%s): keeping the %zu-node solution\n", mr, r.msg.c_str(), M_good);
+            setMesh(M_good);
+            configureDevice(_dev.get());
+            r = r_good;
+            break;
+        }
         if (!r.ok || !refine) break;
         std::vector<double> zf;
         size_t M2 = 0;
@@ -731,6 +753,8 @@ void eMI355X::solve() {
         if (Mnew <= P.nodes) break;
         // refined meshes start from the interpolated solution but with the cold-start barrier settings: the
         // interpolant may cut through keep-outs between the old nodes, and the elastic rows need room to move
+        r_good = r;
+        M_good = P.nodes;
         remesh_with_guess(Mnew);
     }
     const size_t M = P.nodes;

@@ -1187,7 +1187,13 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         force_modified = false;
         if (!accepted) {
             R.msg = "line search failed";
-            if (err0 <= 1e3 * opt.tol && emax <= 1e-6) { R.ok = true; R.msg = "converged to acceptable level (line search at round-off)"; }
+            // IPOPT's rule for a search that can go no further: the point is a solution only if it meets the
+            // acceptable level (the same acceptable_factor as the iteration-count rule above); otherwise the
+            // failure is reported, with kkt_error / constr_viol for the caller to judge
+            if (err0 <= opt.acceptable_factor * opt.tol && (mc == 0 || emax <= 1e-6)) {
+                R.ok = true;
+                R.msg = "converged to acceptable level (line search at round-off)";
+            }
             break;
         }
         // accept

@@ -469,3 +469,29 @@ def test_rows_match_reference_executed_callbacks(built, which):
     for v in range(4):
         assert np.abs(VALS[:, 8 + 2 * recs.shape[0] + v] - h * ev.w * ref["L_p"][:, v]).max() < R.TOL * h
     ev.close()
+
+
+def test_setters_in_any_order_leave_no_stale_sizes(built):
+    """emi_set_mesh after emi_set_batch re-sizes the per-block cost partials (64 -> 1025 nodes is 1 -> 5 blocks per
+    instance), and emi_set_model drops a path table whose (px, py) name states of the previous model."""
+    import etol_amd as E
+    from etol_amd import _lib
+    ev = E.Evaluator(0)
+    B = 3
+    ev.set_mesh(64, 0.0, 4.0)
+    ev.set_model(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS)
+    ev.set_batch(B)
+    X, U, recs = cases.W.quadrotor_batch(11, B, 1025, 2)
+    ev.set_path(recs[:1], 3, 4)                       # rows on states 3 and 4
+    ev.set_mesh(1025, 0.0, 4.0)                       # no emi_set_batch after it
+    got = ev.eval_host(X, U)
+    ref = O.evaluate(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, 1025, (ev.tau, ev.w, ev.D), 0.0, 4.0, X, U, recs[:1], px=3, py=4)
+    assert np.abs(got[2] - ref[2]).max() / np.abs(ref[2]).max() < 1e-13
+    assert np.abs(got[0][:, 6:] - ref[0][:, 6:]).max() < 1e-12
+    ev.set_model(E.MODEL_POINTMASS2D, [])             # 2 states: a table on states (3, 4) must not survive
+    Xp, Up = cases.W.pointmass_batch(3, B, 1025)
+    RES, VALS, COST = ev.eval_host(Xp, Up)
+    assert RES.shape[1] == 2
+    refp = O.evaluate(E.MODEL_POINTMASS2D, [], 1025, (ev.tau, ev.w, ev.D), 0.0, 4.0, Xp, Up)
+    assert np.abs(COST - refp[2]).max() / np.abs(refp[2]).max() < 1e-13
+    ev.close()
