@@ -53,9 +53,12 @@ $(LIBDIR)/emi_rtc.o: $(CSRC)/emi_rtc.hip $(LIBDIR)/emi_rtc_sources.inc $(CSRC_HD
 	$(HIPCC) $(HIPFLAGS) -I$(LIBDIR) -c $< -o $@
 $(LIBDIR)/emi_host.o: $(CSRC)/emi_host.cpp include/emi355x.h | $(LIBDIR)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
+# RCCL gather (librccl is dlopen'ed at first use, not linked)
+$(LIBDIR)/emi_comm.o: $(CSRC)/emi_comm.cpp include/emi355x.h | $(LIBDIR)
+	$(CXX) $(CXXFLAGS) -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include -c $< -o $@
 
-$(LIBDIR)/libemi355x.so: $(LIBDIR)/emi_kernels.o $(LIBDIR)/emi_symdefect.o $(LIBDIR)/emi_defect_f32.o $(LIBDIR)/emi_api.o $(LIBDIR)/emi_rtc.o $(LIBDIR)/emi_kkt.o $(LIBDIR)/emi_host.o
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lhiprtc -lrocsolver -lrocblas
+$(LIBDIR)/libemi355x.so: $(LIBDIR)/emi_kernels.o $(LIBDIR)/emi_symdefect.o $(LIBDIR)/emi_defect_f32.o $(LIBDIR)/emi_api.o $(LIBDIR)/emi_rtc.o $(LIBDIR)/emi_kkt.o $(LIBDIR)/emi_host.o $(LIBDIR)/emi_comm.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^ -L$(ROCM)/lib -lhiprtc -lrocsolver -lrocblas -ldl
 
 HOST_SRC := $(HOST)/TrajectoryOptimizer.cpp $(HOST)/eMI355X.cpp $(HOST)/emi_nlp.cpp $(HOST)/emi_trace.cpp
 HOST_HDR := $(wildcard include/ETOL/*.hpp) $(wildcard $(HOST)/*.hpp) include/emi355x.h

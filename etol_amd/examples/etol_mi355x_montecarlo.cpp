@@ -4,7 +4,10 @@
 // processes (one per GPU: RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run or mpirun set them) and,
 // inside a process, over host threads that each own an ETOL::eMI355X (one device context per thread: the
 // per-iteration kernels of a single solve leave most of the GPU idle, concurrent solves fill it).
-// No communication while solving; every rank writes one summary line per scenario.
+// No communication while solving; every rank writes one summary line per scenario, then the solved
+// trajectories are gathered on rank 0 over RCCL (emi_comm_gather, include/emi355x.h): the only collective of
+// the path.  The RCCL id travels through a file that rank 0 writes (single node; EMI_COMM_FILE overrides the
+// name).  With EMI_MC_SAVE=<dir> rank 0 writes every gathered trajectory as ETOL CSV files there.
 //
 //   etol_mi355x_montecarlo <scenarios> <nsteps> <keep-outs per scenario> <threads> [traced]
 //
@@ -12,6 +15,8 @@
 // redrawn while they cover the start or the goal.  Model: the 6-state planar quadrotor, as a built-in
 // device model or (5th argument "traced") written with mi355x::Var arithmetic and compiled at setup().
 #include <ETOL/eMI355X.hpp>
+#include <emi355x.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <chrono>
@@ -59,7 +64,37 @@ struct Result {
     int scenario = -1, rc = 0, nodes = 0, iterations = 0;
     double cost = 0, seconds = 0;
     std::string message;
+    std::vector<double> states, controls, time;   // [6][nodes], [2][nodes], [nodes] of a solved scenario
 };
+
+// one gathered record per scenario: header {scenario, rc, nodes, iterations, cost} then X[6][M], U[2][M], t[M]
+constexpr int REC_HEAD = 5;
+size_t record_doubles(int M) { return REC_HEAD + (size_t)(6 + 2 + 1) * M; }
+
+// the 128-byte RCCL id goes from rank 0 to the others through a file (one node, shared /tmp)
+bool exchange_id(int rank, char* id) {
+    std::string path = getenv("EMI_COMM_FILE") ? getenv("EMI_COMM_FILE")
+                                               : "/tmp/emi_comm_" + std::to_string((long)getppid()) + "_" +
+                                                     std::string(getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + ".id";
+    if (rank == 0) {
+        if (emi_comm_unique_id(id) != EMI_OK) { fprintf(stderr, "emi_comm_unique_id: %s\n", emi_comm_last_error(nullptr)); return false; }
+        const std::string tmp = path + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f || fwrite(id, 1, EMI_COMM_ID_BYTES, f) != EMI_COMM_ID_BYTES) return false;
+        fclose(f);
+        return rename(tmp.c_str(), path.c_str()) == 0;
+    }
+    for (int tries = 0; tries < 1200; ++tries) {       // up to two minutes
+        FILE* f = fopen(path.c_str(), "rb");
+        if (f) {
+            const size_t n = fread(id, 1, EMI_COMM_ID_BYTES, f);
+            fclose(f);
+            if (n == EMI_COMM_ID_BYTES) return true;
+        }
+        usleep(100000);
+    }
+    return false;
+}
 
 Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
     Result R;
@@ -118,6 +153,7 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
     R.nodes = (int)sol->nodes;
     R.iterations = sol->nlp_iterations_total;
     R.cost = sol->error_flag ? 0.0 : t->getScore();
+    if (!sol->error_flag) { R.states = sol->states; R.controls = sol->controls; R.time = sol->time; }
     t->close();
     R.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return R;
@@ -161,5 +197,73 @@ int main(int argc, char** argv) {
            "\"model\": \"%s\", \"wall_s\": %.3f, \"solves_per_s\": %.3f, \"mean_iterations\": %.1f}\n",
            rank, world, hi - lo, ok, nsteps + 1, ndiscs, nthreads, traced ? "traced" : "built-in", wall,
            (hi - lo) / wall, results.empty() ? 0.0 : iters / results.size());
+
+    // ---- the one collective: every rank's trajectories to rank 0 over RCCL ------------------------------
+    if (env_int("EMI_MC_GATHER", 1)) {
+        const int M = nsteps + 1, per_rank = (nscen + world - 1) / world;    // equal-sized blocks, padded
+        const size_t rec = record_doubles(M), bytes = (size_t)per_rank * rec * sizeof(double);
+        std::vector<double> block((size_t)per_rank * rec, 0.0);
+        for (size_t q = 0; q < block.size(); q += rec) block[q] = -1.0;      // scenario -1 = padding
+        for (size_t i = 0; i < results.size(); ++i) {
+            const Result& r = results[i];
+            double* p = &block[i * rec];
+            p[0] = r.scenario; p[1] = r.rc; p[2] = r.nodes; p[3] = r.iterations; p[4] = r.cost;
+            if (r.rc == 0 && r.nodes == M) {
+                std::copy(r.states.begin(), r.states.end(), p + REC_HEAD);
+                std::copy(r.controls.begin(), r.controls.end(), p + REC_HEAD + 6 * M);
+                std::copy(r.time.begin(), r.time.end(), p + REC_HEAD + 8 * M);
+            }
+        }
+        auto die = [&](const char* what, const char* why) { fprintf(stderr, "rank %d: %s: %s\n", rank, what, why); return EXIT_FAILURE; };
+        char id[EMI_COMM_ID_BYTES];
+        if (!exchange_id(rank, id)) return die("RCCL id exchange", "no id file");
+        emi_ctx_t ctx = nullptr;
+        emi_comm_t comm = nullptr;
+        if (emi_create(device, &ctx) != EMI_OK) return die("emi_create", "no device");
+        if (emi_comm_create(device, world, rank, id, &comm) != EMI_OK) return die("emi_comm_create", emi_comm_last_error(nullptr));
+        void *dsend = nullptr, *drecv = nullptr;
+        if (emi_dev_alloc(ctx, bytes, &dsend) != EMI_OK || (rank == 0 && emi_dev_alloc(ctx, bytes * world, &drecv) != EMI_OK))
+            return die("emi_dev_alloc", emi_last_error(ctx));
+        if (emi_h2d(ctx, dsend, block.data(), bytes) != EMI_OK) return die("emi_h2d", emi_last_error(ctx));
+        const auto g0 = std::chrono::steady_clock::now();
+        if (emi_comm_gather(comm, dsend, drecv, bytes, 0, nullptr) != EMI_OK) return die("emi_comm_gather", emi_comm_last_error(comm));
+        const double gather_ms = 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - g0).count();
+        if (rank == 0) {
+            std::vector<double> all((size_t)world * per_rank * rec);
+            if (emi_d2h(ctx, all.data(), drecv, bytes * world) != EMI_OK) return die("emi_d2h", emi_last_error(ctx));
+            int got = 0, solved = 0;
+            double cost_sum = 0;
+            const char* save_dir = getenv("EMI_MC_SAVE");
+            for (size_t q = 0; q < all.size(); q += rec) {
+                if (all[q] < 0) continue;
+                ++got;
+                if (all[q + 1] != 0) continue;
+                ++solved;
+                cost_sum += all[q + 4];
+                if (save_dir) {
+                    ETOL::traj_t xt, ut;
+                    const double* X = &all[q + REC_HEAD];
+                    for (int k = 0; k < M; ++k) {
+                        ETOL::state_t xs, us;
+                        for (int i = 0; i < 6; ++i) xs.push_back(X[i * M + k]);
+                        for (int j = 0; j < 2; ++j) us.push_back(X[(6 + j) * M + k]);
+                        xt.push_back({X[8 * M + k], xs});
+                        ut.push_back({X[8 * M + k], us});
+                    }
+                    const std::string stem = std::string(save_dir) + "/scenario" + std::to_string((int)all[q]);
+                    ETOL::TrajectoryOptimizer::save(&xt, stem + "_state.csv");
+                    ETOL::TrajectoryOptimizer::save(&ut, stem + "_control.csv");
+                }
+            }
+            printf("{\"gathered\": %d, \"gathered_solved\": %d, \"cost_sum\": %.10f, \"world\": %d, \"bytes_per_rank\": %zu, "
+                   "\"gather_ms\": %.3f, \"collective\": \"RCCL send/recv group (emi_comm_gather)\"}\n",
+                   got, solved, cost_sum, world, bytes, gather_ms);
+            if (got != nscen && env_int("EMI_MC_ONLY", -1) < 0) return die("gather", "scenario count mismatch");
+        }
+        emi_dev_free(ctx, dsend);
+        if (drecv) emi_dev_free(ctx, drecv);
+        emi_comm_destroy(comm);
+        emi_destroy(ctx);
+    }
     return ok == hi - lo ? EXIT_SUCCESS : 2;
 }

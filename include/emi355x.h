@@ -265,6 +265,27 @@ int emi_set_option(emi_ctx_t ctx, const char* name, int value);
 /* 1 if emi_eval(EMI_EVAL_ALL) currently takes the overlapped path             */
 int emi_last_path(emi_ctx_t ctx, int* fused);
 
+/* ---- the one collective: gather of a batch's results over RCCL ---------------- */
+/* SURVEY.md section 8e / north_star: instances shard over the GPUs of a node with no
+ * communication while they are evaluated or solved; afterwards every rank hands its
+ * block to the root: one group of point-to-point ncclSend/ncclRecv over xGMI.
+ * (The reference has no distributed code; this replaces nothing, it is what lets a
+ * caller of ETOL::eMI355X run a Monte-Carlo batch on 8 GPUs and end up with every
+ * trajectory in one place.)  A communicator is its own handle, one per process/GPU.
+ * The 128-byte id is made on one rank (emi_comm_unique_id) and carried to the others
+ * by the launcher's means (a file, an environment variable, torch.distributed).     */
+#define EMI_COMM_ID_BYTES 128
+typedef struct emi_comm_s* emi_comm_t;
+int emi_comm_unique_id(void* id /* EMI_COMM_ID_BYTES, out */);
+int emi_comm_create(int device_id, int world, int rank, const void* id, emi_comm_t* out); /* collective */
+/* every rank sends `bytes` bytes of device memory; on the root, drecv[world][bytes]
+ * (device memory) receives them in rank order (the root's own block is copied).
+ * hip_stream NULL: the communicator's own stream, synchronised before returning;
+ * otherwise asynchronous on that stream.                                            */
+int emi_comm_gather(emi_comm_t comm, const void* dsend, void* drecv, size_t bytes, int root, void* hip_stream);
+int emi_comm_destroy(emi_comm_t comm);
+const char* emi_comm_last_error(emi_comm_t comm); /* NULL: error of the last handle-less call of this thread */
+
 #ifdef __cplusplus
 }
 #endif

@@ -495,3 +495,25 @@ def test_setters_in_any_order_leave_no_stale_sizes(built):
     refp = O.evaluate(E.MODEL_POINTMASS2D, [], 1025, (ev.tau, ev.w, ev.D), 0.0, 4.0, Xp, Up)
     assert np.abs(COST - refp[2]).max() / np.abs(refp[2]).max() < 1e-13
     ev.close()
+
+
+def test_rccl_gather_entry_points_world_of_one(built):
+    """emi_comm_* (the RCCL gather of include/emi355x.h) with a one-rank communicator on the test box: id, create,
+    gather to self (the root's block is a device copy), error paths.  More ranks need more GPUs: the gloo tests
+    cover the partition, the driver's multi-GPU run the transfer."""
+    import ctypes as C
+    import torch
+    from etol_amd import _lib as L
+    lib = L.load()
+    ident = (C.c_char * 128)()
+    assert lib.emi_comm_unique_id(ident) == 0, lib.emi_comm_last_error(None)
+    comm = C.c_void_p()
+    assert lib.emi_comm_create(0, 1, 1, ident, C.byref(comm)) == 1                    # rank out of range
+    assert lib.emi_comm_create(0, 1, 0, ident, C.byref(comm)) == 0, lib.emi_comm_last_error(None)
+    src = torch.arange(4096, dtype=torch.float64, device="cuda:0")
+    dst = torch.zeros(4096, dtype=torch.float64, device="cuda:0")
+    assert lib.emi_comm_gather(comm, src.data_ptr(), None, src.numel() * 8, 0, None) == 1  # root without a buffer
+    assert b"receive buffer" in lib.emi_comm_last_error(comm)
+    assert lib.emi_comm_gather(comm, src.data_ptr(), dst.data_ptr(), src.numel() * 8, 0, None) == 0, lib.emi_comm_last_error(comm)
+    assert torch.equal(src, dst)
+    assert lib.emi_comm_destroy(comm) == 0

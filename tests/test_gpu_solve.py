@@ -83,6 +83,18 @@ def test_example_program_runs(built, tmp_path, xmls):
     assert rows[0] == "time,traj0,traj1" and len(rows) >= 34
 
 
+def test_example_program_takes_the_shipped_mip_configuration(built, tmp_path, xmls):
+    """resource/configs/mip_2d_ex1.xml (states rhorizon="1", four controls) is what the reference's container feeds
+    its PSOPT example (container/singularity/ETOL-examples.def:131-132): a state horizon of 1 adds no delayed
+    state (ePSOPT.cpp:231), the two extra controls are free variables the callbacks never read."""
+    exe = os.path.join(ROOT, "etol_amd", "lib", "etol_mi355x_example1")
+    r = subprocess.run([exe, xmls["mip_2d_ex1.xml"]], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Minimization Score" in r.stdout and "Graceful Exit" in r.stdout
+    rows = open(tmp_path / "control_mi355x1.csv").read().split("\n")
+    assert rows[0] == "time,traj0,traj1,traj2,traj3" and len(rows) >= 18
+
+
 def _solve_quadrotor(H, nsteps, dt, ndiscs, refine, ode_tol=1e-4):
     D = C.POINTER(C.c_double)
     H.harness_solve_quadrotor.argtypes = [C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, D,
@@ -287,17 +299,29 @@ def test_montecarlo_example_shards_scenarios_over_ranks_and_threads(built):
     them, exactly the scenarios a single rank solves, with the same costs."""
     exe = os.path.join(ROOT, "etol_amd", "lib", "etol_mi355x_montecarlo")
 
-    def run(rank, world, threads):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    def run(rank, world, threads, **extra):
+        # the two 'ranks' of this test run one after the other on one GPU: no communicator can form, gather off
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", EMI_MC_GATHER="0" if world > 1 else "1", **extra)
         r = subprocess.run([exe, "6", "40", "4", str(threads)], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         lines = r.stdout.strip().split("\n")
-        summary = json.loads(lines[-1])
+        summary = json.loads([l for l in lines if "solves_per_s" in l][-1])
+        if world == 1:
+            summary["gather"] = json.loads([l for l in lines if "gathered" in l][-1])
         costs = {int(l.split()[1]): float(l.split()[l.split().index("cost") + 1]) for l in lines if l.startswith("scenario")}
         iters = {int(l.split()[1]): int(l.split()[l.split().index("iterations") + 1]) for l in lines if l.startswith("scenario")}
         return summary, costs, iters
 
-    s_all, c_all, i_all = run(0, 1, 3)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        s_all, c_all, i_all = run(0, 1, 3, EMI_MC_SAVE=d)
+        # the RCCL gather (emi_comm_gather through the C ABI; world 1 here) hands rank 0 every solved trajectory
+        g = s_all["gather"]
+        assert g["gathered"] == 6 and g["gathered_solved"] == 6 and abs(g["cost_sum"] - sum(c_all.values())) < 1e-6
+        for sc in range(6):
+            rows = open(os.path.join(d, f"scenario{sc}_state.csv")).read().split("\n")
+            assert rows[0] == "time,traj0,traj1,traj2,traj3,traj4,traj5" and len(rows) == 42
+            assert rows[1].startswith("0.000000,1.000000,1.000000,")            # x(t0) of the scenario set
     assert s_all["solved"] == 6 and sorted(c_all) == list(range(6))
     s0, c0, i0 = run(0, 2, 2)
     s1, c1, i1 = run(1, 2, 1)

@@ -230,3 +230,17 @@ def test_nlp_iteration_fixedwing_lateral_offset(H):
     assert abs(X[1, -1] - 10.0) <= 0.5 + 1e-9 and abs(X[1, 0]) < 1e-12          # east offset reached within xtol
     assert U[0].min() >= -1e-9 and U[0].max() <= 60 + 1e-9 and np.abs(U[1:]).max() <= 0.5 + 1e-9
     assert np.abs(X[3]).max() > 0.02                                             # it banks to get there
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/include/ETOL"), reason="reference tree not present (GPU box)")
+def test_host_sources_compile_against_the_reference_headers():
+    """Drop-in check: the eSolver, its NLP/trace code and the example compile with the REFERENCE's
+    TrajectoryOptimizer.hpp / ETOL_Types.hpp first on the include path (ours only supplies eMI355X*.hpp, emi355x.h)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    srcs = ["etol_amd/host/eMI355X.cpp", "etol_amd/host/emi_nlp.cpp", "etol_amd/host/emi_trace.cpp",
+            "etol_amd/examples/etol_mi355x_example1.cpp", "etol_amd/examples/etol_mi355x_montecarlo.cpp"]
+    for src in srcs:
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I/root/reference/include", "-Iinclude", "-Ietol_amd/host", src],
+                           cwd=root, capture_output=True, text=True)
+        assert r.returncode == 0, src + "\n" + r.stderr[-3000:]
