@@ -557,6 +557,18 @@ std::vector<double> initial_guess(const Prob& P) {
         const double b = 0.5 * (P.event_lower[ns + i] + P.event_upper[ns + i]);
         for (size_t k = 0; k < M; ++k) z0[i * M + k] = a + (b - a) * 0.5 * (P.tau[k] + 1.0);
     }
+    if (P.guess_bend != 0 && P.px < ns && P.py < ns) {
+        // the line bent sideways (half a sine wave along it): another homotopy class round the keep-outs
+        const double dx = z0[P.px * M + M - 1] - z0[P.px * M], dy = z0[P.py * M + M - 1] - z0[P.py * M];
+        const double len = std::sqrt(dx * dx + dy * dy);
+        if (len > 0)
+            for (size_t k = 0; k < M; ++k) {
+                const double s = std::sin(1.5707963267948966 * (P.tau[k] + 1.0));
+                double x = z0[P.px * M + k] - P.guess_bend * dy / len * s, y = z0[P.py * M + k] + P.guess_bend * dx / len * s;
+                z0[P.px * M + k] = std::min(std::max(x, P.state_lower[P.px]), P.state_upper[P.px]);
+                z0[P.py * M + k] = std::min(std::max(y, P.state_lower[P.py]), P.state_upper[P.py]);
+            }
+    }
     repair_guess(P, &z0[P.px * M], &z0[P.py * M]);
     if (P.guess_states.size() == ns * M) std::copy(P.guess_states.begin(), P.guess_states.end(), z0.begin());
     if (P.guess_controls.size() == nc * M)
@@ -599,6 +611,27 @@ void eMI355X::solve() {
         if (P.guess_lamC.size() == P.npath * P.nodes) nlp.lamC0 = P.guess_lamC;
         r = mi355x::solve_nlp(nlp, o, mi355x::initial_guess(P));
         _solution.nlp_iterations_total += r.iterations;
+    };
+    // A cold start that ends locally infeasible (the path rows stay violated whatever the penalty weight: the iterate
+    // sits on the wrong side of a keep-out) is repeated from the straight line bent to either side, by 15 % and 35 %
+    // of its length.  IPOPT's restoration phase does this job for ePSOPT; here it is a search over homotopy classes,
+    // decided by the first start that converges.  Only for the default guess: a user's guess is taken as given.
+    auto solve_cold_with_retries = [&](const mi355x::NlpOptions& o) {
+        solve_current_mesh(o);
+        if (r.ok || P.npath == 0 || !P.guess_states.empty() || _algorithm.guess_retries <= 0) return;
+        double span = 0;
+        if (P.event_lower.size() == 2 * ns) {
+            const double dx = 0.5 * (P.event_lower[ns + P.px] + P.event_upper[ns + P.px]) - 0.5 * (P.event_lower[P.px] + P.event_upper[P.px]);
+            const double dy = 0.5 * (P.event_lower[ns + P.py] + P.event_upper[ns + P.py]) - 0.5 * (P.event_lower[P.py] + P.event_upper[P.py]);
+            span = std::sqrt(dx * dx + dy * dy);
+        }
+        const double bends[4] = {0.15, -0.15, 0.35, -0.35};
+        for (int t = 0; t < 4 && t < _algorithm.guess_retries && !r.ok && span > 0; ++t) {
+            P.guess_bend = bends[t] * span;
+            if (_algorithm.print_level >= 5) printf("cold start failed (%s): retrying from the line bent by %+.3f\n", r.msg.c_str(), P.guess_bend);
+            solve_current_mesh(o);
+        }
+        P.guess_bend = 0;
     };
     // Multipliers are NOT carried to the next mesh by default: measured over 32 Monte-Carlo scenarios at 257 nodes the
     // costate-mapped warm start needed 112 iterations on average against 103 from zero multipliers (interior-point
@@ -689,7 +722,7 @@ void eMI355X::solve() {
             configureDevice(_dev.get());
             mi355x::NlpOptions o = li == 0 ? opt : warm;
             o.tol = std::max(opt.tol, 1e-6);          // intermediate meshes only feed the next guess
-            solve_current_mesh(o);
+            if (li == 0) solve_cold_with_retries(o); else solve_current_mesh(o);
             ++_solution.mesh_iterations;
             if (_algorithm.print_level >= 5)
                 printf("mesh sequencing: %zu nodes, %d iterations, cost %.10e (%s)\n", P.nodes, r.iterations, r.cost,
@@ -720,7 +753,7 @@ void eMI355X::solve() {
     mi355x::NlpResult r_good;           // last converged solution and its mesh
     size_t M_good = 0;
     for (int mr = 0;; ++mr) {
-        solve_current_mesh(sequenced && mr == 0 ? warm : opt);
+        if (mr == 0 && !sequenced) solve_cold_with_retries(opt); else solve_current_mesh(sequenced && mr == 0 ? warm : opt);
         ++_solution.mesh_iterations;
         if (!r.ok && sequenced && mr == 0) {
             // the ladder led into a corner (typically an interpolant cutting through a keep-out the coarse meshes
@@ -730,7 +763,7 @@ void eMI355X::solve() {
             P.guess_controls.clear();
             P.guess_lamF.clear();
             P.guess_lamC.clear();
-            solve_current_mesh(opt);
+            solve_cold_with_retries(opt);
             ++_solution.mesh_iterations;
         }
         if (!r.ok && mr > 0 && r_good.ok) {

@@ -36,6 +36,7 @@ struct Alg {
                                                    // (against stepping over thin obstacles; measured: no gain on the
                                                    // Monte-Carlo sets, off by default)
     bool mesh_sequencing = true;                   // meshes above 80 nodes are reached through 33, 65, 129, ... nodes
+    int guess_retries = 4;                         // a locally infeasible cold start is repeated from up to this many bent lines
     std::string linear_solver = "auto";            // Newton step: "host" (dense LDL^T), "device" (structured
                                                    // factorisation in HBM, emi_kkt_*), "auto" = device above 400 KKT rows
     int nlp_iter_max = 200;
@@ -83,6 +84,8 @@ struct Prob {
     std::vector<double> event_lower, event_upper;  // [2*nstates]: x(t0) then x(tf)
     std::vector<double> guess_states, guess_controls;   // optional warm start, [n][nodes]
     std::vector<double> guess_lamF, guess_lamC;         // multipliers to go with it, [nstates][nodes] / [npath][nodes]
+    double guess_bend = 0;                              // default guess: sideways offset of the straight line at mid-horizon
+                                                        // (set by solve() when it retries a locally infeasible start)
 };
 
 }  // namespace mi355x

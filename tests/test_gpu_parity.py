@@ -397,11 +397,14 @@ def test_abi_error_paths(built):
     assert lib.emi_destroy(None) == 1
 
 
-def test_f32_defect_survives_single_precision_at_4096_nodes(built):
-    """Config 5 shape: M = 4096, 12 states, f32.  The f32 MFMA kernel contracts D with x_j - s
-    (s = x at the centre of each 32-column output tile); its error is measured against the f64
-    oracle relative to sum_j |D_kj||x_j - x_k| -- the scale of the shifted terms.  Without the shift
-    (the f64-accumulating fallback on the same f32 operands) the error is 30x larger."""
+@pytest.mark.parametrize("inputs", ["smooth", "bench"])
+def test_f32_defect_survives_single_precision_at_4096_nodes(built, inputs):
+    """Config 5 shape: M = 4096, 12 states, f32, against the CPU ORACLE (oracle/emi_oracle.c: D.X accumulated in
+    long double from the f64 matrix).  The f32 MFMA kernel contracts D with x_j - s (s = x at the centre of each
+    32-column output tile); its error is measured relative to sum_j |D_kj||x_j - x_k| -- the scale of the shifted
+    terms -- on (a) smooth trajectories, what an NLP iterate looks like, and (b) the seeded random inputs of the
+    benchmark.  Without the shift (the f64-accumulating fallback on the same f32 operands) the
+    smooth case is more than a digit worse."""
     import etol_amd as E
     from etol_amd import workloads as W
     M, B = 4096, 2
@@ -409,25 +412,21 @@ def test_f32_defect_survives_single_precision_at_4096_nodes(built):
     ev.set_mesh(M, 0.0, 20.0)
     ev.set_model(E.MODEL_FIXEDWING12, W.FW_PARAMS)
     ev.set_batch(B)
-    # smooth trajectories (what an NLP iterate looks like): low-order polynomials in tau
-    rng = np.random.default_rng(99)
-    t = ev.tau
-    basis = np.stack([t ** p for p in range(6)])
-    sx = np.array([100, 100, 50, 0.4, 0.3, 3.0, 5, 2, 2, 0.5, 0.5, 0.5])
-    X = (rng.standard_normal((B, 12, 6)) * sx[None, :, None] / 3) @ basis
-    X[:, 6] += 25.0
-    U = (rng.standard_normal((B, 4, 6)) * 0.1) @ basis + np.array([30, 0, 0, 0.0])[None, :, None]
-    X = X.astype(np.float32).astype(np.float64)
+    if inputs == "smooth":
+        rng = np.random.default_rng(99)
+        basis = np.stack([ev.tau ** p for p in range(6)])                    # low-order polynomials in tau
+        sx = np.array([100, 100, 50, 0.4, 0.3, 3.0, 5, 2, 2, 0.5, 0.5, 0.5])
+        X = (rng.standard_normal((B, 12, 6)) * sx[None, :, None] / 3) @ basis
+        X[:, 6] += 25.0
+        U = (rng.standard_normal((B, 4, 6)) * 0.1) @ basis + np.array([30, 0, 0, 0.0])[None, :, None]
+    else:
+        X, U = W.fixedwing_batch(4, B, M)
+    X = X.astype(np.float32).astype(np.float64)                              # what the f32 context sees
     U = U.astype(np.float32).astype(np.float64)
     RES, _, _ = ev.eval_host(X, U)
     ev.set_option("overlap", 0)                 # forces the unshifted fallback kernel
     RES_plain, _, _ = ev.eval_host(X, U)
-    # f64 reference of the defect rows (numpy; D.X in f64 is accurate to ~1e-10 here)
-    ev64 = E.Evaluator(0)
-    ev64.set_mesh(M, 0.0, 20.0)
-    ev64.set_model(E.MODEL_FIXEDWING12, W.FW_PARAMS)
-    ev64.set_batch(B)
-    ref, _, _ = ev64.eval_host(X, U)
+    ref = O.evaluate(E.MODEL_FIXEDWING12, W.FW_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, 20.0, X, U)[0]
     A = np.abs(ev.D)
     scale = np.zeros_like(ref)
     for k0 in range(0, M, 256):
@@ -435,8 +434,10 @@ def test_f32_defect_survives_single_precision_at_4096_nodes(built):
         scale[:, :, k0:k0 + 256] = np.einsum("kj,bskj->bsk", A[k0:k0 + 256], diff)
     err = np.abs(RES - ref) / (scale + np.abs(ref) + 1.0)
     err_plain = np.abs(RES_plain - ref) / (scale + np.abs(ref) + 1.0)
-    assert err.max() < 2e-5, err.max()
-    assert err_plain.max() > 10 * err.max()      # the unshifted form loses more than a digit on top
+    print(f"f32 defect, {inputs}: max err {err.max():.3e} of sum|D||x_j - x_k| (unshifted: {err_plain.max():.3e})")
+    assert err.max() < 2e-6, err.max()          # measured 7e-8 (smooth); f32 epsilon is 6e-8
+    if inputs == "smooth":
+        assert err_plain.max() > 10 * err.max()  # the unshifted form loses more than a digit on top
 
 
 @pytest.mark.parametrize("which", [0, 1])
