@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- collocation-node constraint+Jacobian evaluations per second on MI355X.
 
-A "step" is ONE full evaluation pass of the hot path over the rank's batch of synthetic
+A "step" is ONE full evaluation pass of the hot path over the rank's share of a batch of synthetic
 problem instances (BASELINE.json config 3: 6-state quadrotor VGP, N=1024 LGL nodes, 20 static
 keep-outs), producing for every node F, C, L, the defect row, dF, dC, dL with the Jacobian
 values landed in the NLP value array and the cost reduced.
 Inputs are resident in HBM before the timed region.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--scenarios S] [--batch B] [--config c3|c5]
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-Instances shard across ranks with no data-path collective (weak scaling: B per GPU); the
-only collective of the path, the gather of the trajectories, runs once after the timed region.
+The batch is the 1024-scenario obstacle-field Monte-Carlo of config 4: it is STRONG-scaled, rank r evaluates
+scenarios [r*S/N, (r+1)*S/N) (S/N = 128 per GPU at N = 8) with no data-path collective; `value` = S*M*K / time.
+The same run then repeats the measurement weak-scaled (1024 scenarios per GPU) and reports it as a second field.
+The only collective of the path, the gather of the trajectories, runs once after the timed region.
+--config c5: the fp32 path of config 5 (12-state fixed wing, N=4096, MFMA D.X), 256 instances per GPU.
 """
 import argparse
 import json
@@ -24,12 +27,15 @@ sys.path.insert(0, ROOT)
 ALG_BYTES = {"c3": 1040, "c2": 560, "c5": 944}       # SURVEY.md section 8d, per node-eval
 HBM_PEAK_GBS = 8000.0                                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_MFMA_PEAK_TF = 78.6                               # MI355X fp64 matrix
+FP32_MFMA_PEAK_TF = 157.3                              # MI355X_MICROARCH.md: f32-input MFMA
 
 
 def load_pmc_traffic():
     """HBM bytes per launch from the PMC passes of tools/pmc_traffic.sh (FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE), if a summary of this round exists."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         return json.load(open(path)).get("bytes_per_launch", {})
     except (OSError, ValueError):
@@ -87,15 +93,45 @@ def cpu_baseline(M, n_obs, budget_s=10.0):
                                          f"derivatives and long-double D.X -- built for checking, not for speed), {e2:.1f} s"}}
 
 
+def measure(ev, dX, dU, outs, steps, warmup, barrier, torch):
+    """W untimed passes (profiled at level 1 to find the dominant kernel), then exactly `steps` passes between
+    barrier + synchronize, with ONE pair of HIP events per pass around that kernel on its own launch stream."""
+    ev.profile(1)
+    for _ in range(max(warmup, 1)):
+        ev.eval_dev(dX, dU, *outs)
+    torch.cuda.synchronize()
+    p = ev.profile_read()
+    node_w = p["node_ms"] / max(p["node_launches"], 1)
+    def_w = p["defect_ms"] / max(p["defect_launches"], 1)
+    level = 2 if def_w >= node_w else 3
+    ev.profile(level)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ev.eval_dev(dX, dU, *outs)
+    torch.cuda.synchronize()
+    barrier()
+    t1 = time.perf_counter()
+    q = ev.profile_read()
+    ev.profile(0)
+    dom_ms = (q["defect_ms"] / max(q["defect_launches"], 1)) if level == 2 else (q["node_ms"] / max(q["node_launches"], 1))
+    return dict(seconds=t1 - t0, dominant="defect" if level == 2 else "node", dominant_ms=dom_ms,
+                warm_node_ms=node_w, warm_defect_ms=def_w, overlapped=p["overlapped_passes"] > 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=1024, help="problem instances per GPU")
-    ap.add_argument("--nodes", type=int, default=1024)
+    ap.add_argument("--config", default="c3", choices=["c3", "c5"])
+    ap.add_argument("--scenarios", type=int, default=1024, help="size of the strong-scaled batch (config 4: 1024)")
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (overrides --scenarios: weak scaling)")
+    ap.add_argument("--nodes", type=int, default=0)
     ap.add_argument("--obstacles", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-weak", action="store_true", help="skip the second, weak-scaled measurement of a multi-GPU run")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     a = ap.parse_args()
 
@@ -127,116 +163,146 @@ def main():
     ctl = dev if backend == "nccl" else torch.device("cpu")   # where control-plane tensors live
 
     import etol_amd as E
+    from etol_amd import batch as shard
     from etol_amd import workloads as W
 
-    M, B, n_obs = a.nodes, a.batch, a.obstacles
-    ev = E.Evaluator(local)
-    ev.set_mesh(M, 0.0, W.TF)
-    if os.environ.get("EMI_BENCH_TRACED", "0") == "1":
-        # A/B knob: the same model written as mi355x::Var arithmetic, differentiated and compiled at run time
-        # (text from the test harness); the default run uses the hand-written kernel instantiation
-        import ctypes
-        hl = ctypes.CDLL(os.path.join(ROOT, "tests", "harness", "libetol_harness.so"))
-        hl.harness_traced_model_source.restype = ctypes.c_char_p
-        ev.set_model_source("TracedModel", hl.harness_traced_model_source(0).decode(), 6, 2)
-    else:
-        ev.set_model(E.MODEL_QUADROTOR2D, W.QUAD_PARAMS)
-    ev.set_batch(B)
-    if os.environ.get("EMI_OVERLAP", "1") == "0":
-        ev.set_option("overlap", 0)        # A/B switch: sequential general path
-    for opt in ("sym_ct", "overlap_mode", "sym_order", "sym_ablate", "cu_split"):          # experiment knobs of the overlapped path
-        if os.environ.get("EMI_" + opt.upper()):
-            ev.set_option(opt, int(os.environ["EMI_" + opt.upper()]))
-    X, U, recs = W.quadrotor_batch(3, B, M, n_obs, first_instance=rank * B)   # scenario s -> rank s // B
-    if n_obs:
-        ev.set_path(recs, 0, 1)
-    dX = torch.from_numpy(X).to(dev)
-    dU = torch.from_numpy(U).to(dev)
-    RES, VALS, COST = ev.alloc_outputs()
-    torch.cuda.synchronize()
+    c5 = a.config == "c5"
+    M = a.nodes or (4096 if c5 else 1024)
+    n_obs = 0 if c5 else a.obstacles
+    ns = 12 if c5 else 6
+    dt = torch.float32 if c5 else torch.float64
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        ev.eval_dev(dX, dU, RES, VALS, COST)
-    torch.cuda.synchronize()
-    ev.profile(True)          # HIP-event brackets around each kernel, on the launch stream
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ev.eval_dev(dX, dU, RES, VALS, COST)
-    torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
-    prof = ev.profile_read()
-    ev.profile(False)
+    def build(B, first):
+        """evaluator + resident inputs for scenarios [first, first + B)"""
+        ev = E.Evaluator(local, f32=c5)
+        ev.set_mesh(M, 0.0, 20.0 if c5 else W.TF)
+        if c5:
+            ev.set_model(E.MODEL_FIXEDWING12, W.FW_PARAMS)
+        elif os.environ.get("EMI_BENCH_TRACED", "0") == "1":
+            # A/B knob: the same model written as mi355x::Var arithmetic, differentiated and compiled at run time
+            import ctypes
+            hl = ctypes.CDLL(os.path.join(ROOT, "tests", "harness", "libetol_harness.so"))
+            hl.harness_traced_model_source.restype = ctypes.c_char_p
+            ev.set_model_source("TracedModel", hl.harness_traced_model_source(0).decode(), 6, 2)
+        else:
+            ev.set_model(E.MODEL_QUADROTOR2D, W.QUAD_PARAMS)
+        ev.set_batch(B)
+        if os.environ.get("EMI_OVERLAP", "1") == "0":
+            ev.set_option("overlap", 0)        # A/B switch: sequential general path
+        for opt in ("sym_ct", "overlap_mode", "sym_order", "sym_ablate", "cu_split", "node_store"):   # experiment knobs
+            if os.environ.get("EMI_" + opt.upper()):
+                ev.set_option(opt, int(os.environ["EMI_" + opt.upper()]))
+        if c5:
+            gen = min(B, 16)                     # 16 distinct instances tiled: the kernels do not care, the host generator does
+            X, U = W.fixedwing_batch(4, gen, M, first_instance=first)
+            X, U = np.tile(X, ((B + gen - 1) // gen, 1, 1))[:B], np.tile(U, ((B + gen - 1) // gen, 1, 1))[:B]
+            recs = None
+        else:
+            X, U, recs = W.quadrotor_batch(3, B, M, n_obs, first_instance=first)   # scenario s -> its own obstacle field
+        if n_obs:
+            ev.set_path(recs, 0, 1)
+        dX = torch.from_numpy(X).to(dev, dt)
+        dU = torch.from_numpy(U).to(dev, dt)
+        outs = ev.alloc_outputs()
+        torch.cuda.synchronize()
+        return ev, dX, dU, outs
 
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=ctl)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    el = float(el.item())
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=ctl)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- the headline measurement: the S-scenario batch strong-scaled over the ranks (or --batch per GPU) -----------
+    if a.batch:
+        lo, hi, S, scaling = rank * a.batch, (rank + 1) * a.batch, a.batch * world, "weak"
+    elif c5:
+        lo, hi, S, scaling = rank * 256, (rank + 1) * 256, 256 * world, "weak"
+    else:
+        S, scaling = a.scenarios, "strong"
+        lo, hi = shard.shard_range(S, world, rank)
+    B = hi - lo
+    ev, dX, dU, outs = build(B, lo)
+    m = measure(ev, dX, dU, outs, a.steps, a.warmup, barrier, torch)
+    el = reduce_max(m["seconds"])
     ms_per_step = 1e3 * el / a.steps
-    value = world * B * M * a.steps / el
+    value = S * M * a.steps / el
+    def_name = ev.last_defect_kernel
 
     # the path's one collective: gather the trajectories to rank 0 (once per batch, untimed)
     gather_ms = None
     if world > 1:
-        from etol_amd import batch
         gX, gU = (dX, dU) if backend == "nccl" else (dX.cpu(), dU.cpu())
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        got = batch.gather_trajectories(gX, gU, world * B, dst=0)
+        got = shard.gather_trajectories(gX, gU, S, dst=0)
         torch.cuda.synchronize()
         gather_ms = 1e3 * (time.perf_counter() - tg)
         if rank == 0:
-            assert got[0].shape[0] == world * B and torch.equal(got[0][:B].to(dX.device), dX)
+            assert got[0].shape[0] == S and torch.equal(got[0][:B].to(dX.device), dX)
+    ev.close()
+    del dX, dU, outs
+    torch.cuda.empty_cache()
+
+    weak = None
+    if world > 1 and scaling == "strong" and not a.no_weak:
+        Bw = a.scenarios
+        evw, wX, wU, wouts = build(Bw, rank * Bw)
+        mw = measure(evw, wX, wU, wouts, a.steps, a.warmup, barrier, torch)
+        elw = reduce_max(mw["seconds"])
+        weak = {"value": world * Bw * M * a.steps / elw, "unit": "node-evals/s", "instances_per_gpu": Bw,
+                "ms_per_step": 1e3 * elw / a.steps, "scaling": "weak"}
+        evw.close()
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (longest average launch, HIP events on its own stream)
-        key = "c3" if n_obs == 20 else "c2"
-        per_node = ALG_BYTES[key] if n_obs in (0, 20) else 560 + 24 * n_obs
-        alg_bytes = per_node * B * M                 # SURVEY.md 8d bytes/node-eval x node-evals per launch
-        flops = 2.0 * M * 6 * B * M                  # SURVEY.md 8d D.X flops/node-eval (2*M*ns) x node-evals
-        node_ms = prof["node_ms"] / max(prof["node_launches"], 1)
-        def_ms = prof["defect_ms"] / max(prof["defect_launches"], 1)
-        overlapped = prof["overlapped_passes"] > 0
+        # ---- roofline of the dominant kernel: algorithmic work per launch / its average launch time in the timed region
+        key = "c5" if c5 else ("c3" if n_obs == 20 else "c2")
+        per_node = ALG_BYTES[key] if (c5 or n_obs in (0, 20)) else 560 + 24 * n_obs
+        alg_bytes = per_node * B * M                 # SURVEY.md 8d bytes/node-eval x node-evals per launch (this rank)
+        flops = 2.0 * M * ns * B * M                 # SURVEY.md 8d D.X flops/node-eval (2*M*ns) x node-evals
         node_name = "emi_nodes_kernel"
-        ring = os.environ.get("EMI_SYM_CT", "3") == "3"
-        def_name = (("emi_symdefect_ring_f64_kernel" if ring else "emi_symdefect_f64_kernel") if overlapped
-                    else "emi_defect_f64_kernel")
         traffic = load_pmc_traffic()
-        if node_ms >= def_ms:
-            ach = alg_bytes / (node_ms * 1e-3) / 1e9
+        peak_tf = FP32_MFMA_PEAK_TF if c5 else FP64_MFMA_PEAK_TF
+        if m["dominant"] == "node":
+            ach = alg_bytes / (m["dominant_ms"] * 1e-3) / 1e9
             roof = {"kernel": node_name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(node_name), "avg_ms": node_ms}
+                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(node_name), "avg_ms": m["dominant_ms"]}
         else:
-            ach = flops / (def_ms * 1e-3) / 1e12
-            roof = {"kernel": def_name, "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TF,
-                    "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TF, "traffic": traffic.get(def_name),
-                    "avg_ms": def_ms}
-        roof["kernels_ms"] = {node_name: node_ms, def_name: def_ms}
-        roof["concurrent"] = overlapped
-        if overlapped:
-            pass_ms = prof["pass_ms"] / prof["overlapped_passes"]
-            roof["pass_ms"] = pass_ms                # fork -> both kernels -> join
-            roof["pass_hbm_frac"] = alg_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            ach = flops / (m["dominant_ms"] * 1e-3) / 1e12
+            roof = {"kernel": def_name, "bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s",
+                    "frac": ach / peak_tf, "traffic": traffic.get(def_name.split("<")[0]), "avg_ms": m["dominant_ms"]}
+        roof["kernels_ms_warmup"] = {node_name: m["warm_node_ms"], def_name: m["warm_defect_ms"]}
+        roof["concurrent"] = m["overlapped"]
+        roof["pass_hbm_frac"] = alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["note"] = ("avg_ms: HIP events around the dominant kernel on its launch stream, every pass of the timed region; "
+                        "kernels_ms_warmup: both kernels bracketed during the warm-up passes")
+        if c5:
+            workload = (f"config[4]: 12-state fixed-wing VGP, N={M} LGL nodes, fp32 path with MFMA D.X defect, "
+                        f"{B} instances per GPU")
+            metric = "collocation-node constraint+Jacobian evals/sec, 12-state VGP N=4096 (fp32, config 5)"
+        else:
+            workload = (f"config[2]: 6-state quadrotor VGP, N={M} LGL nodes + {n_obs} static keep-outs; "
+                        + (f"the {S}-scenario obstacle-field batch of config[3] strong-scaled: {B} instances on this GPU"
+                           if scaling == "strong" else f"{B} instances per GPU"))
+            metric = "collocation-node constraint+Jacobian evals/sec, 6-state VGP N=1024"
         line = {
-            "metric": "collocation-node constraint+Jacobian evals/sec, 6-state VGP N=1024",
+            "metric": metric,
             "value": value, "unit": "node-evals/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"config[2]: 6-state quadrotor VGP, N={M} LGL nodes + {n_obs} static keep-outs, "
-                                   f"{B} instances per GPU", "nodes": M, "instances_per_gpu": B,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": "f32" if c5 else "f64", "data": "synthetic",
+            "config": {"workload": workload, "nodes": M, "scenarios": S, "instances_per_gpu": B,
                        "path_rows": n_obs, "parallelism": f"instances sharded x{world}", "gather_ms": gather_ms},
             "roofline": roof,
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if weak:
+            line["weak_scaling"] = weak
+        if world == 1 and not a.no_cpu_baseline and not c5:
             line["cpu_baseline"] = cpu_baseline(M, n_obs, a.cpu_budget)
         print(json.dumps(line), flush=True)
-    ev.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -28,6 +28,7 @@ struct ProfEvents {
     hipEvent_t e[3];        // sequential path: e0 | node | e1 | defect | e2 ; overlapped: e0 fork, e1 join
     hipEvent_t k[4];        // overlapped path: MFMA kernel k0..k1 (main stream), node kernel k2..k3 (stream 2)
     bool has_node, has_defect, fused;
+    int level;              // 1: every bracket; 2: the defect (MFMA) kernel only; 3: the node kernel only
 };
 
 }  // namespace
@@ -43,6 +44,7 @@ struct emi_ctx_s {
     int cu_split = 0;                       // CUs given to the MFMA defect kernel; 0 = both kernels share every CU
     hipStream_t s_mfma = nullptr, s_node = nullptr;
     std::string err;
+    std::string last_defect_kernel;
 
     // mesh
     int M = 0;
@@ -50,12 +52,13 @@ struct emi_ctx_s {
     DevBuf d_w, d_t, d_Ddiag, d_D, d_De, d_Do;
     bool symmetric = false;   // D is exactly centro-antisymmetric and M is even: De/Do are valid
     bool allow_fused = true;      // "overlap" option: even/odd MFMA defect kernel || node kernel on two streams
-    int sym_ct = 3;               // MFMA kernel variant (emi_symdefect.hip): 3 = LDS-DMA ring, 1/2 = register-staged
+    int sym_ct = 0;               // MFMA kernel variant (emi_symdefect.hip): 0 = chosen from the batch, 3 = LDS-DMA ring, 5..8 state-split ring, 1/2 = register-staged
     int sym_order = 1;
     int sym_ablate = 0;
     int small_rows = 24;          // "small_rows": up to this many rows B*ns the skinny defect kernel replaces the MFMA ones
                                   // (measured at 1024 nodes, 6 states: B = 1 / 2 / 4: 21 / 29 / 53 us per pass against 83 us)
     int overlap_mode = 2;         // 2: two streams; 1: same stream, node kernel then MFMA kernel
+    int node_store = -1;          // cache policy of the node kernel's stores on the overlapped path: 0 plain, 1 sc1, 2 nt, -1 by size
     unsigned fused_attr_mask = 0;
     std::vector<double> h_tau, h_w;
     // model
@@ -76,7 +79,7 @@ struct emi_ctx_s {
     DevBuf s_X, s_U, s_RES, s_VALS, s_COST, s_LF, s_LC, s_H;
     // measurement
     hipEvent_t t_start = nullptr, t_stop = nullptr;
-    bool profile = false;
+    int profile = 0;          // emi_profile_enable level (0 off)
     std::vector<ProfEvents> prof;
     size_t prof_used = 0;
     bool attr_set = false;
@@ -192,6 +195,11 @@ void fill_node_args(emi_ctx_t c, emi::NodeArgs<T>& a, const void* dX, const void
     a.ntracks = c->ntracks;
     a.px = c->px;
     a.py = c->py;
+    // Non-temporal result stores once a pass writes more than the Infinity Cache holds (256 MB): measured on the
+    // overlapped pass, B = 1024: 0.31 -> 0.27 ms (the ~1 GB stream no longer evicts the MFMA kernel's operands);
+    // B = 128 (127 MB, stays in the cache): plain stores are 5 % faster.  profiles/r02_pass_variants.json
+    a.store_mode = c->node_store >= 0 ? c->node_store
+                                      : ((size_t)c->B * nvals_of(c) * c->M * (c->f32 ? 4 : 8) > ((size_t)300 << 20) ? 2 : 0);
     a.h = (T)((c->tf - c->t0) / 2.0);
     a.sgn = c->maximize ? T(-1) : T(1);
     for (int i = 0; i < EMI_MAX_PARAMS; ++i) a.P.p[i] = (T)c->params[i];
@@ -581,8 +589,10 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         pe->has_node = nodes;
         pe->has_defect = defect;
         pe->fused = fused;
-        HIP_TRY(c, hipEventRecord(pe->e[0], c->stream));
+        pe->level = c->profile;
+        if (pe->level == 1 || (!fused && pe->level == 3)) HIP_TRY(c, hipEventRecord(pe->e[0], c->stream));
     }
+    const int plv = pe ? pe->level : 0;
     if (fused) {
         // fork: the two kernels read X,U and write disjoint outputs, so they run concurrently.
         // The MFMA kernel goes first and takes one workgroup per CU (LDS-shaped); the streaming
@@ -604,20 +614,22 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
             HIP_TRY(c, hipStreamWaitEvent(s2, c->ev_fork, 0));
             if (split) HIP_TRY(c, hipStreamWaitEvent(s1, c->ev_fork, 0));
         }
-        if (pe) HIP_TRY(c, hipEventRecord(pe->k[0], s1));
+        if (plv == 1 || plv == 2) HIP_TRY(c, hipEventRecord(pe->k[0], s1));
         if (c->rtc) {
             HIP_TRY(c, emi::rtc_launch_symdefect(c->rtc, sa, s1));
+            c->last_defect_kernel = "emi_symdefect_ring_f64_kernel";
         } else {
             HIP_TRY(c, emi::launch_symdefect(c->model, sa, s1, !(c->fused_attr_mask & bit), c->sym_ct));
             c->fused_attr_mask |= bit;
+            const int sw = emi::last_symdefect_sw();
+            c->last_defect_kernel = sw ? "emi_symdefect_ring2_f64_kernel<SW=" + std::to_string(sw) + ">"
+                                       : (c->sym_ct == 1 || c->sym_ct == 2 ? "emi_symdefect_f64_kernel" : "emi_symdefect_ring_f64_kernel");
         }
-        if (pe) {
-            HIP_TRY(c, hipEventRecord(pe->k[1], s1));
-            HIP_TRY(c, hipEventRecord(pe->k[2], s2));
-        }
+        if (plv == 1 || plv == 2) HIP_TRY(c, hipEventRecord(pe->k[1], s1));
+        if (plv == 1 || plv == 3) HIP_TRY(c, hipEventRecord(pe->k[2], s2));
         if (c->rtc) HIP_TRY(c, emi::rtc_launch_nodes<double>(c->rtc, na, jac, false, s2));
         else HIP_TRY(c, emi::launch_nodes<double>(c->model, na, jac, false, s2));
-        if (pe) HIP_TRY(c, hipEventRecord(pe->k[3], s2));
+        if (plv == 1 || plv == 3) HIP_TRY(c, hipEventRecord(pe->k[3], s2));
         HIP_TRY(c, emi::launch_cost_finish<double>(na.cost_part, na.cost, c->B, emi::node_chunks(c->M),
                                                    na.sgn * na.h, s2));
         if (two) {
@@ -628,7 +640,7 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
                 HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
             }
         }
-        if (pe) {
+        if (plv == 1) {
             HIP_TRY(c, hipEventRecord(pe->e[1], c->stream));
             HIP_TRY(c, hipEventRecord(pe->e[2], c->stream));
         }
@@ -651,21 +663,21 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
                                                        c->stream));
         }
     }
-    if (pe) HIP_TRY(c, hipEventRecord(pe->e[1], c->stream));
+    if (plv) HIP_TRY(c, hipEventRecord(pe->e[1], c->stream));
     if (defect) {
         if (c->f32) {
             emi::DefectArgsF32 a{(const float*)dX, (const float*)c->d_D.p, (float*)dRES, c->B * c->ns,
                                  c->M, c->ns, nres_of(c)};
-            if (emi::defect_f32_mfma_supported(c->M) && c->allow_fused) HIP_TRY(c, emi::launch_defect_f32_mfma(a, c->stream));
-            else HIP_TRY(c, emi::launch_defect_f32(a, c->stream));
+            if (emi::defect_f32_mfma_supported(c->M) && c->allow_fused) { HIP_TRY(c, emi::launch_defect_f32_mfma(a, c->stream)); c->last_defect_kernel = "emi_defect_f32_mfma_kernel"; }
+            else { HIP_TRY(c, emi::launch_defect_f32(a, c->stream)); c->last_defect_kernel = "emi_defect_f32_kernel"; }
         } else {
             emi::DefectArgs a{(const double*)dX, (const double*)c->d_D.p, (double*)dRES, c->B * c->ns,
                               c->M, c->ns, nres_of(c)};
-            if (small) HIP_TRY(c, emi::launch_defect_small_f64(a, c->stream));
-            else HIP_TRY(c, emi::launch_defect_f64(a, c->stream));
+            if (small) { HIP_TRY(c, emi::launch_defect_small_f64(a, c->stream)); c->last_defect_kernel = "emi_defect_small_f64_kernel"; }
+            else { HIP_TRY(c, emi::launch_defect_f64(a, c->stream)); c->last_defect_kernel = "emi_defect_f64_kernel"; }
         }
     }
-    if (pe) HIP_TRY(c, hipEventRecord(pe->e[2], c->stream));
+    if (plv == 1 || plv == 2) HIP_TRY(c, hipEventRecord(pe->e[2], c->stream));
     return EMI_OK;
 }
 
@@ -796,7 +808,7 @@ int emi_timer_stop(emi_ctx_t c, float* ms) {
 int emi_profile_enable(emi_ctx_t c, int on) {
     if (!c) return EMI_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->profile = on != 0;
+    c->profile = (on >= 0 && on <= 3) ? on : 1;
     c->prof_used = 0;
     return EMI_OK;
 }
@@ -812,23 +824,29 @@ int emi_profile_read(emi_ctx_t c, float* node_ms, int* node_launches, float* def
         ProfEvents& pe = c->prof[i];
         float ms = 0;
         if (pe.fused) {
-            HIP_TRY(c, hipEventElapsedTime(&ms, pe.e[0], pe.e[1]));
-            fm += ms;
+            if (pe.level == 1) {
+                HIP_TRY(c, hipEventElapsedTime(&ms, pe.e[0], pe.e[1]));
+                fm += ms;
+            }
             ++fl;
-            HIP_TRY(c, hipEventElapsedTime(&ms, pe.k[0], pe.k[1]));
-            dm += ms;
-            ++dl;
-            HIP_TRY(c, hipEventElapsedTime(&ms, pe.k[2], pe.k[3]));
-            nm += ms;
-            ++nl;
+            if (pe.level == 1 || pe.level == 2) {
+                HIP_TRY(c, hipEventElapsedTime(&ms, pe.k[0], pe.k[1]));
+                dm += ms;
+                ++dl;
+            }
+            if (pe.level == 1 || pe.level == 3) {
+                HIP_TRY(c, hipEventElapsedTime(&ms, pe.k[2], pe.k[3]));
+                nm += ms;
+                ++nl;
+            }
             continue;
         }
-        if (pe.has_node) {
+        if (pe.has_node && pe.level != 2) {
             HIP_TRY(c, hipEventElapsedTime(&ms, pe.e[0], pe.e[1]));
             nm += ms;
             ++nl;
         }
-        if (pe.has_defect) {
+        if (pe.has_defect && pe.level != 3) {
             HIP_TRY(c, hipEventElapsedTime(&ms, pe.e[1], pe.e[2]));
             dm += ms;
             ++dl;
@@ -848,7 +866,7 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
     if (!c || !name) return EMI_ERR_ARG;
     if (strcmp(name, "overlap") == 0 || strcmp(name, "fused") == 0) { c->allow_fused = value != 0; return EMI_OK; }
     if (strcmp(name, "sym_ct") == 0) {
-        if (value < 1 || value > 3) return fail(c, EMI_ERR_ARG, "sym_ct must be 1, 2 or 3 (3 = LDS-DMA ring)");
+        if (value < 0 || value > 8) return fail(c, EMI_ERR_ARG, "sym_ct must be 0..8 (0/4 = chosen from the batch, 3 = LDS-DMA ring, 5..8 = state-split ring with SW = NS/2/1/3)");
         c->sym_ct = value;
         return EMI_OK;
     }
@@ -884,6 +902,11 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
     }
     if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }
     if (strcmp(name, "sym_ablate") == 0) { c->sym_ablate = value; return EMI_OK; }   // diagnostics only
+    if (strcmp(name, "node_store") == 0) {
+        if (value < -1 || value > 2) return fail(c, EMI_ERR_ARG, "node_store must be -1 (by size), 0 (plain), 1 (write-through) or 2 (non-temporal)");
+        c->node_store = value;
+        return EMI_OK;
+    }
     if (strcmp(name, "overlap_mode") == 0) {
         if (value != 1 && value != 2) return fail(c, EMI_ERR_ARG, "overlap_mode must be 1 or 2");
         c->overlap_mode = value;
@@ -897,6 +920,12 @@ int emi_last_path(emi_ctx_t c, int* fused) {
     const bool small = !c->f32 && c->B > 0 && c->B * c->ns <= c->small_rows && emi::defect_small_supported(c->B * c->ns);
     *fused = (!small && overlapped_path(c)) ? 1 : 0;
     return EMI_OK;
+}
+
+/* name of the kernel that produced the defect rows in the last emi_eval_dev of this context (for reports) */
+const char* emi_last_defect_kernel(emi_ctx_t c) {
+    if (!c) return "";
+    return c->last_defect_kernel.c_str();
 }
 
 }  // extern "C"

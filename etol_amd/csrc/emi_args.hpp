@@ -45,6 +45,7 @@ template <typename T> struct NodeArgs {
     int M, B, np, nres, nvals;
     int path_sets, track_sets, ntracks;
     int px, py;
+    int store_mode;     // launcher only: cache policy of the result stores (0 plain, 1 write-through sc1, 2 non-temporal)
     T h, sgn;
     ModelParams<T> P;
 };

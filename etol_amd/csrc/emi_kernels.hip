@@ -294,6 +294,11 @@ static hipError_t launch_nodes_model(const NodeArgs<T>& a, bool jac, hipStream_t
     const bool vec2 = (M % 2 == 0);
     const int per_block = EMI_NODE_THREADS * (vec2 ? 2 : 1);
     dim3 grid((M + per_block - 1) / per_block, a.B), block(EMI_NODE_THREADS);
+    if constexpr (sizeof(T) == 8 && !DEFROWS) {
+        // the kernel that runs beside the MFMA defect kernel: its stores may bypass L2 retention
+        if (vec2 && jac && a.store_mode == 1) { hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 2, true, DEFROWS, 1>), grid, block, 0, s, a); return hipGetLastError(); }
+        if (vec2 && jac && a.store_mode == 2) { hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 2, true, DEFROWS, 2>), grid, block, 0, s, a); return hipGetLastError(); }
+    }
     if (vec2) {
         if (jac) hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 2, true, DEFROWS>), grid, block, 0, s, a);
         else     hipLaunchKernelGGL((emi_nodes_kernel<T, Model, 2, false, DEFROWS>), grid, block, 0, s, a);

@@ -30,6 +30,7 @@ template <typename T>
 hipError_t launch_cost_finish(const T* part, T* cost, int B, int nchunks, T scale, hipStream_t s);
 bool fused_supported(int model, int M, int ct);
 hipError_t launch_symdefect(int model, const SymDefectArgs& a, hipStream_t s, bool set_attr, int ct);
+int last_symdefect_sw();   // states per workgroup of this thread's last launch_symdefect (0: the one-workgroup ring kernel / register-staged forms)
 
 // model programs compiled at run time (emi_rtc.hip); the int results are EMI_* status codes
 struct RtcModel;

@@ -24,14 +24,29 @@ EMI_DEV void load_vec(const T* __restrict__ p, T (&r)[VEC]) {
 #pragma unroll
     for (int i = 0; i < VEC; ++i) r[i] = e[i];
 }
-template <typename T, int VEC>
+// ST: cache policy of the streaming stores.  0 plain; 1 write-through (sc1): the line is not kept in the XCD's L2, so
+// the ~1 GB result stream does not evict the operands of the MFMA defect kernel that runs beside it
+// (MI355X_MICROARCH.md, stores of each flavour); 2 non-temporal.  1 and 2 exist for 16-byte packs only.
+typedef int emi_v4i __attribute__((ext_vector_type(4)));
+template <typename T, int VEC, int ST = 0>
 EMI_DEV void store_vec(T* __restrict__ p, const T (&r)[VEC]) {
     using P = typename Pack<T, VEC>::type;
     P v;
     T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
     for (int i = 0; i < VEC; ++i) e[i] = r[i];
-    *reinterpret_cast<P*>(p) = v;
+    if constexpr (ST == 1 && sizeof(P) == 16) {
+        emi_v4i q;
+        __builtin_memcpy(&q, &v, 16);
+        // the trailing s_nop keeps the compiler's next instruction off the data registers until the store has read them
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(q) : "memory");
+    } else if constexpr (ST == 2 && sizeof(P) == 16) {
+        emi_v4i q;
+        __builtin_memcpy(&q, &v, 16);
+        __builtin_nontemporal_store(q, reinterpret_cast<emi_v4i*>(p));
+    } else {
+        *reinterpret_cast<P*>(p) = v;
+    }
 }
 
 // wave64 sum (all lanes end with lane 0 holding the total)
@@ -56,7 +71,7 @@ template <typename T> EMI_DEV T wave_sum(T v) {
 // every one of them.  For the same reason the wave-uniform keep-out records
 // are read through the constant address space (scalar loads, lgkmcnt).
 // ---------------------------------------------------------------------------
-template <typename T, class Model, int VEC, bool JAC, bool DEFROWS>
+template <typename T, class Model, int VEC, bool JAC, bool DEFROWS, int ST = 0>
 __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T> a) {
     constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
     const int b = blockIdx.y;
@@ -99,7 +114,7 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T>
             }
             if (DEFROWS) {
 #pragma unroll
-                for (int i = 0; i < NS; ++i) store_vec<T, VEC>(Rb + (size_t)i * M + k0, fo[i]);
+                for (int i = 0; i < NS; ++i) store_vec<T, VEC, ST>(Rb + (size_t)i * M + k0, fo[i]);
             }
         }
         if (JAC) {
@@ -126,10 +141,10 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T>
             for (int i = 0; i < NS; ++i)
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
-                    store_vec<T, VEC>(Vb + (size_t)(i * NV + v) * M + k0, Jv[i][v]);
+                    store_vec<T, VEC, ST>(Vb + (size_t)(i * NV + v) * M + k0, Jv[i][v]);
             T* __restrict__ Gb = Vb + (size_t)(NS * NV + 2 * a.np) * M;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) store_vec<T, VEC>(Gb + (size_t)v * M + k0, gv[v]);
+            for (int v = 0; v < NV; ++v) store_vec<T, VEC, ST>(Gb + (size_t)v * M + k0, gv[v]);
         }
         // ---- K2 path constraints (records are wave-uniform: scalar loads) --
         const int np = a.np - Model::NPATH;      // rows of the record table; the model's own rows follow them
@@ -194,10 +209,10 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T>
                         cy[e] = T(-2) * dy;
                     }
                 }
-                store_vec<T, VEC>(Cb + (size_t)j * M + k0, c);
+                store_vec<T, VEC, ST>(Cb + (size_t)j * M + k0, c);
                 if (JAC) {
-                    store_vec<T, VEC>(JCb + (size_t)(2 * j) * M + k0, cx);
-                    store_vec<T, VEC>(JCb + (size_t)(2 * j + 1) * M + k0, cy);
+                    store_vec<T, VEC, ST>(JCb + (size_t)(2 * j) * M + k0, cx);
+                    store_vec<T, VEC, ST>(JCb + (size_t)(2 * j + 1) * M + k0, cy);
                 }
             }
             if constexpr (Model::NPATH > 0) {
@@ -215,10 +230,10 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T>
                 }
 #pragma unroll
                 for (int j = 0; j < NPM; ++j) {
-                    store_vec<T, VEC>(Cb + (size_t)(np + j) * M + k0, cm[j]);
+                    store_vec<T, VEC, ST>(Cb + (size_t)(np + j) * M + k0, cm[j]);
                     if (JAC) {
-                        store_vec<T, VEC>(JCb + (size_t)(2 * (np + j)) * M + k0, cxm[j]);
-                        store_vec<T, VEC>(JCb + (size_t)(2 * (np + j) + 1) * M + k0, cym[j]);
+                        store_vec<T, VEC, ST>(JCb + (size_t)(2 * (np + j)) * M + k0, cxm[j]);
+                        store_vec<T, VEC, ST>(JCb + (size_t)(2 * (np + j) + 1) * M + k0, cym[j]);
                     }
                 }
             }

@@ -69,13 +69,82 @@ static hipError_t launch_symdefect_model(const SymDefectArgs& a, hipStream_t s, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// second ring form: SW states per workgroup, 8-deep stages, 16-byte fragment reads, two (or more) workgroups per CU
+template <class Model, int SW>
+static hipError_t launch_ring2_model(const SymDefectArgs& a, hipStream_t s) {
+    constexpr int NS = Model::NS;
+    const int mtiles = (a.B + FUSED_TI - 1) / FUSED_TI, ntiles = (a.M / 2) / 64;
+    const size_t lds = (size_t)3 * ((2 * SW * FUSED_TI + 2 * 64 + 63) / 64 * 64) * 8 * sizeof(double);
+    static bool attr_done = false;          // per instantiation; a repeated call is harmless
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute((const void*)emi_symdefect_ring2_f64_kernel<Model, SW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    dim3 grid(mtiles * ntiles * (NS / SW)), block(256);
+    hipLaunchKernelGGL((emi_symdefect_ring2_f64_kernel<Model, SW>), grid, block, lds, s, a);
+    return hipGetLastError();
+}
+
+// ct 4 (and 0 = the context's default): the variant is chosen from the batch, by what was measured on MI355X with
+// the node kernel running beside it (profiles/r02_pass_variants.json; 6-state model, 1024 nodes):
+//   >= 448 full-state tiles (B = 1024: 512): SW = 2 -- 78 registers and 36 KB of LDS per workgroup leave the streaming
+//      kernel's waves the room they need on every CU (pass 0.24-0.25 ms against 0.26-0.27 with 60 KB workgroup pairs);
+//   320 .. 447 tiles (B = 768): SW = NS, all workgroups resident at once, two per CU (0.172 ms against 0.198);
+//   192 .. 319 tiles (B = 512): the one-workgroup-per-CU ring kernel, whose grid is then a single round;
+//   fewer (the shard of config 4: 128 instances = 64 tiles): SW = 1, 384 workgroups instead of 64.
+// 5 / 6 / 7 / 8 force SW = NS / 2 / 1 / 3.   Returns -1 for "use the first ring kernel (ct 3)".
+static thread_local int g_last_sw = 0;      // states per workgroup of the last state-split launch (0: first ring kernel)
+int last_symdefect_sw() { return g_last_sw; }
+
+template <class Model>
+static hipError_t launch_ring2_auto(const SymDefectArgs& a, hipStream_t s, int ct, bool* use_ring1) {
+    constexpr int NS = Model::NS;
+    g_last_sw = 0;
+    const int nwg_full = ((a.B + FUSED_TI - 1) / FUSED_TI) * ((a.M / 2) / 64);
+    int sw = NS;
+    *use_ring1 = false;
+    if (ct == 4 || ct == 0) {
+        if (nwg_full >= 448) sw = (NS % 2 == 0 && NS > 2) ? 2 : NS;
+        else if (nwg_full >= 320) sw = NS;
+        else if (nwg_full >= 192) { *use_ring1 = true; return hipSuccess; }
+        else sw = 1;
+    } else {
+        sw = ct == 5 ? NS : (ct == 6 ? 2 : (ct == 8 ? 3 : 1));
+    }
+    g_last_sw = sw;
+    if (sw == NS) return launch_ring2_model<Model, NS>(a, s);
+    if constexpr (NS > 2 && NS % 2 == 0) {
+        if (sw == 2) return launch_ring2_model<Model, 2>(a, s);
+    }
+    if constexpr (NS > 3 && NS % 3 == 0) {
+        if (sw == 3) return launch_ring2_model<Model, 3>(a, s);
+    }
+    g_last_sw = 1;
+    return launch_ring2_model<Model, 1>(a, s);
+}
+
 bool fused_supported(int model, int M, int ct) {
+    if (ct == 0 || (ct >= 4 && ct <= 8))
+        return (model == EMI_MODEL_POINTMASS2D || model == EMI_MODEL_QUADROTOR2D) && M >= 128 && M % 128 == 0;
     const int w = ct == 2 ? 2 : 1;     // ct == 3 is the ring variant of the 64-column tiling
     return (model == EMI_MODEL_POINTMASS2D || model == EMI_MODEL_QUADROTOR2D) && ct >= 1 && ct <= 3 &&
            M >= 128 * w && M % (128 * w) == 0;
 }
 
 hipError_t launch_symdefect(int model, const SymDefectArgs& a, hipStream_t s, bool set_attr, int ct) {
+    g_last_sw = 0;
+    if (ct == 0 || (ct >= 4 && ct <= 8)) {
+        bool ring1 = false;
+        hipError_t e = hipErrorInvalidValue;
+        if (model == EMI_MODEL_POINTMASS2D) e = launch_ring2_auto<PointMass2D<double>>(a, s, ct, &ring1);
+        if (model == EMI_MODEL_QUADROTOR2D) e = launch_ring2_auto<Quadrotor2D<double>>(a, s, ct, &ring1);
+        if (!ring1) return e;
+        ct = 3;
+        set_attr = true;    // cheap; the attribute bookkeeping of the caller is per requested ct
+    }
     if (ct == 3) {   // LDS-DMA ring variant (column tiling as ct == 1)
         if (model == EMI_MODEL_POINTMASS2D) return launch_symdefect_ring_model<PointMass2D<double>>(a, s, set_attr);
         if (model == EMI_MODEL_QUADROTOR2D) return launch_symdefect_ring_model<Quadrotor2D<double>>(a, s, set_attr);

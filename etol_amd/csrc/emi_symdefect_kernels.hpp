@@ -330,4 +330,171 @@ __global__ __launch_bounds__(256, 2) void emi_symdefect_ring_f64_kernel(SymDefec
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ring kernel, second form: SW states per workgroup, 8-deep K tiles, 16-byte fragment reads.
+//   * A ring stage is 20 KB (SW = 6; three stages 60 KB), so TWO workgroups share a CU: the prologue (two DMA
+//     round trips), the epilogue (f at the output nodes, stores) and the barrier skew of one workgroup are
+//     covered by the other's MFMAs.  Measured with operands in registers (tools/diag/clock_probe.hip):
+//     v_mfma_f64_16x16x4_f64 issues every 64-68 cycles per SIMD at 2.39 GHz with one wave per SIMD and with
+//     two, i.e. 74-76 TFLOP/s: the matrix pipe is not what held the first ring kernel at 37.
+//   * One ds_read_b128 per operand row and K tile.  The MFMA sums over k, so WHICH k a lane holds in which
+//     k-step is free as long as A and B agree: lane group kq takes k = 2kq in the first step of a tile and
+//     k = 2kq+1 in the second, i.e. one 16-byte chunk per row.  (With k = 4 ks + kq the compiler pairs the
+//     8-byte reads into ds_read2st64_b64, which moves half the bytes per LDS cycle and, with 32 banks in
+//     its lane groups, was 2-way conflicted on this image: 224 LDS cycles per wave and tile against 56 now.)
+//   * SW < NS splits the states of an instance group over NS/SW workgroups (each re-reads the De/Do panel,
+//     which is L2-resident): a shard of config 4 (128 instances) then launches 384 workgroups instead of 64.
+// Tile: 16 instances x SW states (rows of XF / XM, 64 B each) against 64 half-indices (rows of De / Do); 4 waves,
+// wave w owns half-indices 16w .. 16w+15.  Row r keeps its 16-byte chunk c at position c ^ swz(r), swz(r) =
+// (-(r >> 2)) & 3, applied to the DMA source address and to the fragment read address: each of the four
+// 16-lane groups of a ds_read_b128 then covers a 256-byte bank row exactly once (MI355X_MICROARCH.md, LDS).
+// ---------------------------------------------------------------------------------------------
+EMI_DEV constexpr int ring_swz(int r) { return (0 - (r >> 2)) & 3; }
+
+template <class Model, int SW>
+__global__ __launch_bounds__(256, 2) void emi_symdefect_ring2_f64_kernel(SymDefectArgs a) {
+    constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
+    constexpr int TI = FUSED_TI, TM = SW * TI, TN = 64, NST = 3, BK = 8, CH = 4, NSG = NS / SW;
+    constexpr int ROWS = 2 * TM + 2 * TN;
+    constexpr int ROWS_PAD = (ROWS + 63) / 64 * 64;      // a DMA wave instruction moves 16 rows: 4 waves x 16 rows
+    constexpr int STAGE = ROWS_PAD * BK;                 // doubles per ring stage
+    constexpr int L = ROWS_PAD * CH / 256;               // LDS-DMA instructions per wave and stage (1 KB each)
+    static_assert(NS % SW == 0, "states split evenly over workgroups");
+
+    extern __shared__ __attribute__((aligned(16))) double smem[];   // [NST][STAGE]: XF, XM, De, Do (, padding)
+
+    const int M = a.M, Hh = M >> 1, B = a.B;
+    const int ntiles = Hh / TN;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: an XCD gets a contiguous run of tiles
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    // the ntiles workgroups that share one X tile (same instance group, same states) are neighbours: one XCD's L2
+    const int ntile = bid % ntiles, grp = bid / ntiles;
+    const int sg = grp % NSG, mtile = grp / NSG;
+    const int inst0 = mtile * TI, i0 = ntile * TN, s0 = sg * SW;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    const double* src[L];
+    int kdir[L];
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+        const int q = (wid + 4 * t) * 64 + lane;       // 16-byte chunk id within the stage
+        const int row = q >> 2, p = q & 3;
+        if (row < 2 * TM) {
+            const bool mir = row >= TM;
+            const int rr = mir ? row - TM : row;
+            const int c = p ^ ring_swz(rr);
+            int inst = inst0 + (rr & 15);
+            inst = inst < B ? inst : B - 1;            // rows past the batch are never written out
+            const double* xr = a.X + ((size_t)inst * NS + s0 + (rr >> 4)) * M;
+            src[t] = mir ? xr + (M - BK) + 2 * c : xr + 2 * c;
+            kdir[t] = mir ? -1 : 1;
+        } else if (row < ROWS) {
+            const bool od = row >= 2 * TM + TN;
+            const int rr = row - 2 * TM - (od ? TN : 0);
+            const int c = p ^ ring_swz(rr);
+            src[t] = (od ? a.Do : a.De) + (size_t)(i0 + rr) * Hh + 2 * c;
+            kdir[t] = 1;
+        } else {                                       // padding rows of the last DMA instruction: never read
+            src[t] = a.De + 2 * p;
+            kdir[t] = 0;
+        }
+    }
+    auto issue = [&](int stage, int kt) {
+        double* base = smem + (size_t)stage * STAGE;
+#pragma unroll
+        for (int t = 0; t < L; ++t) {
+            double* dst = base + (size_t)(wid + 4 * t) * 128;      // wave-uniform: 1 KB per instruction
+            const double* g = src[t] + (ptrdiff_t)kdir[t] * kt * BK;
+            __builtin_amdgcn_global_load_lds((emi_glb_ptr_t)g, (emi_lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
+
+    d4 acc_a[SW], acc_b[SW];
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+        acc_a[s] = d4{0.0, 0.0, 0.0, 0.0};
+        acc_b[s] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+
+    const int nkt = Hh / BK;
+    issue(0, 0);
+    if (nkt > 1) issue(1, 1);
+    // fragment addresses (doubles within a stage): B rows of this wave, A rows of every state
+    const int rb = wid * 16 + r16;
+    const int off_b = rb * BK + ((kq ^ ring_swz(rb)) << 1);
+    int off_f[SW], off_m[SW];
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+        const int r = s * 16 + r16;
+        off_f[s] = r * BK + ((kq ^ ring_swz(r)) << 1);               // chunk kq: x_(2kq), x_(2kq+1)
+        off_m[s] = (TM + r) * BK + (((3 - kq) ^ ring_swz(r)) << 1);  // chunk 3-kq of the mirrored tile
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tile kt has landed once all but this wave's L youngest DMA instructions are done
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");     // every wave's part landed; stage (kt-1)%3 is free
+        if (kt + 2 < nkt && !(a.ablate & 2)) issue((kt + 2) % NST, kt + 2);
+        if (a.ablate & 1) continue;
+        const double* S = smem + (size_t)(kt % NST) * STAGE;
+        const double2 be = *reinterpret_cast<const double2*>(S + 2 * TM * BK + off_b);
+        const double2 bo = *reinterpret_cast<const double2*>(S + (2 * TM + TN) * BK + off_b);
+        double2 xf[SW], xm[SW];
+#pragma unroll
+        for (int s = 0; s < SW; ++s) {
+            xf[s] = *reinterpret_cast<const double2*>(S + off_f[s]);
+            xm[s] = *reinterpret_cast<const double2*>(S + off_m[s]);
+        }
+        // k = 2kq (+1): forward x_k in xf.x (.y), its mirror x_(N-k) at position 7-k of the mirrored tile: xm.y (.x)
+#pragma unroll
+        for (int s = 0; s < SW; ++s) {
+            acc_a[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[s].x + xm[s].y, be.x, acc_a[s], 0, 0, 0);
+            acc_b[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[s].x - xm[s].y, bo.x, acc_b[s], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < SW; ++s) {
+            acc_a[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[s].y + xm[s].x, be.y, acc_a[s], 0, 0, 0);
+            acc_b[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[s].y - xm[s].x, bo.y, acc_b[s], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: defect = D.X - h f, forward node i and mirrored node N-i, states s0 .. s0+SW-1 ----
+    const int col = wid * 16 + r16;
+    const int node_f = i0 + col, node_m = M - 1 - node_f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int inst = inst0 + kq + 4 * i;
+        if (inst >= B || (a.ablate & 4)) continue;
+        const double* __restrict__ Xb = a.X + (size_t)inst * NS * M;
+        const double* __restrict__ Ub = a.U + (size_t)inst * NC * M;
+        double* __restrict__ Rb = a.RES + (size_t)inst * a.nres * M;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int node = side == 0 ? node_f : node_m;
+            double z[NV], f[NS];
+#pragma unroll
+            for (int v = 0; v < NS; ++v) z[v] = Xb[(size_t)v * M + node];
+#pragma unroll
+            for (int v = 0; v < NC; ++v) z[NS + v] = Ub[(size_t)v * M + node];
+            Model::f(a.P, z, a.node_t[node], f);
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                double fs = f[s];                       // f[s0 + s] without a runtime register index
+                if (SW < NS) {
+#pragma unroll
+                    for (int v = 0; v < NS; ++v) fs = (v == s0 + s) ? f[v] : fs;
+                }
+                const double dx = side == 0 ? acc_a[s][i] + acc_b[s][i] : acc_b[s][i] - acc_a[s][i];
+                Rb[(size_t)(s0 + s) * M + node] = dx - a.h * fs;
+            }
+        }
+    }
+}
+
 }  // namespace emi

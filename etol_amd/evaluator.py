@@ -219,8 +219,9 @@ class Evaluator:
         self._ck(self.lib.emi_timer_stop(self.ctx, C.byref(ms)), "emi_timer_stop")
         return ms.value
 
-    def profile(self, on):
-        self._ck(self.lib.emi_profile_enable(self.ctx, int(on)), "emi_profile_enable")
+    def profile(self, level):
+        """0 off, 1 every bracket, 2 the defect (MFMA) kernel only, 3 the node kernel only (include/emi355x.h)"""
+        self._ck(self.lib.emi_profile_enable(self.ctx, int(level)), "emi_profile_enable")
 
     def profile_read(self):
         nm, dm, fm = C.c_float(), C.c_float(), C.c_float()
@@ -232,6 +233,10 @@ class Evaluator:
 
     def set_option(self, name, value):
         self._ck(self.lib.emi_set_option(self.ctx, name.encode(), int(value)), "emi_set_option")
+
+    @property
+    def last_defect_kernel(self):
+        return self.lib.emi_last_defect_kernel(self.ctx).decode()
 
     @property
     def uses_fused_kernel(self):

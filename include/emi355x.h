@@ -243,10 +243,12 @@ int emi_hess_host(emi_ctx_t ctx, const double* X, const double* U,
 /* HIP-event timers on the context's stream.                                 */
 int emi_timer_start(emi_ctx_t ctx);
 int emi_timer_stop(emi_ctx_t ctx, float* elapsed_ms); /* synchronises */
-/* Per-kernel event brackets inside emi_eval_dev (adds two events/launch).
- * node/defect: the two kernels of the sequential path; fused: the whole
- * overlapped pass (fork -> both kernels -> join).                            */
-int emi_profile_enable(emi_ctx_t ctx, int on);
+/* Per-kernel event brackets inside emi_eval_dev, recorded on the stream the
+ * kernel is launched on.  level 1: every bracket (both kernels and the whole
+ * overlapped pass: eight events per pass, ~25 us of dependency latency on a
+ * 0.25 ms pass -- for diagnosis); 2: the defect (MFMA) kernel only; 3: the
+ * node kernel only (two events per pass); 0: off.                            */
+int emi_profile_enable(emi_ctx_t ctx, int level);
 int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
                      float* defect_ms, int* defect_launches,
                      float* fused_ms, int* fused_launches); /* syncs+resets */
@@ -256,14 +258,22 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * kernel (emi_symdefect.hip) and the streaming node kernel CONCURRENTLY on two
  * streams when the mesh allows it (f64, M % 128 == 0, centro-antisymmetric D,
  * 2- or 6-state model); 0 forces the general node-then-defect sequence.
- * "sym_ct": MFMA kernel variant, 3 (default) = LDS-DMA operand ring, 1 / 2 =
- * register-staged with 64 / 128 columns per workgroup (2 needs M % 256 == 0).
- * "sym_order" (default 1): workgroup -> tile order within an XCD.
+ * "sym_ct": MFMA kernel variant.  0 (default) = chosen from the batch size;
+ * 3 = LDS-DMA operand ring, one workgroup per CU; 5 / 6 / 7 / 8 = the ring with
+ * SW = NS / 2 / 1 / 3 states per workgroup, 8-deep K tiles, several workgroups per
+ * CU; 4 = as 0; 1 / 2 = register-staged, 64 / 128 columns (2 needs M % 256 == 0).
+ * "node_store": cache policy of the node kernel's result stores on the overlapped
+ * path: -1 (default) non-temporal once a pass writes more than the Infinity Cache
+ * holds, 0 plain, 1 write-through, 2 non-temporal.
+ * "sym_order" (default 1): workgroup -> tile order within an XCD (sym_ct 1..3).
  * "overlap_mode" (2 = two streams, default; 1 = same stream back to back).
  * "sym_ablate": diagnostics only, results invalid.                             */
 int emi_set_option(emi_ctx_t ctx, const char* name, int value);
 /* 1 if emi_eval(EMI_EVAL_ALL) currently takes the overlapped path             */
 int emi_last_path(emi_ctx_t ctx, int* fused);
+/* name of the kernel that produced the defect rows in this context's last
+ * emi_eval_dev (what a rocprofv3 kernel trace will show); "" before the first  */
+const char* emi_last_defect_kernel(emi_ctx_t ctx);
 
 /* ---- the one collective: gather of a batch's results over RCCL ---------------- */
 /* SURVEY.md section 8e / north_star: instances shard over the GPUs of a node with no

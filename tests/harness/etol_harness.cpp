@@ -324,6 +324,8 @@ void configure_quadrotor(ETOL::TrajectoryOptimizer* t, QuadSetup& q, int nsteps,
 
 extern "C" void harness_set_quad_tau_max(double v) { g_quad_tau_max = v; }
 extern "C" void harness_set_traced(int on) { g_traced = on; }
+int g_refine = -1;              // harness_solve_example1: -1 = the setup() default ("automatic"), 0 = "none", 1 = "automatic"
+extern "C" void harness_set_refine(int mode) { g_refine = mode; }
 extern "C" void harness_set_linear_solver(const char* name) { g_linear_solver = name; }
 extern "C" const char* harness_last_linear_solver(void) { return g_out2.c_str(); }
 
@@ -786,6 +788,7 @@ int harness_solve_example1(const char* xml, int with_obstacles, double tol, int 
     e.solver.getAlgorithm()->nlp_tolerance = tol;
     e.solver.getAlgorithm()->print_level = print_level;
     e.solver.getAlgorithm()->linear_solver = g_linear_solver;
+    if (g_refine >= 0) e.solver.getAlgorithm()->mesh_refinement = g_refine ? "automatic" : "none";
     t->solve();
     g_out2 = e.solver.getSolution()->linear_solver;
     const mx::Sol* s = e.solver.getSolution();

@@ -435,7 +435,9 @@ def test_f32_defect_survives_single_precision_at_4096_nodes(built, inputs):
     err = np.abs(RES - ref) / (scale + np.abs(ref) + 1.0)
     err_plain = np.abs(RES_plain - ref) / (scale + np.abs(ref) + 1.0)
     print(f"f32 defect, {inputs}: max err {err.max():.3e} of sum|D||x_j - x_k| (unshifted: {err_plain.max():.3e})")
-    assert err.max() < 2e-6, err.max()          # measured 7e-8 (smooth); f32 epsilon is 6e-8
+    # measured: smooth 6.6e-8 (f32 epsilon is 6e-8; unshifted 2.2e-6); bench inputs 1.4e-6 -- with random node values
+    # x_j - s is as large as x_j, the shift buys nothing and 4096 f32 accumulations cost ~20 epsilon
+    assert err.max() < (2e-6 if inputs == "smooth" else 5e-6), err.max()
     if inputs == "smooth":
         assert err_plain.max() > 10 * err.max()  # the unshifted form loses more than a digit on top
 
@@ -518,3 +520,28 @@ def test_rccl_gather_entry_points_world_of_one(built):
     assert lib.emi_comm_gather(comm, src.data_ptr(), dst.data_ptr(), src.numel() * 8, 0, None) == 0, lib.emi_comm_last_error(comm)
     assert torch.equal(src, dst)
     assert lib.emi_comm_destroy(comm) == 0
+
+
+@pytest.mark.parametrize("sym_ct", [3, 5, 6, 7, 8, 0])
+@pytest.mark.parametrize("shape", [(1024, 5), (256, 19), (128, 33)])
+def test_every_mfma_defect_kernel_variant_matches_the_oracle(built, sym_ct, shape):
+    """The even/odd MFMA defect kernels (one-workgroup ring; state-split rings with SW = 6 / 2 / 1 / 3; the choice by
+    batch size), with the streaming kernel beside them and its three store policies: same results as the oracle at
+    several mesh and batch sizes (B not a multiple of the 16-instance tile, M = 128 = one tile)."""
+    import etol_amd as E
+    M, B = shape
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 9.0)
+    ev.set_model(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS)
+    ev.set_batch(B)
+    X, U, recs = cases.W.quadrotor_batch(21, B, M, 3)
+    ev.set_path(recs[:1], 0, 1)
+    ev.set_option("sym_ct", sym_ct)
+    ref = O.evaluate(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, 9.0, X, U, recs[:1])
+    c = dict(X=X)
+    for store in (0, 1, 2):
+        ev.set_option("node_store", store)
+        got = ev.eval_host(X, U)
+        assert ev.uses_fused_kernel
+        check(c, ev, got, ref)
+    ev.close()
