@@ -57,7 +57,7 @@ struct emi_ctx_s {
     int sym_ablate = 0;
     int small_rows = 24;          // "small_rows": up to this many rows B*ns the skinny defect kernel replaces the MFMA ones
                                   // (measured at 1024 nodes, 6 states: B = 1 / 2 / 4: 21 / 29 / 53 us per pass against 83 us)
-    int overlap_mode = 2;         // 2: two streams; 1: same stream, node kernel then MFMA kernel
+    int overlap_mode = 0;         // 0: by batch size (3 below 192 tiles, else 2); 1: one stream, back to back; 2: two streams; 3: one launch
     int node_store = -1;          // cache policy of the node kernel's stores on the overlapped path: 0 plain, 1 sc1, 2 nt, -1 by size
     unsigned fused_attr_mask = 0;
     std::vector<double> h_tau, h_w;
@@ -75,6 +75,9 @@ struct emi_ctx_s {
     int ntracks = 0, track_sets = 0;
     DevBuf d_trkx, d_trky;
     DevBuf d_cost_part;
+    DevBuf d_slab;              // partial sums of a split-K defect launch
+    DevBuf d_ticket;            // [B] arrival counters of the in-kernel COST finish (zeroed once, self-resetting)
+    int sym_ksplit = 0;         // "sym_ksplit" option: K slices of an SW = NS launch (0: by batch size)
     // host-form staging
     DevBuf s_X, s_U, s_RES, s_VALS, s_COST, s_LF, s_LC, s_H;
     // measurement
@@ -179,6 +182,7 @@ void fill_node_args(emi_ctx_t c, emi::NodeArgs<T>& a, const void* dX, const void
     a.VALS = (T*)dVALS;
     a.cost_part = (T*)c->d_cost_part.p;
     a.cost = (T*)dCOST;
+    a.cost_ticket = nullptr;
     a.w = (const T*)c->d_w.p;
     a.node_t = (const T*)c->d_t.p;
     a.Ddiag = (const T*)c->d_Ddiag.p;
@@ -258,7 +262,7 @@ int emi_destroy(emi_ctx_t c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_w, &c->d_t, &c->d_Ddiag, &c->d_D, &c->d_De, &c->d_Do, &c->d_path, &c->d_trkx, &c->d_trky,
-                      &c->d_cost_part, &c->s_X, &c->s_U, &c->s_RES, &c->s_VALS, &c->s_COST,
+                      &c->d_cost_part, &c->d_slab, &c->d_ticket, &c->s_X, &c->s_U, &c->s_RES, &c->s_VALS, &c->s_COST,
                       &c->s_LF, &c->s_LC, &c->s_H};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -600,11 +604,38 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
         emi::SymDefectArgs sa;
         sa.X = (const double*)dX; sa.U = (const double*)dU; sa.RES = (double*)dRES;
         sa.node_t = (const double*)c->d_t.p; sa.De = (const double*)c->d_De.p; sa.Do = (const double*)c->d_Do.p;
-        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0; sa.order = c->sym_order; sa.ablate = c->sym_ablate;
+        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0; sa.order = c->sym_order; sa.ablate = c->sym_ablate; sa.ksplit = 1; sa.slab = nullptr;
         for (int i = 0; i < EMI_MAX_PARAMS; ++i) sa.P.p[i] = c->params[i];
         emi::NodeArgs<double> na;
         fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
-        const bool two = c->overlap_mode == 2;
+        const int tiles16 = ((c->B + 15) / 16) * (c->M / 128);
+        const bool auto_mode = c->overlap_mode == 0;
+        if ((c->overlap_mode == 3 || (auto_mode && tiles16 < 192)) && !c->rtc && jac) {
+            // The pass as ONE launch: MFMA-role and node-role workgroups in one grid, COST finished in-kernel.
+            // Chosen by itself for small batches, where the fork / join of the two-stream form costs as much as a
+            // kernel (B = 128: 0.055 ms against 0.060; B = 256: 0.081 against 0.090; from B = 512 the two streams win,
+            // 0.130 against 0.167: profiles/r02_pass_variants.json).
+            emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, 1);
+            if (auto_mode && (c->sym_ct == 0 || c->sym_ct == 4))
+                plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 <= 96 ? 7 : 6, 1);        // SW = 1 / 2
+            else if (plan.ring1) plan = emi::plan_symdefect(c->ns, c->B, c->M, 5, 1);
+            plan.ks = 1;
+            if (emi::pass_supported(c->model, c->ns, c->B, c->M, plan)) {
+                if (c->d_ticket.bytes < (size_t)c->B * 4) {
+                    int est = ensure(c, c->d_ticket, (size_t)c->B * 4);
+                    if (est) return est;
+                    HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, (size_t)c->B * 4, c->stream));
+                }
+                na.cost_ticket = (unsigned*)c->d_ticket.p;
+                if (plv) HIP_TRY(c, hipEventRecord(pe->k[0], c->stream));
+                HIP_TRY(c, emi::launch_pass(c->model, sa, na, c->stream, plan));
+                if (plv) HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
+                if (pe) pe->level = -1;                 // one bracket: the pass kernel
+                c->last_defect_kernel = "emi_pass_f64_kernel<SW=" + std::to_string(plan.sw) + "> (MFMA + node roles, one launch)";
+                return EMI_OK;
+            }
+        }
+        const bool two = c->overlap_mode != 1;
         const bool split = two && c->cu_split > 0;
         hipStream_t s1 = split ? c->s_mfma : c->stream;
         hipStream_t s2 = split ? c->s_node : (two ? c->stream2 : c->stream);
@@ -619,11 +650,18 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
             HIP_TRY(c, emi::rtc_launch_symdefect(c->rtc, sa, s1));
             c->last_defect_kernel = "emi_symdefect_ring_f64_kernel";
         } else {
-            HIP_TRY(c, emi::launch_symdefect(c->model, sa, s1, !(c->fused_attr_mask & bit), c->sym_ct));
+            const emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, c->sym_ksplit);
+            if (plan.slab_bytes) {
+                int est = ensure(c, c->d_slab, plan.slab_bytes);
+                if (est) return est;
+            }
+            sa.ksplit = plan.ring1 ? 1 : plan.ks;
+            sa.slab = (double*)c->d_slab.p;
+            HIP_TRY(c, emi::launch_symdefect(c->model, sa, s1, !(c->fused_attr_mask & bit), c->sym_ct, plan));
             c->fused_attr_mask |= bit;
-            const int sw = emi::last_symdefect_sw();
-            c->last_defect_kernel = sw ? "emi_symdefect_ring2_f64_kernel<SW=" + std::to_string(sw) + ">"
-                                       : (c->sym_ct == 1 || c->sym_ct == 2 ? "emi_symdefect_f64_kernel" : "emi_symdefect_ring_f64_kernel");
+            c->last_defect_kernel = !plan.ring1 ? "emi_symdefect_ring2_f64_kernel<SW=" + std::to_string(plan.sw) + ">" +
+                                                      (plan.ks > 1 ? " x" + std::to_string(plan.ks) + " K slices + emi_symdefect_combine_kernel" : "")
+                                                : (c->sym_ct == 1 || c->sym_ct == 2 ? "emi_symdefect_f64_kernel" : "emi_symdefect_ring_f64_kernel");
         }
         if (plv == 1 || plv == 2) HIP_TRY(c, hipEventRecord(pe->k[1], s1));
         if (plv == 1 || plv == 3) HIP_TRY(c, hipEventRecord(pe->k[2], s2));
@@ -823,6 +861,11 @@ int emi_profile_read(emi_ctx_t c, float* node_ms, int* node_launches, float* def
     for (size_t i = 0; i < c->prof_used; ++i) {
         ProfEvents& pe = c->prof[i];
         float ms = 0;
+        if (pe.fused && pe.level == -1) {
+            HIP_TRY(c, hipEventElapsedTime(&ms, pe.k[0], pe.k[1]));
+            dm += ms; ++dl; fm += ms; ++fl;
+            continue;
+        }
         if (pe.fused) {
             if (pe.level == 1) {
                 HIP_TRY(c, hipEventElapsedTime(&ms, pe.e[0], pe.e[1]));
@@ -902,13 +945,18 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
     }
     if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }
     if (strcmp(name, "sym_ablate") == 0) { c->sym_ablate = value; return EMI_OK; }   // diagnostics only
+    if (strcmp(name, "sym_ksplit") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, EMI_ERR_ARG, "sym_ksplit must be 0 (by batch size), 1, 2, 4 or 8");
+        c->sym_ksplit = value;
+        return EMI_OK;
+    }
     if (strcmp(name, "node_store") == 0) {
         if (value < -1 || value > 2) return fail(c, EMI_ERR_ARG, "node_store must be -1 (by size), 0 (plain), 1 (write-through) or 2 (non-temporal)");
         c->node_store = value;
         return EMI_OK;
     }
     if (strcmp(name, "overlap_mode") == 0) {
-        if (value != 1 && value != 2) return fail(c, EMI_ERR_ARG, "overlap_mode must be 1 or 2");
+        if (value < 0 || value > 3) return fail(c, EMI_ERR_ARG, "overlap_mode must be 0 (by batch size), 1 (one stream), 2 (two streams) or 3 (one launch)");
         c->overlap_mode = value;
         return EMI_OK;
     }

@@ -36,6 +36,7 @@ template <typename T> struct NodeArgs {
     T* VALS;            // [B][nvals][M]
     T* cost_part;       // [B][nchunks]
     T* cost;            // [B]
+    unsigned* cost_ticket;  // [B] zeroed once; non-null: the node kernel finishes COST itself (no emi_cost_finish_kernel)
     const T* w;         // [M]  LGL weights
     const T* node_t;    // [M]  node times t0 + h (tau+1)
     const T* Ddiag;     // [M]  D_kk
@@ -74,6 +75,8 @@ struct SymDefectArgs {
     int M, B, nres;
     int order;              // block -> tile order within an XCD (see emi_symdefect.hip)
     int ablate;             // diagnostics (results invalid): 1 skip MFMAs, 2 skip operand DMA, 4 skip epilogue
+    int ksplit;             // state-split ring kernel: K slices per tile (1 = none); > 1 goes through `slab`
+    double* slab;           // [tiles][ksplit][2 SW][4][256] partial sums of a split-K launch
     double h;
     ModelParams<double> P;
 };

@@ -29,8 +29,18 @@ hipError_t defect_f64_set_attr();
 template <typename T>
 hipError_t launch_cost_finish(const T* part, T* cost, int B, int nchunks, T scale, hipStream_t s);
 bool fused_supported(int model, int M, int ct);
-hipError_t launch_symdefect(int model, const SymDefectArgs& a, hipStream_t s, bool set_attr, int ct);
-int last_symdefect_sw();   // states per workgroup of this thread's last launch_symdefect (0: the one-workgroup ring kernel / register-staged forms)
+// which even/odd MFMA defect kernel a launch uses (emi_symdefect.hip, plan_symdefect)
+struct SymPlan {
+    bool ring1 = false;       // the one-workgroup-per-CU ring kernel / register-staged forms (sym_ct 1..3)
+    int sw = 0;               // state-split ring: states per workgroup
+    int ks = 1;               // ... and K slices per tile (> 1: partial sums through a slab + combine launch)
+    size_t slab_bytes = 0;
+};
+SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt);
+hipError_t launch_symdefect(int model, const SymDefectArgs& a, hipStream_t s, bool set_attr, int ct, const SymPlan& plan);
+// the whole pass as one launch (MFMA-role and node-role workgroups in one grid; COST finished in-kernel)
+bool pass_supported(int model, int ns, int B, int M, const SymPlan& plan);
+hipError_t launch_pass(int model, const SymDefectArgs& sa, const NodeArgs<double>& na, hipStream_t s, const SymPlan& plan);
 
 // model programs compiled at run time (emi_rtc.hip); the int results are EMI_* status codes
 struct RtcModel;

@@ -71,12 +71,13 @@ template <typename T> EMI_DEV T wave_sum(T v) {
 // every one of them.  For the same reason the wave-uniform keep-out records
 // are read through the constant address space (scalar loads, lgkmcnt).
 // ---------------------------------------------------------------------------
-template <typename T, class Model, int VEC, bool JAC, bool DEFROWS, int ST = 0>
-__global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T> a) {
+// bx / nbx: node chunk of this workgroup and chunks per instance; b: instance.  (A device function so that the
+// one-launch pass kernel of emi_symdefect_kernels.hpp can give some of its workgroups this role.)
+template <typename T, class Model, int VEC, bool JAC, bool DEFROWS, int ST>
+EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, const int nbx) {
     constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
-    const int b = blockIdx.y;
     const int M = a.M;
-    const int k0 = (blockIdx.x * EMI_NODE_THREADS + threadIdx.x) * VEC;
+    const int k0 = (bx * EMI_NODE_THREADS + threadIdx.x) * VEC;
     const bool active = k0 < M;  // M % VEC == 0 by dispatch, so the pack is whole
 
     T lsum = T(0);
@@ -249,8 +250,29 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T>
         T s = T(0);
 #pragma unroll
         for (int i = 0; i < EMI_NODE_THREADS / 64; ++i) s += wsum[i];
-        a.cost_part[(size_t)b * gridDim.x + blockIdx.x] = s;
+        T* part = a.cost_part + (size_t)b * nbx;
+        if (a.cost_ticket == nullptr) {
+            part[bx] = s;                                  // emi_cost_finish_kernel sums the partials
+        } else {
+            // In-kernel finish: the workgroup that draws the last ticket of its instance adds the partials IN CHUNK
+            // ORDER (bitwise reproducible).  Partials travel write-through / L1-bypassing (agent-scope atomics,
+            // HIP guide Guideline 16 R1: store, drain, then the ticket); the ticket word resets itself.
+            __hip_atomic_store(part + bx, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(a.cost_ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == (unsigned)nbx - 1u) {
+                T tot = T(0);
+                for (int c = 0; c < nbx; ++c) tot += __hip_atomic_load(part + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.cost[b] = a.sgn * a.h * tot;
+                __hip_atomic_store(a.cost_ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
+}
+
+template <typename T, class Model, int VEC, bool JAC, bool DEFROWS, int ST = 0>
+__global__ __launch_bounds__(EMI_NODE_THREADS) void emi_nodes_kernel(NodeArgs<T> a) {
+    emi_nodes_body<T, Model, VEC, JAC, DEFROWS, ST>(a, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
 }
 
 template <typename T>

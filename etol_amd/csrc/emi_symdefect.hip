@@ -70,7 +70,8 @@ static hipError_t launch_symdefect_model(const SymDefectArgs& a, hipStream_t s, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// second ring form: SW states per workgroup, 8-deep stages, 16-byte fragment reads, two (or more) workgroups per CU
+// second ring form: SW states per workgroup, 8-deep stages, 16-byte fragment reads, two (or more) workgroups per CU,
+// optionally split-K (partial sums through a slab, combined in slice order by a second launch)
 template <class Model, int SW>
 static hipError_t launch_ring2_model(const SymDefectArgs& a, hipStream_t s) {
     constexpr int NS = Model::NS;
@@ -83,47 +84,110 @@ static hipError_t launch_ring2_model(const SymDefectArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_done = true;
     }
-    dim3 grid(mtiles * ntiles * (NS / SW)), block(256);
-    hipLaunchKernelGGL((emi_symdefect_ring2_f64_kernel<Model, SW>), grid, block, lds, s, a);
+    const int tiles = mtiles * ntiles * (NS / SW), ks = a.ksplit > 1 ? a.ksplit : 1;
+    hipLaunchKernelGGL((emi_symdefect_ring2_f64_kernel<Model, SW>), dim3(tiles * ks), dim3(256), lds, s, a);
+    if (ks > 1) hipLaunchKernelGGL((emi_symdefect_combine_kernel<Model, SW>), dim3(tiles), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
-// ct 4 (and 0 = the context's default): the variant is chosen from the batch, by what was measured on MI355X with
-// the node kernel running beside it (profiles/r02_pass_variants.json; 6-state model, 1024 nodes):
-//   >= 448 full-state tiles (B = 1024: 512): SW = 2 -- 78 registers and 36 KB of LDS per workgroup leave the streaming
+// The variant for a batch, by what was measured on MI355X with the node kernel running beside it
+// (profiles/r02_pass_variants.json; 6-state model, 1024 nodes; "tiles" = 16-instance x 64-half-index tiles):
+//   >= 448 tiles (B = 1024: 512): SW = 2 -- 78 registers and 36 KB of LDS per workgroup leave the streaming
 //      kernel's waves the room they need on every CU (pass 0.24-0.25 ms against 0.26-0.27 with 60 KB workgroup pairs);
 //   320 .. 447 tiles (B = 768): SW = NS, all workgroups resident at once, two per CU (0.172 ms against 0.198);
 //   192 .. 319 tiles (B = 512): the one-workgroup-per-CU ring kernel, whose grid is then a single round;
-//   fewer (the shard of config 4: 128 instances = 64 tiles): SW = 1, 384 workgroups instead of 64.
-// 5 / 6 / 7 / 8 force SW = NS / 2 / 1 / 3.   Returns -1 for "use the first ring kernel (ct 3)".
-static thread_local int g_last_sw = 0;      // states per workgroup of the last state-split launch (0: first ring kernel)
-int last_symdefect_sw() { return g_last_sw; }
+//   fewer (the shard of config 4: 128 instances = 64 tiles for 256 CUs): SW = NS with the K range of a tile cut
+//      into 4 (<= 96 tiles) or 2 slices, combined in slice order by a second launch.
+// ct 5 / 6 / 7 / 8 force SW = NS / 2 / 1 / 3; ksplit_opt > 0 forces the slice count of an SW = NS launch.
+SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt) {
+    SymPlan p;
+    const int tiles = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64);
+    const int nkt = (M / 2) / 8;
+    if (ct == 0 || ct == 4) {
+        if (tiles >= 448) p.sw = (ns % 2 == 0 && ns > 2) ? 2 : ns;
+        else if (tiles >= 320) p.sw = ns;
+        else if (tiles >= 192) { p.ring1 = true; return p; }
+        else { p.sw = ns; p.ks = tiles <= 96 ? 4 : 2; }
+    } else if (ct >= 5 && ct <= 8) {
+        p.sw = ct == 5 ? ns : (ct == 6 ? 2 : (ct == 8 ? 3 : 1));
+        if (ns % p.sw != 0) p.sw = 1;
+    } else {
+        p.ring1 = true;
+        return p;
+    }
+    if (ksplit_opt > 0 && p.sw == ns) p.ks = ksplit_opt;
+    while (p.ks > 1 && (nkt % p.ks != 0 || nkt / p.ks < 2)) p.ks >>= 1;
+    if (p.ks > 1) p.slab_bytes = (size_t)tiles * p.ks * (2 * p.sw * 4) * 256 * sizeof(double);
+    return p;
+}
 
 template <class Model>
-static hipError_t launch_ring2_auto(const SymDefectArgs& a, hipStream_t s, int ct, bool* use_ring1) {
+static hipError_t launch_ring2_planned(const SymDefectArgs& a, hipStream_t s, const SymPlan& p) {
     constexpr int NS = Model::NS;
-    g_last_sw = 0;
-    const int nwg_full = ((a.B + FUSED_TI - 1) / FUSED_TI) * ((a.M / 2) / 64);
-    int sw = NS;
-    *use_ring1 = false;
-    if (ct == 4 || ct == 0) {
-        if (nwg_full >= 448) sw = (NS % 2 == 0 && NS > 2) ? 2 : NS;
-        else if (nwg_full >= 320) sw = NS;
-        else if (nwg_full >= 192) { *use_ring1 = true; return hipSuccess; }
-        else sw = 1;
-    } else {
-        sw = ct == 5 ? NS : (ct == 6 ? 2 : (ct == 8 ? 3 : 1));
-    }
-    g_last_sw = sw;
-    if (sw == NS) return launch_ring2_model<Model, NS>(a, s);
+    if (p.sw == NS) return launch_ring2_model<Model, NS>(a, s);
     if constexpr (NS > 2 && NS % 2 == 0) {
-        if (sw == 2) return launch_ring2_model<Model, 2>(a, s);
+        if (p.sw == 2) return launch_ring2_model<Model, 2>(a, s);
     }
     if constexpr (NS > 3 && NS % 3 == 0) {
-        if (sw == 3) return launch_ring2_model<Model, 3>(a, s);
+        if (p.sw == 3) return launch_ring2_model<Model, 3>(a, s);
     }
-    g_last_sw = 1;
     return launch_ring2_model<Model, 1>(a, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the pass as one launch (emi_pass_f64_kernel): MFMA-role and node-role workgroups interleaved per XCD
+template <class Model, int SW>
+static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<double>& na, hipStream_t s) {
+    constexpr int NS = Model::NS;
+    PassArgs a;
+    a.s = sa;
+    a.n = na;
+    const int mtiles = (sa.B + FUSED_TI - 1) / FUSED_TI, ntiles = (sa.M / 2) / 64;
+    const int nm = mtiles * ntiles * (NS / SW);
+    a.nbx = (na.M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS);
+    const int nn = a.nbx * na.B;
+    if (nm % 8 || nn % 8) return hipErrorInvalidConfiguration;
+    a.nm8 = nm / 8;
+    a.nn8 = nn / 8;
+    const size_t lds = (size_t)3 * ((2 * SW * FUSED_TI + 2 * 64 + 63) / 64 * 64) * 8 * sizeof(double);
+    static bool attr_done[2] = {false, false};
+    const int st = na.store_mode == 2 ? 1 : 0;
+    auto kern = st ? emi_pass_f64_kernel<Model, SW, 2, 2> : emi_pass_f64_kernel<Model, SW, 2, 0>;
+    if (!attr_done[st]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done[st] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nm + nn), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+template <class Model>
+static hipError_t launch_pass_planned(const SymDefectArgs& sa, const NodeArgs<double>& na, hipStream_t s, const SymPlan& p) {
+    constexpr int NS = Model::NS;
+    if (p.sw == NS) return launch_pass_model<Model, NS>(sa, na, s);
+    if constexpr (NS > 2 && NS % 2 == 0) {
+        if (p.sw == 2) return launch_pass_model<Model, 2>(sa, na, s);
+    }
+    if constexpr (NS > 3 && NS % 3 == 0) {
+        if (p.sw == 3) return launch_pass_model<Model, 3>(sa, na, s);
+    }
+    return launch_pass_model<Model, 1>(sa, na, s);
+}
+
+// true if the pass can go out as one launch with this plan (state-split ring role, no K slices, whole XCD shares)
+bool pass_supported(int model, int ns, int B, int M, const SymPlan& p) {
+    if (p.ring1 || p.ks > 1 || p.sw < 1 || (model != EMI_MODEL_POINTMASS2D && model != EMI_MODEL_QUADROTOR2D)) return false;
+    if (M % 128 != 0 || ns % p.sw != 0) return false;
+    const int nm = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64) * (ns / p.sw);
+    const int nn = ((M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS)) * B;
+    return nm % 8 == 0 && nn % 8 == 0;
+}
+
+hipError_t launch_pass(int model, const SymDefectArgs& sa, const NodeArgs<double>& na, hipStream_t s, const SymPlan& p) {
+    if (model == EMI_MODEL_POINTMASS2D) return launch_pass_planned<PointMass2D<double>>(sa, na, s, p);
+    if (model == EMI_MODEL_QUADROTOR2D) return launch_pass_planned<Quadrotor2D<double>>(sa, na, s, p);
+    return hipErrorInvalidValue;
 }
 
 bool fused_supported(int model, int M, int ct) {
@@ -134,14 +198,13 @@ bool fused_supported(int model, int M, int ct) {
            M >= 128 * w && M % (128 * w) == 0;
 }
 
-hipError_t launch_symdefect(int model, const SymDefectArgs& a, hipStream_t s, bool set_attr, int ct) {
-    g_last_sw = 0;
-    if (ct == 0 || (ct >= 4 && ct <= 8)) {
-        bool ring1 = false;
-        hipError_t e = hipErrorInvalidValue;
-        if (model == EMI_MODEL_POINTMASS2D) e = launch_ring2_auto<PointMass2D<double>>(a, s, ct, &ring1);
-        if (model == EMI_MODEL_QUADROTOR2D) e = launch_ring2_auto<Quadrotor2D<double>>(a, s, ct, &ring1);
-        if (!ring1) return e;
+hipError_t launch_symdefect(int model, const SymDefectArgs& a, hipStream_t s, bool set_attr, int ct, const SymPlan& plan) {
+    if (!plan.ring1) {
+        if (model == EMI_MODEL_POINTMASS2D) return launch_ring2_planned<PointMass2D<double>>(a, s, plan);
+        if (model == EMI_MODEL_QUADROTOR2D) return launch_ring2_planned<Quadrotor2D<double>>(a, s, plan);
+        return hipErrorInvalidValue;
+    }
+    if (ct == 0 || ct >= 4) {
         ct = 3;
         set_attr = true;    // cheap; the attribute bookkeeping of the caller is per requested ct
     }

@@ -3,6 +3,7 @@
 // models in emi_symdefect.hip and, through hiprtc, for generated model structs (emi_rtc.hip).
 #pragma once
 #include "emi_args.hpp"
+#include "emi_node_kernels.hpp"
 
 namespace emi {
 
@@ -351,9 +352,51 @@ __global__ __launch_bounds__(256, 2) void emi_symdefect_ring_f64_kernel(SymDefec
 // ---------------------------------------------------------------------------------------------
 EMI_DEV constexpr int ring_swz(int r) { return (0 - (r >> 2)) & 3; }
 
+// defect = D.X - h f at the tile's output nodes: forward node i (a + b) and mirrored node N-i (b - a), states
+// s0 .. s0+SW-1; lane (r16, kq) of wave wid holds half-index column 16 wid + r16 and instances kq + 4 i.
 template <class Model, int SW>
-__global__ __launch_bounds__(256, 2) void emi_symdefect_ring2_f64_kernel(SymDefectArgs a) {
+EMI_DEV void ring_epilogue(const SymDefectArgs& a, const d4 (&acc_a)[SW], const d4 (&acc_b)[SW], int inst0, int i0,
+                           int s0, int wid, int r16, int kq) {
     constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
+    const int M = a.M, B = a.B;
+    const int col = wid * 16 + r16;
+    const int node_f = i0 + col, node_m = M - 1 - node_f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int inst = inst0 + kq + 4 * i;
+        if (inst >= B || (a.ablate & 4)) continue;
+        const double* __restrict__ Xb = a.X + (size_t)inst * NS * M;
+        const double* __restrict__ Ub = a.U + (size_t)inst * NC * M;
+        double* __restrict__ Rb = a.RES + (size_t)inst * a.nres * M;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int node = side == 0 ? node_f : node_m;
+            double z[NV], f[NS];
+#pragma unroll
+            for (int v = 0; v < NS; ++v) z[v] = Xb[(size_t)v * M + node];
+#pragma unroll
+            for (int v = 0; v < NC; ++v) z[NS + v] = Ub[(size_t)v * M + node];
+            Model::f(a.P, z, a.node_t[node], f);
+#pragma unroll
+            for (int s = 0; s < SW; ++s) {
+                double fs = f[s];                       // f[s0 + s] without a runtime register index
+                if (SW < NS) {
+#pragma unroll
+                    for (int v = 0; v < NS; ++v) fs = (v == s0 + s) ? f[v] : fs;
+                }
+                const double dx = side == 0 ? acc_a[s][i] + acc_b[s][i] : acc_b[s][i] - acc_a[s][i];
+                Rb[(size_t)(s0 + s) * M + node] = dx - a.h * fs;
+            }
+        }
+    }
+}
+
+// a.ksplit > 1: the K range of a tile is cut into ksplit slices, one workgroup each (a shard of config 4 has 64
+// tiles for 256 CUs); a slice leaves its partial sums in a.slab[tile][slice][2 SW][4][256 threads] and
+// emi_symdefect_combine_kernel adds the slices IN SLICE ORDER (bitwise reproducible) and runs the epilogue.
+template <class Model, int SW>
+EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-slice id, XCD-local runs */) {
+    constexpr int NS = Model::NS;
     constexpr int TI = FUSED_TI, TM = SW * TI, TN = 64, NST = 3, BK = 8, CH = 4, NSG = NS / SW;
     constexpr int ROWS = 2 * TM + 2 * TN;
     constexpr int ROWS_PAD = (ROWS + 63) / 64 * 64;      // a DMA wave instruction moves 16 rows: 4 waves x 16 rows
@@ -365,13 +408,10 @@ __global__ __launch_bounds__(256, 2) void emi_symdefect_ring2_f64_kernel(SymDefe
 
     const int M = a.M, Hh = M >> 1, B = a.B;
     const int ntiles = Hh / TN;
-    int bid = blockIdx.x;
-    {   // XCD-aware bijective remap: an XCD gets a contiguous run of tiles
-        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    }
+    const int KS = a.ksplit > 1 ? a.ksplit : 1;
+    const int kslice = bid % KS, tile = bid / KS;
     // the ntiles workgroups that share one X tile (same instance group, same states) are neighbours: one XCD's L2
-    const int ntile = bid % ntiles, grp = bid / ntiles;
+    const int ntile = tile % ntiles, grp = tile / ntiles;
     const int sg = grp % NSG, mtile = grp / NSG;
     const int inst0 = mtile * TI, i0 = ntile * TN, s0 = sg * SW;
 
@@ -422,9 +462,9 @@ __global__ __launch_bounds__(256, 2) void emi_symdefect_ring2_f64_kernel(SymDefe
         acc_b[s] = d4{0.0, 0.0, 0.0, 0.0};
     }
 
-    const int nkt = Hh / BK;
-    issue(0, 0);
-    if (nkt > 1) issue(1, 1);
+    const int nkt = (Hh / BK) / KS, kt0 = kslice * nkt;       // this slice's K tiles: kt0 .. kt0 + nkt - 1
+    issue(0, kt0);
+    if (nkt > 1) issue(1, kt0 + 1);
     // fragment addresses (doubles within a stage): B rows of this wave, A rows of every state
     const int rb = wid * 16 + r16;
     const int off_b = rb * BK + ((kq ^ ring_swz(rb)) << 1);
@@ -440,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void emi_symdefect_ring2_f64_kernel(SymDefe
         if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
         else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");     // every wave's part landed; stage (kt-1)%3 is free
-        if (kt + 2 < nkt && !(a.ablate & 2)) issue((kt + 2) % NST, kt + 2);
+        if (kt + 2 < nkt && !(a.ablate & 2)) issue((kt + 2) % NST, kt0 + kt + 2);
         if (a.ablate & 1) continue;
         const double* S = smem + (size_t)(kt % NST) * STAGE;
         const double2 be = *reinterpret_cast<const double2*>(S + 2 * TM * BK + off_b);
@@ -464,36 +504,86 @@ __global__ __launch_bounds__(256, 2) void emi_symdefect_ring2_f64_kernel(SymDefe
         }
     }
 
-    // ---- epilogue: defect = D.X - h f, forward node i and mirrored node N-i, states s0 .. s0+SW-1 ----
-    const int col = wid * 16 + r16;
-    const int node_f = i0 + col, node_m = M - 1 - node_f;
+    if (KS > 1) {       // partial sums of this K slice -> slab (coalesced: one 2 KB row per register)
+        double* sl = a.slab + ((size_t)tile * KS + kslice) * (2 * SW * 4) * 256 + tid;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int inst = inst0 + kq + 4 * i;
-        if (inst >= B || (a.ablate & 4)) continue;
-        const double* __restrict__ Xb = a.X + (size_t)inst * NS * M;
-        const double* __restrict__ Ub = a.U + (size_t)inst * NC * M;
-        double* __restrict__ Rb = a.RES + (size_t)inst * a.nres * M;
+        for (int s = 0; s < SW; ++s)
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int node = side == 0 ? node_f : node_m;
-            double z[NV], f[NS];
-#pragma unroll
-            for (int v = 0; v < NS; ++v) z[v] = Xb[(size_t)v * M + node];
-#pragma unroll
-            for (int v = 0; v < NC; ++v) z[NS + v] = Ub[(size_t)v * M + node];
-            Model::f(a.P, z, a.node_t[node], f);
-#pragma unroll
-            for (int s = 0; s < SW; ++s) {
-                double fs = f[s];                       // f[s0 + s] without a runtime register index
-                if (SW < NS) {
-#pragma unroll
-                    for (int v = 0; v < NS; ++v) fs = (v == s0 + s) ? f[v] : fs;
-                }
-                const double dx = side == 0 ? acc_a[s][i] + acc_b[s][i] : acc_b[s][i] - acc_a[s][i];
-                Rb[(size_t)(s0 + s) * M + node] = dx - a.h * fs;
+            for (int i = 0; i < 4; ++i) {
+                sl[(size_t)((2 * s) * 4 + i) * 256] = acc_a[s][i];
+                sl[(size_t)((2 * s + 1) * 4 + i) * 256] = acc_b[s][i];
             }
-        }
+        return;
+    }
+    ring_epilogue<Model, SW>(a, acc_a, acc_b, inst0, i0, s0, wid, r16, kq);
+}
+
+template <class Model, int SW>
+__global__ __launch_bounds__(256, 2) void emi_symdefect_ring2_f64_kernel(SymDefectArgs a) {
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: an XCD gets a contiguous run of tiles
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    emi_ring2_body<Model, SW>(a, bid);
+}
+
+// second half of a split-K launch: one workgroup per tile, thread layout of the ring kernel
+template <class Model, int SW>
+__global__ __launch_bounds__(256) void emi_symdefect_combine_kernel(SymDefectArgs a) {
+    constexpr int NS = Model::NS, TI = FUSED_TI, TN = 64, NSG = NS / SW;
+    const int ntiles = (a.M >> 1) / TN, KS = a.ksplit;
+    const int tile = blockIdx.x;
+    const int ntile = tile % ntiles, grp = tile / ntiles;
+    const int sg = grp % NSG, mtile = grp / NSG;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    d4 acc_a[SW], acc_b[SW];
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+        acc_a[s] = d4{0.0, 0.0, 0.0, 0.0};
+        acc_b[s] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+    for (int k = 0; k < KS; ++k) {                      // fixed order
+        const double* sl = a.slab + ((size_t)tile * KS + k) * (2 * SW * 4) * 256 + tid;
+#pragma unroll
+        for (int s = 0; s < SW; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc_a[s][i] += sl[(size_t)((2 * s) * 4 + i) * 256];
+                acc_b[s][i] += sl[(size_t)((2 * s + 1) * 4 + i) * 256];
+            }
+    }
+    ring_epilogue<Model, SW>(a, acc_a, acc_b, mtile * TI, ntile * TN, sg * SW, wid, lane & 15, lane >> 4);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The whole evaluation pass in ONE launch: some workgroups take the MFMA defect role (emi_ring2_body), the others
+// the streaming node role (emi_nodes_body, which also finishes COST through its ticket).  Two launches on two
+// streams need a fork and a join through events at every pass: measured 21 us of idle chip between consecutive
+// 250 us passes at 1024 instances, 22 us inside a 75 us pass at 128 (profiles/r02_notes.md); one launch has none.
+// (The single-launch form of round 1 lost because its MFMA role needed 219 registers, which capped the streaming
+// waves at two per SIMD; the state-split ring role needs 78, less than the node role itself.)
+// Roles are dealt per XCD (blocks b, b+8, ... share one): block j of an XCD is an MFMA block when
+// floor((j+1) nm / t) > floor(j nm / t), nm of the XCD's t blocks being MFMA blocks -- evenly interleaved, so both
+// roles are resident on every CU throughout, and the MFMA blocks of an XCD are a contiguous run of tiles (they
+// share X and De/Do panels in that XCD's L2).  Requires nm % 8 == 0 and nn % 8 == 0 (the launcher checks).
+// ---------------------------------------------------------------------------------------------
+struct PassArgs {
+    SymDefectArgs s;
+    NodeArgs<double> n;
+    int nm8, nn8;           // MFMA / node workgroups per XCD
+    int nbx;                // node chunks per instance
+};
+
+template <class Model, int SW, int VEC, int ST>
+__global__ __launch_bounds__(256, 2) void emi_pass_f64_kernel(PassArgs a) {
+    const int g = blockIdx.x, xcd = g & 7, j = g >> 3, t8 = a.nm8 + a.nn8;
+    const int m0 = (int)(((long long)j * a.nm8) / t8), m1 = (int)(((long long)(j + 1) * a.nm8) / t8);
+    if (m1 > m0) {
+        emi_ring2_body<Model, SW>(a.s, xcd * a.nm8 + m0);
+    } else {
+        const int nid = xcd * a.nn8 + (j - m0);
+        emi_nodes_body<double, Model, VEC, true, false, ST>(a.n, nid % a.nbx, nid / a.nbx, a.nbx);
     }
 }
 

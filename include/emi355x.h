@@ -266,7 +266,12 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * path: -1 (default) non-temporal once a pass writes more than the Infinity Cache
  * holds, 0 plain, 1 write-through, 2 non-temporal.
  * "sym_order" (default 1): workgroup -> tile order within an XCD (sym_ct 1..3).
- * "overlap_mode" (2 = two streams, default; 1 = same stream back to back).
+ * "overlap_mode": how the two kernels share the chip.  0 (default) = by batch size;
+ * 2 = two streams (fork / join through events); 3 = ONE launch, MFMA-role and
+ * node-role workgroups in one grid with COST finished in-kernel (chosen below 192
+ * tiles, e.g. the 128-instance shard of config 4); 1 = one stream, back to back.
+ * "sym_ksplit": K slices of a full-state tile (0 = by batch size; > 1 goes through
+ * a slab and a combine launch, summed in slice order).
  * "sym_ablate": diagnostics only, results invalid.                             */
 int emi_set_option(emi_ctx_t ctx, const char* name, int value);
 /* 1 if emi_eval(EMI_EVAL_ALL) currently takes the overlapped path             */

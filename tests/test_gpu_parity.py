@@ -523,7 +523,7 @@ def test_rccl_gather_entry_points_world_of_one(built):
 
 
 @pytest.mark.parametrize("sym_ct", [3, 5, 6, 7, 8, 0])
-@pytest.mark.parametrize("shape", [(1024, 5), (256, 19), (128, 33)])
+@pytest.mark.parametrize("shape", [(1024, 8), (256, 19), (128, 32)])
 def test_every_mfma_defect_kernel_variant_matches_the_oracle(built, sym_ct, shape):
     """The even/odd MFMA defect kernels (one-workgroup ring; state-split rings with SW = 6 / 2 / 1 / 3; the choice by
     batch size), with the streaming kernel beside them and its three store policies: same results as the oracle at
@@ -544,4 +544,20 @@ def test_every_mfma_defect_kernel_variant_matches_the_oracle(built, sym_ct, shap
         got = ev.eval_host(X, U)
         assert ev.uses_fused_kernel
         check(c, ev, got, ref)
+    ev.set_option("node_store", -1)
+    ev.set_option("overlap_mode", 3)      # the pass as one launch (MFMA-role and node-role workgroups, COST by ticket)
+    one = ev.eval_host(X, U)
+    if sym_ct != 3 and M == 1024:      # (the other shapes do not fill whole XCD shares and fall back to two streams)
+        assert "one launch" in ev.last_defect_kernel, ev.last_defect_kernel
+    check(c, ev, one, ref)
+    assert np.array_equal(ev.eval_host(X, U)[2], one[2])              # COST: fixed summation order
+    ev.set_option("overlap_mode", 2)
+    if sym_ct == 5:          # split-K: partial sums through the slab, combined in slice order by the second launch
+        for ks in (2, 4, 8):
+            ev.set_option("sym_ksplit", ks)
+            got2 = ev.eval_host(X, U)
+            assert "K slices" in ev.last_defect_kernel or M // 16 // ks < 2
+            check(c, ev, got2, ref)
+            again = ev.eval_host(X, U)
+            assert np.array_equal(again[0], got2[0])          # fixed summation order: bitwise reproducible
     ev.close()

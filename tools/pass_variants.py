@@ -28,6 +28,19 @@ VARIANTS = {
     "ring2_sw2_conc_nt": dict(sym_ct=6, overlap_mode=2, node_store=2),
     "ring2_sw1_conc_nt": dict(sym_ct=7, overlap_mode=2, node_store=2),
     "ring2_sw3_conc_nt": dict(sym_ct=8, overlap_mode=2, node_store=2),
+    "sw6_ks2_conc": dict(sym_ct=5, sym_ksplit=2, overlap_mode=2, node_store=-1),
+    "sw6_ks4_conc": dict(sym_ct=5, sym_ksplit=4, overlap_mode=2, node_store=-1),
+    "sw6_ks8_conc": dict(sym_ct=5, sym_ksplit=8, overlap_mode=2, node_store=-1),
+    "sw6_ks4_seq": dict(sym_ct=5, sym_ksplit=4, overlap_mode=1, node_store=-1),
+    "sw1_conc": dict(sym_ct=7, overlap_mode=2, node_store=-1),
+    "auto": dict(sym_ct=0, overlap_mode=2, node_store=-1),
+    "default": dict(sym_ct=0, overlap_mode=0, node_store=-1),
+    "one_launch_auto": dict(sym_ct=0, overlap_mode=3, node_store=-1),
+    "one_launch_sw6": dict(sym_ct=5, overlap_mode=3, node_store=-1),
+    "one_launch_sw3": dict(sym_ct=8, overlap_mode=3, node_store=-1),
+    "one_launch_sw2": dict(sym_ct=6, overlap_mode=3, node_store=-1),
+    "one_launch_sw1": dict(sym_ct=7, overlap_mode=3, node_store=-1),
+    "one_launch_sw2_plain": dict(sym_ct=6, overlap_mode=3, node_store=0),
     "ring2_sw2_conc_plain": dict(sym_ct=6, overlap_mode=2, node_store=0),
     "ring2_sw1_conc_plain": dict(sym_ct=7, overlap_mode=2, node_store=0),
     "ring2_auto_conc_nt": dict(sym_ct=4, overlap_mode=2, node_store=2),
@@ -67,7 +80,9 @@ def main():
 
     def apply(opts):
         ev.set_option("overlap", 1)
+        ev.set_option("overlap_mode", 2)
         ev.set_option("node_store", 0)
+        ev.set_option("sym_ksplit", 0)
         for k, v in opts.items():
             ev.set_option(k, v)
 
