@@ -933,6 +933,10 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         }
         return EMI_OK;
     }
+    if (strncmp(name, "kkt_", 4) == 0 && strcmp(name, "kkt_method") != 0) {
+        if (emi::kkt_set_option(name, value)) return EMI_OK;
+        return fail(c, EMI_ERR_ARG, "unknown option %s", name);
+    }
     if (strcmp(name, "kkt_method") == 0) {
         if (value != 0 && value != 1) return fail(c, EMI_ERR_ARG, "kkt_method must be 0 (LU) or 1 (Schur complement + Cholesky)");
         c->kkt_method = value;

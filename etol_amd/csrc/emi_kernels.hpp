@@ -58,6 +58,7 @@ struct KktWorkspace;
 int kkt_factor(KktWorkspace** w, hipStream_t stream, const double* dD, int M, int ns, int nv, const double* Qblk,
                const double* Jblk, const unsigned char* fixed, double dc, int method, int* info, std::string* err);
 int kkt_solve(KktWorkspace* w, hipStream_t stream, int nz, double* rhs, int nrhs, std::string* err);
+bool kkt_set_option(const char* name, int value);   // process-wide diagnostics of the factorisation ("kkt_cholesky", ...)
 int kkt_lowrank(KktWorkspace* w, hipStream_t stream, int nz, int r, const int* node, const double* vec, const double* delta,
                 int* exact, std::string* err);
 void kkt_destroy(KktWorkspace* w);

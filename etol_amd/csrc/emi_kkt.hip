@@ -23,6 +23,8 @@
 //              + Doff o (1 g^T) + (Doff o (1 g'^T))^T + diag(r)    element-wise, from P_k J_k^T and J_k P_k J_k^T
 // -> Cholesky (rocSOLVER potrf: 31 ms at 8192 rows where the LU of the full matrix takes 208 ms at
 // 14336), and a solve is two GEMMs with D, two triangular solves and node-local 8x8 products.
+#include <atomic>
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <rocsolver/rocsolver.h>
 
@@ -37,6 +39,25 @@
 #include "emi_kernels.hpp"
 
 namespace emi {
+
+// Diagnostic switches of the factorisation (process-wide, set through emi_set_option "kkt_*"; the defaults are what
+// every number in profiles/ was measured with)
+struct KktTuning {
+    std::atomic<int> own_cholesky{1};       // "kkt_cholesky": 1 the library's blocked Cholesky, 0 rocsolver_dpotrf (+ confirmation on a copy)
+    std::atomic<int> own_panel{1};          // "kkt_chol_panel": 1 own panel kernel, 0 rocblas_dtrsm
+    std::atomic<int> batched_max_nodes{256};// "kkt_batched_max_nodes": largest mesh with the batched Schur-block build
+    std::atomic<int> debug{0};              // "kkt_debug": 1 retries and fallbacks on stderr, 2 also the blocks around a failing pivot
+    std::atomic<int> potrf_lock{0};         // "kkt_potrf_lock": serialise rocsolver_dpotrf calls of different host threads
+};
+static KktTuning g_tune;
+bool kkt_set_option(const char* name, int value) {
+    if (!strcmp(name, "kkt_cholesky")) { g_tune.own_cholesky = value != 0; return true; }
+    if (!strcmp(name, "kkt_chol_panel")) { g_tune.own_panel = value != 0; return true; }
+    if (!strcmp(name, "kkt_batched_max_nodes")) { g_tune.batched_max_nodes = value; return true; }
+    if (!strcmp(name, "kkt_debug")) { g_tune.debug = value; return true; }
+    if (!strcmp(name, "kkt_potrf_lock")) { g_tune.potrf_lock = value != 0; return true; }
+    return false;
+}
 
 struct KktWorkspace {
     rocblas_handle handle = nullptr;
@@ -434,7 +455,7 @@ int potrf_checked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A,
     rocblas_int first = 0;
     for (int attempt = 0; attempt < 3; ++attempt) {
         if (attempt > 0) KKT_HIP(hipMemcpyAsync(A, w->chol_copy, bytes, hipMemcpyDeviceToDevice, stream));
-        static const bool serialise = getenv("EMI_POTRF_LOCK") ? atoi(getenv("EMI_POTRF_LOCK")) != 0 : false;
+        const bool serialise = g_tune.potrf_lock.load() != 0;
         std::unique_lock<std::mutex> lk(g_potrf_mutex, std::defer_lock);
         if (serialise) {
             KKT_HIP(hipStreamSynchronize(stream));
@@ -447,7 +468,7 @@ int potrf_checked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A,
         if (*hinfo == 0) {
             if (attempt > 0) {
                 ++g_potrf_spurious;
-                if (getenv("EMI_KKT_DEBUG"))
+                if (g_tune.debug.load())
                     fprintf(stderr, "emi_kkt: dpotrf reported pivot %d of %d, the same matrix factorised on repeat %d\n", (int)first,
                             (int)n, attempt);
             }
@@ -471,7 +492,7 @@ int chol_blocked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, 
             double* P = A + (size_t)j0 * n + j0 + nb;
             // own kernel by default; rocblas_dtrsm (EMI_CHOL_PANEL=0) is 5 % faster on a single 1024-node solve and 20-40 %
             // slower on eight concurrent 129-node solves (profiles/r01_notes.md)
-            static const int own_panel = getenv("EMI_CHOL_PANEL") ? atoi(getenv("EMI_CHOL_PANEL")) : 1;
+            const int own_panel = g_tune.own_panel.load();
             if (own_panel) {
                 hipLaunchKernelGGL(emi_chol_panel_kernel, dim3((rest + 63) / 64), dim3(64), 0, stream, A, (int)n, (int)n, j0,
                                    (const double*)w->chol_blk);
@@ -492,7 +513,7 @@ int chol_blocked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, 
 
 // which Cholesky: 1 (default) the blocked one above, 0 rocsolver_dpotrf with the confirmation on a copy
 int cholesky(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, rocblas_int* hinfo, std::string* err) {
-    static const int own = getenv("EMI_CHOLESKY") ? atoi(getenv("EMI_CHOLESKY")) : 1;
+    const int own = g_tune.own_cholesky.load();
     return own ? chol_blocked(w, stream, n, A, hinfo, err) : potrf_checked(w, stream, n, A, hinfo, err);
 }
 
@@ -548,7 +569,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         KKT_ENSURE(w->Doff, w->cap_Doff, (size_t)M * M * sizeof(double));
         // one batched GEMM for all state pairs where the build is launch-bound (measured: +5-10 % Monte-Carlo throughput
         // at 65 nodes, +3 % at 129; no gain per factorisation at 1024 nodes, where the unbatched form is kept)
-        static const int batched_max_m = getenv("EMI_KKT_BATCHED") ? atoi(getenv("EMI_KKT_BATCHED")) : 256;
+        const int batched_max_m = g_tune.batched_max_nodes.load();
         const bool batched = M <= batched_max_m;
         const int npairs = ns * (ns + 1) / 2;
         KKT_ENSURE(w->W, w->cap_W, (size_t)(batched ? npairs : 1) * M * M * sizeof(double));
@@ -612,7 +633,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
             KKT_HIP(hipMemcpyAsync(&hflag, w->flag, sizeof hflag, hipMemcpyDeviceToHost, stream));
             KKT_HIP(hipStreamSynchronize(stream));
             if (hinfo == 0 || hflag != 0) break;      // factorised, or hopeless (a Q block is not positive definite)
-            if (getenv("EMI_KKT_DEBUG"))
+            if (g_tune.debug.load())
                 fprintf(stderr, "emi_kkt_factor: S not positive definite at %d with dual regularisation %.1e (M %d), retrying\n",
                         (int)hinfo, dc_schur, M);
         }
@@ -623,7 +644,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
             return EMI_OK;
         }
         // a block was not positive definite or S is not: not the quasi-definite case -- general path below
-        if (getenv("EMI_KKT_DEBUG") && atoi(getenv("EMI_KKT_DEBUG")) >= 2 && hinfo > 0) {
+        if (g_tune.debug.load() >= 2 && hinfo > 0) {
             // diagnosis: the node blocks around the failing pivot (diagonals of Q as uploaded and of P = Q^-1)
             const int kf = ((int)hinfo - 1) % M, i_f = ((int)hinfo - 1) / M;
             std::vector<double> hq((size_t)nh * M), hp((size_t)nv * nv * M);
@@ -640,7 +661,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
                 fprintf(stderr, "\n");
             }
         }
-        if (getenv("EMI_KKT_DEBUG"))
+        if (g_tune.debug.load())
             fprintf(stderr, "emi_kkt_factor: Schur path gave up (block flag %d, potrf info %d, M %d, dc %.3g) -> LU\n", hflag,
                     (int)hinfo, M, dc);
     }

@@ -588,6 +588,10 @@ void eMI355X::solve() {
     opt.max_iter = _algorithm.nlp_iter_max;
     opt.print_level = _algorithm.print_level;
     opt.max_cpu_time = _algorithm.max_cpu_time;
+    opt.max_shift_trials = _algorithm.max_shift_trials;
+    opt.stagnation_iters = _algorithm.stagnation_iters;
+    opt.crawl_limit = _algorithm.crawl_limit;
+    opt.crawl_frac = _algorithm.crawl_frac;
 
     // the guess vectors of the problem are working storage of the mesh loop below; the caller's own guess
     // (ePSOPT.cpp:47-56) is put back when solve() returns, so that a second solve() starts from it again
@@ -635,8 +639,8 @@ void eMI355X::solve() {
     };
     // Multipliers are NOT carried to the next mesh by default: measured over 32 Monte-Carlo scenarios at 257 nodes the
     // costate-mapped warm start needed 112 iterations on average against 103 from zero multipliers (interior-point
-    // warm starts want centred pairs, which interpolated multipliers are not).  EMI_WARM_MULTIPLIERS=1 enables it.
-    const bool warm_multipliers = getenv("EMI_WARM_MULTIPLIERS") ? atoi(getenv("EMI_WARM_MULTIPLIERS")) != 0 : false;
+    // warm starts want centred pairs, which interpolated multipliers are not).  Alg::warm_multipliers enables it.
+    const bool warm_multipliers = _algorithm.warm_multipliers;
     // the solution on the current mesh, interpolated to Mnew LGL nodes, becomes the guess there
     auto remesh_with_guess = [&](size_t Mnew) {
         const std::vector<double> tau = P.tau, w = P.w;
@@ -675,8 +679,8 @@ void eMI355X::solve() {
         }
     };
     mi355x::NlpOptions warm = opt;      // started from an interpolated solution: stay close to it
-    warm.mu_init = getenv("EMI_WARM_MU") ? atof(getenv("EMI_WARM_MU")) : 1e-5;   // (env: tuning; 1e-3 .. 1e-5 measured, profiles/r01_notes.md)
-    warm.bound_push = warm.bound_frac = getenv("EMI_WARM_PUSH") ? atof(getenv("EMI_WARM_PUSH")) : 1e-4;
+    warm.mu_init = _algorithm.warm_mu_init;               // (1e-3 .. 1e-5 measured, profiles/r01_notes.md)
+    warm.bound_push = warm.bound_frac = _algorithm.warm_bound_push;
     _solution.mesh_iterations = 0;
     _solution.nlp_iterations_total = 0;
     _solution.ode_error = 0;

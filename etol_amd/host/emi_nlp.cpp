@@ -749,10 +749,10 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         return ++futile >= opt.max_futile_escalations;
     };
     int stagn = 0, crawl = 0;
-    // (env: experiments, profiles/r01_notes.md) EMI_SHIFT_TRIALS=0 switches the inertia search off, EMI_CRAWL=1000 the crawl rule
-    const int max_shift_trials = getenv("EMI_SHIFT_TRIALS") ? atoi(getenv("EMI_SHIFT_TRIALS")) : opt.max_shift_trials;
-    const int stagn_limit = getenv("EMI_STAGN") ? atoi(getenv("EMI_STAGN")) : 12;
-    const int crawl_limit = getenv("EMI_CRAWL") ? atoi(getenv("EMI_CRAWL")) : 3;
+    // (experiments, profiles/r01_notes.md) max_shift_trials = 0 switches the inertia search off, crawl_limit = 1000 the crawl rule
+    const int max_shift_trials = opt.max_shift_trials;
+    const int stagn_limit = opt.stagnation_iters;
+    const int crawl_limit = opt.crawl_limit;
     double stagn_ref = 1e300;
     for (int iter = 0;; ++iter) {
         R.iterations = iter;
@@ -1197,7 +1197,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             break;
         }
         // accept
-        static const double crawl_frac = getenv("EMI_CRAWL_FRAC") ? atof(getenv("EMI_CRAWL_FRAC")) : 0.3;
+        const double crawl_frac = opt.crawl_frac;
         crawl = alpha < crawl_frac * apr ? crawl + 1 : 0;
         if (!take_step(alpha, adu)) { R.msg = "evaluator failed: " + P.ev->last_error(); return R; }
     }

@@ -72,7 +72,10 @@ struct NlpOptions {
     double bound_push = 1e-2, bound_frac = 1e-2;
     double max_cpu_time = 1e9;          // seconds
     int max_futile_escalations = 3;     // tenfold raises of the penalty weight beyond 1e5 without halving the largest elastic before giving up
-    int max_shift_trials = 6;           // inertia search: trial shifts delta_w per iteration before the reflected step is taken
+    int max_shift_trials = 6;           // inertia search: trial shifts delta_w per iteration before the reflected step is taken (0: search off)
+    int stagnation_iters = 12;          // iterations without 10 % progress of the barrier KKT residual before the inertia search starts
+    int crawl_limit = 3;                // consecutive short steps (alpha < crawl_frac * alpha_max) before the crawl rule acts
+    double crawl_frac = 0.3;
     double rho_init = 10.0;             // exact-penalty weight of the elastic path rows (escalated x10 as needed)
     double acceptable_factor = 100.0;   // "acceptable": KKT error <= acceptable_factor * tol ...
     int acceptable_iter = 10;           // ... over this many consecutive iterations (as IPOPT's acceptable_*)

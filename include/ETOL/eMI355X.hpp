@@ -37,6 +37,11 @@ struct Alg {
                                                    // Monte-Carlo sets, off by default)
     bool mesh_sequencing = true;                   // meshes above 80 nodes are reached through 33, 65, 129, ... nodes
     int guess_retries = 4;                         // a locally infeasible cold start is repeated from up to this many bent lines
+    bool warm_multipliers = false;                 // carry costate-mapped multipliers to the next mesh (measured: no gain, profiles/r01_notes.md)
+    double warm_mu_init = 1e-5;                    // barrier parameter of a solve started from an interpolated solution
+    double warm_bound_push = 1e-4;                 // ... and its bound push / fraction
+    int max_shift_trials = 6, stagnation_iters = 12, crawl_limit = 3;   // inertia search / crawl rule of the NLP iteration (emi_nlp.hpp)
+    double crawl_frac = 0.3;
     std::string linear_solver = "auto";            // Newton step: "host" (dense LDL^T), "device" (structured
                                                    // factorisation in HBM, emi_kkt_*), "auto" = device above 400 KKT rows
     int nlp_iter_max = 200;

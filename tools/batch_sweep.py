@@ -60,7 +60,7 @@ def run(name, model, params, M, B, n_obs, f32=False, overlap=True, steps=None):
 
 def main():
     rows = []
-    for B in (1, 64, 1024, 16384):
+    for B in (1, 64, 128, 256, 512, 1024, 16384):
         rows.append(run("c3 quadrotor N=1024 +20 keep-outs", E.MODEL_QUADROTOR2D, W.QUAD_PARAMS, 1024, B, 20))
         rows.append(run("c3 quadrotor N=1024 +20 keep-outs", E.MODEL_QUADROTOR2D, W.QUAD_PARAMS, 1024, B, 20, overlap=False))
         print(json.dumps(rows[-2]), flush=True)

@@ -5,7 +5,7 @@
 # --kernel-trace.  Summary -> gpurun_out/pmc_busy.json (copy to profiles/).   usage: tools/pmc_busy.sh [sym_ct]
 mkdir -p gpurun_out
 OUT=$GRAFT_REPO_ROOT/gpurun_out
-CT=${1:-4}
+CT=${1:-0}
 cd /tmp && export TMPDIR=/tmp
 SET_A="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_WAVES"
 SET_B="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES"
@@ -28,8 +28,8 @@ for mode in (1, 2):
     for f in glob.glob(f"{out}/pmc_busy_m{mode}_*/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"]
-            key = next((k for k in ("emi_nodes_kernel", "emi_symdefect_ring2_f64_kernel", "emi_symdefect_ring_f64_kernel",
-                                    "emi_cost_finish_kernel") if k in name), None)
+            key = next((k for k in ("emi_nodes_kernel", "emi_pass_f64_kernel", "emi_symdefect_ring2_f64_kernel",
+                                    "emi_symdefect_ring_f64_kernel", "emi_cost_finish_kernel") if k in name), None)
             if key:
                 a = acc[key][r["Counter_Name"]]
                 a[0] += float(r["Counter_Value"]); a[1] += 1

@@ -22,8 +22,9 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             if r.get("Counter_Name") != ctr:
                 continue
             name = r["Kernel_Name"]
-            key = next((k for k in ("emi_nodes_kernel", "emi_symdefect_ring_f64_kernel", "emi_symdefect_f64_kernel",
-                                    "emi_defect_f64_kernel", "emi_cost_finish_kernel") if k in name), None)
+            key = next((k for k in ("emi_nodes_kernel", "emi_pass_f64_kernel", "emi_symdefect_ring2_f64_kernel",
+                                    "emi_symdefect_combine_kernel", "emi_symdefect_ring_f64_kernel", "emi_symdefect_f64_kernel",
+                                    "emi_defect_f64_kernel", "emi_defect_f32_mfma_kernel", "emi_cost_finish_kernel") if k in name), None)
             if key:
                 acc[key][0] += float(r["Counter_Value"])
                 acc[key][1] += 1
