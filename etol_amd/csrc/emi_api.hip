@@ -51,6 +51,7 @@ struct emi_ctx_s {
     double t0 = 0, tf = 0;
     DevBuf d_w, d_t, d_Ddiag, d_D, d_De, d_Do;
     bool symmetric = false;   // D is exactly centro-antisymmetric and M is even: De/Do are valid
+    bool points_only = false; // emi_set_mesh(D = NULL): abscissae without a differentiation matrix
     bool allow_fused = true;      // "overlap" option: even/odd MFMA defect kernel || node kernel on two streams
     int sym_ct = 0;               // MFMA kernel variant (emi_symdefect.hip): 0 = chosen from the batch, 3 = LDS-DMA ring, 5..8 state-split ring, 1/2 = register-staged
     int sym_order = 1;
@@ -317,7 +318,32 @@ int emi_synchronize(emi_ctx_t c) {
 
 int emi_set_mesh(emi_ctx_t c, int M, const double* tau, const double* w, const double* D, double t0,
                  double tf) {
-    if (!c || M < 2 || !tau || !w || !D) return fail(c, EMI_ERR_ARG, "emi_set_mesh: bad argument");
+    if (!c || M < 2 || !tau || !w) return fail(c, EMI_ERR_ARG, "emi_set_mesh: bad argument");
+    if (!D) {
+        // points-only mesh: the node functions are evaluated at arbitrary abscissae (the ODE-error estimate between
+        // the collocation nodes); there is no differentiation matrix, so EMI_EVAL_DEFECT and the KKT entry points refuse
+        HIP_TRY(c, hipSetDevice(c->device));
+        const double hh = (tf - t0) / 2.0;
+        if (!(tf > t0)) return fail(c, EMI_ERR_ARG, "emi_set_mesh: tf must exceed t0");
+        std::vector<double> nt(M), zero(M, 0.0);
+        for (int k = 0; k < M; ++k) nt[k] = t0 + hh * (tau[k] + 1.0);
+        int st;
+        if ((st = upload_real(c, c->d_w, w, M))) return st;
+        if ((st = upload_real(c, c->d_t, nt.data(), M))) return st;
+        if ((st = upload_real(c, c->d_Ddiag, zero.data(), M))) return st;
+        c->symmetric = false;
+        c->points_only = true;
+        c->h_tau.assign(tau, tau + M);
+        c->h_w.assign(w, w + M);
+        c->M = M; c->t0 = t0; c->tf = tf;
+        c->ntracks = 0; c->track_sets = 0;
+        if (c->B > 0) {
+            const size_t rb = c->f32 ? 4 : 8;
+            if ((st = ensure(c, c->d_cost_part, (size_t)c->B * emi::node_chunks(M) * rb))) return st;
+        }
+        return EMI_OK;
+    }
+    c->points_only = false;
     if (!(tf > t0)) return fail(c, EMI_ERR_ARG, "emi_set_mesh: tf must exceed t0");
     HIP_TRY(c, hipSetDevice(c->device));
     const double h = (tf - t0) / 2.0;
@@ -571,6 +597,7 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
     const bool nodes = flags & EMI_EVAL_NODES, defect = flags & EMI_EVAL_DEFECT;
     const bool jac = !(flags & EMI_EVAL_NOJAC);
     if (!nodes && !defect) return fail(c, EMI_ERR_ARG, "emi_eval: empty flags");
+    if (defect && c->points_only) return fail(c, EMI_ERR_STATE, "emi_eval: the mesh has no differentiation matrix (points-only mesh): EMI_EVAL_NODES only");
     if (!dX || !dRES || (nodes && (!dU || !dCOST || (jac && !dVALS))))
         return fail(c, EMI_ERR_ARG, "emi_eval: null device pointer");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -799,6 +826,7 @@ int emi_kkt_factor(emi_ctx_t c, const double* Qblk, const double* Jblk, const un
     if (!c) return EMI_ERR_ARG;
     if (c->M <= 0 || c->model < 0) return fail(c, EMI_ERR_STATE, "emi_kkt_factor: mesh and model must be set");
     if (c->f32) return fail(c, EMI_ERR_UNSUPPORTED, "emi_kkt_factor: f64 contexts only");
+    if (c->points_only) return fail(c, EMI_ERR_STATE, "emi_kkt_factor: the mesh has no differentiation matrix");
     if (!Qblk || !Jblk || !fixed || !info || !(dc >= 0.0)) return fail(c, EMI_ERR_ARG, "emi_kkt_factor: bad argument");
     HIP_TRY(c, hipSetDevice(c->device));
     std::string err;

@@ -435,41 +435,88 @@ void interp_lgl(const std::vector<double>& tau, const std::vector<double>& w, co
 }
 }  // namespace
 
-// Relative ODE error of the solution z on the current mesh: its interpolant is put on the LGL
-// grid with twice the intervals and the collocation defect there is evaluated ON THE DEVICE
-// (values-only pass).  error_i = max_k |defect_ik| / (h (1 + max_k |xdot_ik|)).
+// Relative local ODE error of the solution z on the current mesh, the quantity PSOPT's automatic mesh refinement
+// compares with ode_tolerance (ePSOPT.cpp:69-71; PSOPT 5.0.0 follows Betts' relative local error): between every two
+// consecutive nodes the ODE residual of the INTERPOLATED solution is integrated,
+//     eta_(i,k) = int_{t_k}^{t_k+1} | d/dt x~_i(s) - f_i(x~(s), u~(s), s) | ds ,
+// and the estimate is  max_(i,k) eta_(i,k) / (w_i + 1),  w_i = max_k max(|x~_i(t_k)|, |d/dt x~_i(t_k)|).
+// x~, u~ are the Lagrange interpolants through the LGL nodes (barycentric form); the integral is a 5-point
+// Gauss-Legendre rule per interval (PSOPT uses a Romberg rule; PSOPT is not in the reference tree, so this follows
+// the published definition, not its source).  f at the (M-1) x 5 quadrature points is evaluated ON THE DEVICE: the
+// node kernel on a points-only mesh (emi_set_mesh with D = NULL), values only.
 double eMI355X::odeError(const std::vector<double>& z, std::vector<double>* z_fine, size_t* nodes_fine) {
     mi355x::Prob& P = _problem;
-    const size_t ns = P.nstates, nc = P.ncontrols, nv = ns + nc, M = P.nodes, M2 = 2 * M - 1;
-    const std::vector<double> tau = P.tau, w = P.w;          // coarse mesh (P is re-meshed below)
-    const std::vector<double> D_keep = P.D, tx_keep = P.track_x, ty_keep = P.track_y;
-    setMesh(M2);
-    std::vector<double> zf(nv * M2);
-    for (size_t v = 0; v < nv; ++v) interp_lgl(tau, w, &z[v * M], M, P.tau, &zf[v * M2]);
-    for (size_t j = 0; j < nc; ++j)      // the interpolant of a bounded control may overshoot: clip
-        for (size_t k = 0; k < M2; ++k)
-            zf[(ns + j) * M2 + k] = std::min(std::max(zf[(ns + j) * M2 + k], P.control_lower[j]), P.control_upper[j]);
-    configureDevice(_dev.get());         // the solve context, on the fine mesh for one evaluation
-    std::vector<double> RES((ns + P.npath) * M2), cost(1);
-    must(emi_eval_host(_dev->ctx, zf.data(), zf.data() + ns * M2, RES.data(), nullptr, cost.data(),
-                       EMI_EVAL_ALL | EMI_EVAL_NOJAC), _dev->ctx, "emi_eval_host (ODE error)");
+    const size_t ns = P.nstates, nc = P.ncontrols, nv = ns + nc, M = P.nodes;
+    static const double gx[5] = {-0.9061798459386640, -0.5384693101056831, 0.0, 0.5384693101056831, 0.9061798459386640};
+    static const double gw[5] = {0.2369268850561891, 0.4786286704993665, 0.5688888888888889, 0.4786286704993665, 0.2369268850561891};
+    const size_t Q = 5, Mq = (M - 1) * Q;
     const double h = (P.tf - P.t0) / 2.0;
+    std::vector<double> tq(Mq), wq(Mq, 0.0);
+    for (size_t k = 0; k + 1 < M; ++k)
+        for (size_t q = 0; q < Q; ++q) tq[k * Q + q] = P.tau[k] + 0.5 * (P.tau[k + 1] - P.tau[k]) * (gx[q] + 1.0);
+    // interpolant and its tau-derivative at the quadrature points (barycentric: weights (-1)^j sqrt(w_j))
+    std::vector<double> zq(nv * Mq), dq(ns * Mq);
+    for (size_t p = 0; p < Mq; ++p) {
+        double den = 0;
+        std::vector<double> lam(M);
+        for (size_t j = 0; j < M; ++j) {
+            lam[j] = ((j & 1) ? -1.0 : 1.0) * std::sqrt(P.w[j]) / (tq[p] - P.tau[j]);
+            den += lam[j];
+        }
+        for (size_t v = 0; v < nv; ++v) {
+            double num = 0;
+            for (size_t j = 0; j < M; ++j) num += lam[j] * z[v * M + j];
+            const double val = num / den;
+            zq[v * Mq + p] = val;
+            if (v < ns) {      // p'(s) = sum_j lam_j (p(s) - x_j) / (s - tau_j) / sum_j lam_j
+                double dn = 0;
+                for (size_t j = 0; j < M; ++j) dn += lam[j] * (val - z[v * M + j]) / (tq[p] - P.tau[j]);
+                dq[v * Mq + p] = dn / den;
+            }
+        }
+    }
+    for (size_t j = 0; j < nc; ++j)      // the interpolant of a bounded control may overshoot: clip
+        for (size_t p = 0; p < Mq; ++p)
+            zq[(ns + j) * Mq + p] = std::min(std::max(zq[(ns + j) * Mq + p], P.control_lower[j]), P.control_upper[j]);
+    // moving-zone centres at the quadrature times, then f at the points on the device
+    emi_ctx_t c = _dev->ctx;
+    must(emi_set_mesh(c, (int)Mq, tq.data(), wq.data(), nullptr, P.t0, P.tf), c, "emi_set_mesh (points)");
+    if (P.ntracks) {
+        std::vector<double> tt(Mq), tx(P.tracks.size() * Mq), ty(P.tracks.size() * Mq);
+        for (size_t p = 0; p < Mq; ++p) tt[p] = P.t0 + h * (tq[p] + 1.0);
+        for (size_t i = 0; i < P.tracks.size(); ++i) {
+            const mi355x::TrackTable& tb = P.tracks[i];
+            must(emi_track_centres((int)tb.t.size(), tb.t.data(), tb.x.data(), tb.y.data(), (int)Mq, tt.data(), &tx[i * Mq], &ty[i * Mq]),
+                 nullptr, "emi_track_centres");
+        }
+        must(emi_set_tracks(c, (int)P.ntracks, 1, tx.data(), ty.data()), c, "emi_set_tracks");
+    }
+    std::vector<double> RES((ns + P.npath) * Mq), cost(1);
+    must(emi_eval_host(c, zq.data(), zq.data() + ns * Mq, RES.data(), nullptr, cost.data(), EMI_EVAL_NODES | EMI_EVAL_NOJAC), c,
+         "emi_eval_host (ODE error)");
+    // weights w_i from the nodes: |x_ik| and |(D x)_ik| / h
     double err = 0;
     for (size_t i = 0; i < ns; ++i) {
-        double dmax = 0, rate = 0;
-        for (size_t k = 0; k < M2; ++k) {
-            dmax = std::max(dmax, std::fabs(RES[i * M2 + k]));
+        double wi = 0;
+        for (size_t k = 0; k < M; ++k) {
             double dx = 0;
-            for (size_t j = 0; j < M2; ++j) dx += P.D[k * M2 + j] * zf[i * M2 + j];
-            rate = std::max(rate, std::fabs(dx));
+            for (size_t j = 0; j < M; ++j) dx += P.D[k * M + j] * z[i * M + j];
+            wi = std::max(wi, std::max(std::fabs(z[i * M + k]), std::fabs(dx) / h));
         }
-        err = std::max(err, dmax / (h * (1.0 + rate / h)));
+        for (size_t k = 0; k + 1 < M; ++k) {
+            double eta = 0;
+            for (size_t q = 0; q < Q; ++q) {
+                const size_t p = k * Q + q;
+                const double xdot = dq[i * Mq + p] / h, f = -RES[i * Mq + p] / h;      // RES defect rows hold -h f
+                eta += gw[q] * std::fabs(xdot - f);
+            }
+            eta *= 0.5 * (P.tau[k + 1] - P.tau[k]) * h;
+            err = std::max(err, eta / (wi + 1.0));
+        }
     }
-    if (z_fine) *z_fine = zf;
-    if (nodes_fine) *nodes_fine = M2;
-    // back to the coarse mesh (the caller decides whether to adopt a finer one)
-    P.nodes = M; P.tau = tau; P.w = w; P.D = D_keep; P.track_x = tx_keep; P.track_y = ty_keep;
-    configureDevice(_dev.get());
+    if (z_fine) z_fine->clear();
+    if (nodes_fine) *nodes_fine = 0;
+    configureDevice(_dev.get());         // back to the collocation mesh
     return err;
 }
 

@@ -61,7 +61,7 @@ struct Sol {
     double kkt_error = 0, constraint_violation = 0;
     std::string linear_solver;      // what the last solve used for the Newton step
     int mesh_iterations = 0;        // NLP solves performed (1 = no refinement happened)
-    double ode_error = 0;           // relative ODE error estimate on the doubled grid
+    double ode_error = 0;           // relative local ODE error of the last mesh (integral of the ODE residual between nodes)
     size_t nstates = 0, ncontrols = 0, nodes = 0;
     std::vector<double> states;     // [nstates][nodes]
     std::vector<double> controls;   // [ncontrols][nodes]
@@ -109,6 +109,9 @@ class eMI355X : public TrajectoryOptimizer {
     mi355x::Alg* getAlgorithm();
     mi355x::Sol* getSolution();
     mi355x::Prob* getProblem();
+    // PSOPT-style relative local ODE error of a trajectory z = [X (nstates x nodes), U (ncontrols x nodes)] on the
+    // current mesh (what the automatic mesh refinement compares with ode_tolerance); needs setup()
+    double odeError(const std::vector<double>& z, std::vector<double>* z_fine = nullptr, size_t* nodes_fine = nullptr);
 
  protected:
     mi355x::Alg _algorithm;
@@ -124,7 +127,6 @@ class eMI355X : public TrajectoryOptimizer {
     void getTraj();
     void setMesh(size_t nodes);          // LGL mesh + track tables for this node count
     void configureDevice(Device* dev);   // mesh, model, batch of one, path table -> device context
-    double odeError(const std::vector<double>& z, std::vector<double>* z_fine, size_t* nodes_fine);
 };
 
 }  // namespace ETOL

@@ -150,6 +150,10 @@ int emi_get_stream(emi_ctx_t ctx, void** hip_stream);
 int emi_synchronize(emi_ctx_t ctx);
 
 /* ---- problem definition ------------------------------------------------- */
+/* D may be NULL: a points-only mesh (abscissae tau and weights w without a
+ * differentiation matrix), for evaluating the node functions BETWEEN the collocation
+ * nodes (the ODE-error estimate of the mesh refinement); such a context accepts
+ * EMI_EVAL_NODES only.                                                            */
 int emi_set_mesh(emi_ctx_t ctx, int M, const double* tau, const double* w,
                  const double* D, double t0, double tf);
 int emi_set_model(emi_ctx_t ctx, int model, const double* params, int nparams,

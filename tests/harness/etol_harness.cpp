@@ -329,6 +329,21 @@ extern "C" void harness_set_refine(int mode) { g_refine = mode; }
 extern "C" void harness_set_linear_solver(const char* name) { g_linear_solver = name; }
 extern "C" const char* harness_last_linear_solver(void) { return g_out2.c_str(); }
 
+// ETOL::eMI355X::odeError (the PSOPT-style relative local error) of a given trajectory of the quadrotor problem
+extern "C" int harness_ode_error_quadrotor(int nsteps, double dt, int ndiscs, const double* X, const double* U, double* err) {
+    ETOL::eMI355X solver;
+    QuadSetup q;
+    configure_quadrotor(&solver, q, nsteps, dt, ndiscs);
+    solver.setup();
+    const size_t M = nsteps + 1;
+    std::vector<double> z(8 * M);
+    std::copy(X, X + 6 * M, z.begin());
+    std::copy(U, U + 2 * M, z.begin() + 6 * M);
+    *err = solver.odeError(z);
+    solver.close();
+    return 0;
+}
+
 // Solve the quadrotor VGP on the GPU through ETOL::eMI355X.  Outputs X[6][M], U[2][M].
 extern "C" int harness_solve_quadrotor(int nsteps, double dt, int ndiscs, double tol, int print_level, int refine,
                                        double ode_tol, double* cost, int* M, double* X, double* U, int cap, int* iters,

@@ -147,6 +147,47 @@ def test_shipped_mip_configuration_is_solved_from_a_bent_start(H, xmls):
     _assert_trajectory_parity("mip_2d_ex1", cost, X, U, "mip_2d_ex1")
 
 
+def test_ode_error_estimate_matches_an_independent_evaluation(H):
+    """The mesh-refinement criterion (PSOPT's relative local error: the ODE residual of the interpolated solution
+    integrated between consecutive nodes, ePSOPT.cpp:69-71) computed by ETOL::eMI355X::odeError -- f at the
+    quadrature points on the device -- against the same quantity from numpy + the CPU oracle, on the stored optimum
+    of the 41-node quadrotor problem and on a rough trajectory."""
+    prob = json.load(open(os.path.join(GOLD, "solve_optima.json")))["problems"]["quadrotor_41"]
+    M, tf = prob["M"], prob["tf"]
+    h = tf / 2
+    tau, w, D = O.lgl(M)
+    gx = np.polynomial.legendre.leggauss(5)
+    D_ = C.POINTER(C.c_double)
+    H.harness_ode_error_quadrotor.argtypes = [C.c_int, C.c_double, C.c_int, D_, D_, D_]
+    rng = np.random.default_rng(3)
+    for label in ("optimum", "perturbed"):
+        X, U = np.array(prob["optima"][0]["X"]), np.array(prob["optima"][0]["U"])
+        if label == "perturbed":
+            X = X + 0.05 * rng.standard_normal(X.shape) * np.sin(np.pi * (tau + 1) / 2)
+            U = np.clip(U + 0.3 * rng.standard_normal(U.shape), [[0.0], [-1.0]], [[25.0], [1.0]])
+        got = C.c_double()
+        assert H.harness_ode_error_quadrotor(M - 1, tf / (M - 1), 2, np.ascontiguousarray(X).ctypes.data_as(D_),
+                                             np.ascontiguousarray(U).ctypes.data_as(D_), C.byref(got)) == 0
+        # independent evaluation: Lagrange interpolant by polynomial fitting in the Legendre basis, oracle f
+        Z = np.vstack([X, U])
+        coef = [np.polynomial.legendre.Legendre.fit(tau, Z[v], M - 1, domain=[-1, 1]) for v in range(8)]
+        pts = np.concatenate([tau[k] + 0.5 * (tau[k + 1] - tau[k]) * (gx[0] + 1) for k in range(M - 1)])
+        Zq = np.array([c(pts) for c in coef])
+        Zq[6] = np.clip(Zq[6], 0, 25); Zq[7] = np.clip(Zq[7], -1, 1)
+        dZq = np.array([coef[i].deriv()(pts) for i in range(6)]) / h
+        P = len(pts)
+        RES, _, _ = O.evaluate(1, [1.0, 0.01, 9.81, 1.0, 1.0], P, (pts, np.zeros(P), np.zeros((P, P))), 0.0, tf,
+                               Zq[None, :6], Zq[None, 6:])
+        f = -RES[0, :6] / h
+        resid = np.abs(dZq - f).reshape(6, M - 1, 5)
+        eta = (resid * gx[1]).sum(axis=2) * 0.5 * np.diff(tau) * h
+        wi = np.maximum(np.abs(X).max(axis=1), np.abs(X @ D.T).max(axis=1) / h)
+        ref = (eta / (wi[:, None] + 1)).max()
+        print(f"ODE error estimate, {label}: device-assisted {got.value:.6e}, independent {ref:.6e}")
+        assert abs(got.value - ref) < 1e-7 * ref + 1e-13
+    assert got.value > 1e-3          # the rough trajectory is far from satisfying the ODE between its nodes
+
+
 def test_example_program_runs(built, tmp_path, xmls):
     exe = os.path.join(ROOT, "etol_amd", "lib", "etol_mi355x_example1")
     r = subprocess.run([exe, xmls["ocp_2d_ex1.xml"]], cwd=tmp_path, capture_output=True, text=True, timeout=300)

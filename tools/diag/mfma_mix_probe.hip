@@ -5,6 +5,8 @@
 //   bit 2: one s_barrier per tile (256-thread workgroups)
 //   bit 3: 5 LDS-DMA instructions (global_load_lds_dwordx4, 1 KB each) per wave and tile from an L2-resident buffer,
 //          counted vmcnt two tiles behind
+//   bit 4: (with bit 3) the B operands (De / Do rows, private to a wave) do not go through LDS: two 16-byte global
+//          loads per lane and tile straight into registers (inline asm, one tile ahead), 3 LDS-DMA instructions left
 // W = workgroups per CU (1 or 2).  Prints cycles per MFMA per SIMD (64 = the pipe's rate) and TFLOP/s.
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -31,22 +33,38 @@ __global__ __launch_bounds__(256, 2) void tile_loop(int tiles, unsigned long lon
     const double* src = gbuf + ((size_t)blockIdx.x * 64 + lane) * 2 + wid * 128;
     auto issue = [&](int stage, int kt) {
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
+        for (int t = 0; t < ((MODE & 16) ? 3 : 5); ++t) {
             double* dst = smem + (size_t)stage * STAGE + (size_t)(wid + 4 * t) * 128;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + ((kt * 5 + t) & 63) * 512), (lds_ptr_t)dst, 16, 0, 0);
         }
     };
-    if (MODE & 8) { issue(0, 0); issue(1, 1); }
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i dn0 = {0, 0, 0, 0}, dn1 = {0, 0, 0, 0};          // B fragments of the NEXT tile, in flight
+    const double* dsrc = gbuf + (size_t)(blockIdx.x & 63) * 4096 + (wid * 16 + r16) * 64 + kq * 2;
+    auto dload = [&](int kt) {
+        const double* g0 = dsrc + (kt & 7) * 8, *g1 = g0 + 2048;
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off" : "=v"(dn0), "=v"(dn1) : "v"(g0), "v"(g1) : "memory");
+    };
+    if (MODE & 8) { issue(0, 0); if (MODE & 16) dload(0); issue(1, 1); }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int kt = 0; kt < tiles; ++kt) {
-        if (MODE & 8) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if ((MODE & 24) == 24) {
+            // outstanding, oldest first: X(kt) | D(kt) | X(kt+1): all but the 3 youngest must have landed
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(dn0), "+v"(dn1) :: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_memcpy(&be, &dn0, 16);
+            __builtin_memcpy(&bo, &dn1, 16);
+        } else if (MODE & 8) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         if (MODE & 4) asm volatile("s_barrier" ::: "memory");
+        if ((MODE & 24) == 24) dload(kt + 1);
         if (MODE & 8) issue((kt + 2) % 3, kt + 2);
         if (MODE & 2) {
             const double* S = smem + (size_t)(kt % 3) * STAGE;
             const int rb = wid * 16 + r16;
-            be = *reinterpret_cast<const double2*>(S + 192 * 8 + rb * 8 + ((kq ^ ((0 - (rb >> 2)) & 3)) << 1));
-            bo = *reinterpret_cast<const double2*>(S + 256 * 8 + rb * 8 + ((kq ^ ((0 - (rb >> 2)) & 3)) << 1));
+            if (!(MODE & 16)) {
+                be = *reinterpret_cast<const double2*>(S + 192 * 8 + rb * 8 + ((kq ^ ((0 - (rb >> 2)) & 3)) << 1));
+                bo = *reinterpret_cast<const double2*>(S + 256 * 8 + rb * 8 + ((kq ^ ((0 - (rb >> 2)) & 3)) << 1));
+            }
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
                 const int r = s * 16 + r16;
@@ -93,8 +111,8 @@ template <int MODE> void run(int wpc, const double* gbuf, unsigned long long* d_
     for (int i = 0; i < nblk; ++i) { clk[i] = (double)st[2 * i] / st[2 * i + 1] * 100e6; cyc[i] = (double)st[2 * i]; }
     std::sort(clk.begin(), clk.end()); std::sort(cyc.begin(), cyc.end());
     const double nm = 24.0 * tiles;
-    printf("{\"mode\": %d, \"v_add\": %d, \"lds_reads\": %d, \"barrier\": %d, \"lds_dma\": %d, \"wg_per_cu\": %d, \"ms\": %.3f, \"clock_GHz\": %.3f, "
-           "\"cycles_per_mfma_per_simd\": %.2f, \"TFLOPs\": %.2f}\n", MODE, MODE & 1, (MODE >> 1) & 1, (MODE >> 2) & 1, (MODE >> 3) & 1, wpc, ms,
+    printf("{\"mode\": %d, \"v_add\": %d, \"lds_reads\": %d, \"barrier\": %d, \"lds_dma\": %d, \"b_direct\": %d, \"wg_per_cu\": %d, \"ms\": %.3f, \"clock_GHz\": %.3f, "
+           "\"cycles_per_mfma_per_simd\": %.2f, \"TFLOPs\": %.2f}\n", MODE, MODE & 1, (MODE >> 1) & 1, (MODE >> 2) & 1, (MODE >> 3) & 1, (MODE >> 4) & 1, wpc, ms,
            clk[nblk / 2] / 1e9, cyc[nblk / 2] / nm / wpc, nm * 2048.0 * 4 * nblk / (ms * 1e-3) / 1e12);
 }
 
@@ -109,6 +127,7 @@ int main() {
         run<3>(wpc, gbuf, d_st, d_sink);
         run<7>(wpc, gbuf, d_st, d_sink);
         run<15>(wpc, gbuf, d_st, d_sink);
+        run<31>(wpc, gbuf, d_st, d_sink);
     }
     return 0;
 }
