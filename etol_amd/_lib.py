@@ -57,8 +57,8 @@ SYMBOLS = {
     "emi_synchronize": (C.c_int, [_P]),
     "emi_set_mesh": (C.c_int, [_P, C.c_int, _D, _D, _D, C.c_double, C.c_double]),
     "emi_set_model": (C.c_int, [_P, C.c_int, _D, C.c_int, C.c_int]),
-    "emi_set_model_source": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, _D, C.c_int, C.c_int]),
-    "emi_check_model_source": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    "emi_set_model_source": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, _I, C.c_int, _D, C.c_int, C.c_int]),
+    "emi_check_model_source": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "emi_kkt_factor": (C.c_int, [_P, _D, _D, C.POINTER(C.c_ubyte), C.c_double, C.POINTER(C.c_int)]),
     "emi_kkt_solve": (C.c_int, [_P, _D, C.c_int]),
     "emi_kkt_lowrank": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _D, _D, C.POINTER(C.c_int)]),

@@ -72,12 +72,14 @@ struct emi_ctx_s {
     int B = 0;
     int np = 0, path_sets = 0, px = 0, py = 1;
     int np_model = 0;           // path rows computed by the model itself (emi_set_model_source npath)
+    std::vector<int> pvars;     // node variables those rows depend on (PW of them): PW partials per traced row in VALS
     DevBuf d_path;
     int ntracks = 0, track_sets = 0;
     DevBuf d_trkx, d_trky;
     DevBuf d_cost_part;
     DevBuf d_slab;              // partial sums of a split-K defect launch
     DevBuf d_ticket;            // [B] arrival counters of the in-kernel COST finish (zeroed once, self-resetting)
+    int slice_first = 0;        // first instance of the slice emi_eval_dev is working on (per-instance tables are offset by it)
     int sym_ksplit = 0;         // "sym_ksplit" option: K slices of an SW = NS launch (0: by batch size)
     // host-form staging
     DevBuf s_X, s_U, s_RES, s_VALS, s_COST, s_LF, s_LC, s_H;
@@ -158,7 +160,7 @@ bool overlapped_path(emi_ctx_t c) {
 }
 
 int np_total(emi_ctx_t c) { return c->np + c->np_model; }     // rows of the record table, then the model's own (traced) rows
-int nvals_of(emi_ctx_t c) { return c->ns * (c->ns + c->nc) + 2 * np_total(c) + (c->ns + c->nc); }
+int nvals_of(emi_ctx_t c) { return c->ns * (c->ns + c->nc) + 2 * c->np + c->np_model * (int)c->pvars.size() + (c->ns + c->nc); }
 int nres_of(emi_ctx_t c) { return c->ns + np_total(c); }
 int nhess_of(emi_ctx_t c) { const int nv = c->ns + c->nc; return nv * (nv + 1) / 2; }
 
@@ -181,15 +183,15 @@ void fill_node_args(emi_ctx_t c, emi::NodeArgs<T>& a, const void* dX, const void
     a.U = (const T*)dU;
     a.RES = (T*)dRES;
     a.VALS = (T*)dVALS;
-    a.cost_part = (T*)c->d_cost_part.p;
+    a.cost_part = (T*)c->d_cost_part.p + (size_t)c->slice_first * emi::node_chunks(c->M);
     a.cost = (T*)dCOST;
     a.cost_ticket = nullptr;
     a.w = (const T*)c->d_w.p;
     a.node_t = (const T*)c->d_t.p;
     a.Ddiag = (const T*)c->d_Ddiag.p;
-    a.path = (const T*)c->d_path.p;
-    a.track_x = (const T*)c->d_trkx.p;
-    a.track_y = (const T*)c->d_trky.p;
+    a.path = (const T*)c->d_path.p + (c->path_sets > 1 ? (size_t)c->slice_first * c->np * EMI_PATH_REC : 0);
+    a.track_x = (const T*)c->d_trkx.p + (c->track_sets > 1 ? (size_t)c->slice_first * c->ntracks * c->M : 0);
+    a.track_y = (const T*)c->d_trky.p + (c->track_sets > 1 ? (size_t)c->slice_first * c->ntracks * c->M : 0);
     a.M = c->M;
     a.B = c->B;
     a.np = np_total(c);
@@ -428,6 +430,7 @@ int emi_set_model(emi_ctx_t c, int model, const double* params, int nparams, int
     c->ns = ns;
     c->nc = nc;
     c->np_model = 0;
+    c->pvars.clear();
     c->maximize = maximize ? 1 : 0;
     memset(c->params, 0, sizeof c->params);
     for (int i = 0; i < nparams; ++i) c->params[i] = params[i];
@@ -438,16 +441,21 @@ int emi_set_model(emi_ctx_t c, int model, const double* params, int nparams, int
 }
 
 int emi_set_model_source(emi_ctx_t c, const char* struct_name, const char* source, int ns, int nc, int npath,
-                         const double* params, int nparams, int maximize) {
+                         const int* path_vars, int n_path_vars, const double* params, int nparams, int maximize) {
     if (!c) return EMI_ERR_ARG;
     if (npath < 0 || npath > 64) return fail(c, EMI_ERR_ARG, "emi_set_model_source: npath must be in [0, 64]");
+    if (npath > 0 && (!path_vars || n_path_vars < 1 || n_path_vars > ns + nc))
+        return fail(c, EMI_ERR_ARG, "emi_set_model_source: %d traced rows need the list of variables they depend on", npath);
+    for (int q = 0; q < (npath > 0 ? n_path_vars : 0); ++q)
+        if (path_vars[q] < 0 || path_vars[q] >= ns + nc || (q > 0 && path_vars[q] <= path_vars[q - 1]))
+            return fail(c, EMI_ERR_ARG, "emi_set_model_source: path_vars must be ascending node-variable indices below %d", ns + nc);
     if (nparams < 0 || nparams > EMI_MAX_PARAMS || (nparams > 0 && !params))
         return fail(c, EMI_ERR_ARG, "emi_set_model_source: at most %d parameters", EMI_MAX_PARAMS);
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     emi::RtcModel* m = nullptr;
     std::string log;
-    const int st = emi::rtc_build(c->f32, struct_name, source, ns, nc, npath, &m, &log);
+    const int st = emi::rtc_build(c->f32, struct_name, source, ns, nc, npath, npath > 0 ? n_path_vars : 0, &m, &log);
     if (st) {
         c->err = log;
         return st;
@@ -458,6 +466,7 @@ int emi_set_model_source(emi_ctx_t c, const char* struct_name, const char* sourc
     c->ns = ns;
     c->nc = nc;
     c->np_model = npath;
+    c->pvars.assign(path_vars, path_vars + (npath > 0 ? n_path_vars : 0));
     c->maximize = maximize ? 1 : 0;
     memset(c->params, 0, sizeof c->params);
     for (int i = 0; i < nparams; ++i) c->params[i] = params[i];
@@ -467,10 +476,10 @@ int emi_set_model_source(emi_ctx_t c, const char* struct_name, const char* sourc
     return EMI_OK;
 }
 
-int emi_check_model_source(const char* struct_name, const char* source, int ns, int nc, int npath, int f32, char* log,
-                           size_t log_len) {
+int emi_check_model_source(const char* struct_name, const char* source, int ns, int nc, int npath, int n_path_vars, int f32,
+                           char* log, size_t log_len) {
     std::string l;
-    const int st = emi::rtc_check(f32 != 0, struct_name, source, ns, nc, npath, &l);
+    const int st = emi::rtc_check(f32 != 0, struct_name, source, ns, nc, npath, npath > 0 ? n_path_vars : 0, &l);
     if (log && log_len) {
         strncpy(log, l.c_str(), log_len - 1);
         log[log_len - 1] = '\0';
@@ -550,16 +559,22 @@ int emi_get_layout(emi_ctx_t c, emi_layout_t* o) {
 int emi_jac_structure(emi_ctx_t c, int* rows, int* cols) {
     if (!c || !rows || !cols) return EMI_ERR_ARG;
     if (c->M <= 0 || c->model < 0) return fail(c, EMI_ERR_STATE, "mesh and model must be set");
-    const int M = c->M, ns = c->ns, nv = c->ns + c->nc, np = np_total(c);
+    const int M = c->M, ns = c->ns, nv = c->ns + c->nc;
     size_t e = 0;
     for (int i = 0; i < ns; ++i)
         for (int v = 0; v < nv; ++v)
             for (int k = 0; k < M; ++k, ++e) { rows[e] = i * M + k; cols[e] = v * M + k; }
-    for (int j = 0; j < np; ++j)
+    for (int j = 0; j < c->np; ++j)                      // rows of the record table: two partials, (px, py)
         for (int s = 0; s < 2; ++s)
             for (int k = 0; k < M; ++k, ++e) {
                 rows[e] = ns * M + 2 * ns + j * M + k;
                 cols[e] = (s == 0 ? c->px : c->py) * M + k;
+            }
+    for (int j = 0; j < c->np_model; ++j)                // traced rows: one partial per variable of the model's list
+        for (size_t q = 0; q < c->pvars.size(); ++q)
+            for (int k = 0; k < M; ++k, ++e) {
+                rows[e] = ns * M + 2 * ns + (c->np + j) * M + k;
+                cols[e] = c->pvars[q] * M + k;
             }
     for (int v = 0; v < nv; ++v)
         for (int k = 0; k < M; ++k, ++e) { rows[e] = -1; cols[e] = v * M + k; }
@@ -590,10 +605,36 @@ int emi_d2h(emi_ctx_t c, void* dst, const void* src, size_t bytes) {
     return EMI_OK;
 }
 
+static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* dVALS, void* dCOST, unsigned flags);
+
 int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* dVALS, void* dCOST,
                  unsigned flags) {
     int st = ready(c);
     if (st) return st;
+    // Very large batches go through the overlapped pass in slices of 1024 instances: the two kernels of a slice finish
+    // together, whereas one pair of launches over 16384 instances drifts apart (measured 3.4e9 node-evals/s against
+    // 4.1e9 at 1024, profiles/r02_batch_sweep.json).  Not while per-kernel profiling is on (one bracket per call).
+    const int SL = 1024;
+    if (c->B > 2 * SL && !c->profile && !c->f32 && (flags & EMI_EVAL_ALL) == EMI_EVAL_ALL && overlapped_path(c) && dX && dU && dRES && dCOST &&
+        (dVALS || (flags & EMI_EVAL_NOJAC))) {
+        const int Btot = c->B;
+        const size_t rb = 8, M = c->M;
+        const size_t nres = nres_of(c), nvals = nvals_of(c);
+        for (int first = 0; first < Btot && st == EMI_OK; first += SL) {
+            c->B = std::min(SL, Btot - first);
+            c->slice_first = first;
+            st = eval_dev_slice(c, (const char*)dX + (size_t)first * c->ns * M * rb, (const char*)dU + (size_t)first * c->nc * M * rb,
+                                (char*)dRES + (size_t)first * nres * M * rb, dVALS ? (char*)dVALS + (size_t)first * nvals * M * rb : nullptr,
+                                (char*)dCOST + (size_t)first * rb, flags);
+        }
+        c->B = Btot;
+        c->slice_first = 0;
+        return st;
+    }
+    return eval_dev_slice(c, dX, dU, dRES, dVALS, dCOST, flags);
+}
+
+static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* dVALS, void* dCOST, unsigned flags) {
     const bool nodes = flags & EMI_EVAL_NODES, defect = flags & EMI_EVAL_DEFECT;
     const bool jac = !(flags & EMI_EVAL_NOJAC);
     if (!nodes && !defect) return fail(c, EMI_ERR_ARG, "emi_eval: empty flags");

@@ -44,8 +44,8 @@ hipError_t launch_pass(int model, const SymDefectArgs& sa, const NodeArgs<double
 
 // model programs compiled at run time (emi_rtc.hip); the int results are EMI_* status codes
 struct RtcModel;
-int rtc_check(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, std::string* log);
-int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, RtcModel** out, std::string* log);
+int rtc_check(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, int pw, std::string* log);
+int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, int pw, RtcModel** out, std::string* log);
 void rtc_destroy(RtcModel* m);
 bool rtc_has_symdefect(const RtcModel* m);
 template <typename T>

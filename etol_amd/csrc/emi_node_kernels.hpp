@@ -49,6 +49,12 @@ EMI_DEV void store_vec(T* __restrict__ p, const T (&r)[VEC]) {
     }
 }
 
+// VALS entries of the rows traced from constraint callbacks: NPATH * PW (0 for the hand-written models)
+template <class Model> EMI_DEV constexpr int emi_traced_partials() {
+    if constexpr (Model::NPATH > 0) return Model::NPATH * Model::PW;
+    else return 0;
+}
+
 // wave64 sum (all lanes end with lane 0 holding the total)
 template <typename T> EMI_DEV T wave_sum(T v) {
 #pragma unroll
@@ -143,7 +149,8 @@ EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, con
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
                     store_vec<T, VEC, ST>(Vb + (size_t)(i * NV + v) * M + k0, Jv[i][v]);
-            T* __restrict__ Gb = Vb + (size_t)(NS * NV + 2 * a.np) * M;
+            // cost gradient: behind the dynamics block, two partials per table row and PW per traced row
+            T* __restrict__ Gb = Vb + (size_t)(NS * NV + 2 * (a.np - Model::NPATH) + emi_traced_partials<Model>()) * M;
 #pragma unroll
             for (int v = 0; v < NV; ++v) store_vec<T, VEC, ST>(Gb + (size_t)v * M + k0, gv[v]);
         }
@@ -217,25 +224,26 @@ EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, con
                 }
             }
             if constexpr (Model::NPATH > 0) {
-                // rows traced from the user's constraint callbacks (generated straight-line code)
-                constexpr int NPM = Model::NPATH;
-                T cm[NPM][VEC], cxm[NPM][VEC], cym[NPM][VEC];
+                // rows traced from the user's constraint callbacks (generated straight-line code): values, then PW
+                // partials per row (w.r.t. the variables Model::pvar(0..PW-1)) behind the table rows' pairs
+                constexpr int NPM = Model::NPATH, PW = Model::PW;
+                T cm[NPM][VEC], cdm[NPM * PW][VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) {
-                    T ze[NV], ce[NPM], cxe[NPM], cye[NPM];
+                    T ze[NV], ce[NPM], cde[NPM * PW];
 #pragma unroll
                     for (int v = 0; v < NV; ++v) ze[v] = z[v][e];
-                    Model::path(a.P, ze, tk[e], ce, cxe, cye);
+                    Model::path(a.P, ze, tk[e], ce, cde);
 #pragma unroll
-                    for (int j = 0; j < NPM; ++j) { cm[j][e] = ce[j]; cxm[j][e] = cxe[j]; cym[j][e] = cye[j]; }
+                    for (int j = 0; j < NPM; ++j) cm[j][e] = ce[j];
+#pragma unroll
+                    for (int j = 0; j < NPM * PW; ++j) cdm[j][e] = cde[j];
                 }
 #pragma unroll
-                for (int j = 0; j < NPM; ++j) {
-                    store_vec<T, VEC, ST>(Cb + (size_t)(np + j) * M + k0, cm[j]);
-                    if (JAC) {
-                        store_vec<T, VEC, ST>(JCb + (size_t)(2 * (np + j)) * M + k0, cxm[j]);
-                        store_vec<T, VEC, ST>(JCb + (size_t)(2 * (np + j) + 1) * M + k0, cym[j]);
-                    }
+                for (int j = 0; j < NPM; ++j) store_vec<T, VEC, ST>(Cb + (size_t)(np + j) * M + k0, cm[j]);
+                if (JAC) {
+#pragma unroll
+                    for (int j = 0; j < NPM * PW; ++j) store_vec<T, VEC, ST>(JCb + (size_t)(2 * np + j) * M + k0, cdm[j]);
                 }
             }
         }
@@ -326,14 +334,11 @@ __global__ __launch_bounds__(EMI_NODE_THREADS) void emi_hess_kernel(HessArgs<T> 
                 hyy += mu * T(-2);
             }
         }
-        if constexpr (Model::NPATH > 0) {
-            T mu[Model::NPATH], h3[3] = {T(0), T(0), T(0)};
+        if constexpr (Model::NPATH > 0) {      // traced rows: sum_j mu_j c_j,zz straight into the packed triangle
+            T mu[Model::NPATH];
 #pragma unroll
             for (int j = 0; j < Model::NPATH; ++j) mu[j] = a.lamC[((size_t)b * a.np + np + j) * M + k];
-            Model::path_hess(a.P, z, a.node_t[k], mu, h3);
-            hxx += h3[0];
-            hxy += h3[1];
-            hyy += h3[2];
+            Model::path_hess(a.P, z, a.node_t[k], mu, H);
         }
         const int lo = a.px < a.py ? a.px : a.py, hi = a.px < a.py ? a.py : a.px;
         const int qxx = a.px * (a.px + 1) / 2 + a.px, qyy = a.py * (a.py + 1) / 2 + a.py;

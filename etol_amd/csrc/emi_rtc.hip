@@ -65,7 +65,7 @@ Names kernel_names(const char* sn, bool f32, bool with_ring) {
 
 // compile; on success *code holds the gfx950 code object and *lowered the mangled kernel names in
 // the order nodes[0][0][0..1], nodes[0][1][..], nodes[1][..][..], hess, ring
-int compile(bool f32, const char* sn, const char* source, int ns, int nc, int npath, std::vector<char>* code,
+int compile(bool f32, const char* sn, const char* source, int ns, int nc, int npath, int pw, std::vector<char>* code,
             std::vector<std::string>* lowered, bool* has_ring, std::string* log) {
     if (!valid_identifier(sn) || !source || ns < 1 || nc < 0 || ns + nc > 64) {
         if (log) *log = "emi_set_model_source: bad struct name, null source or dimensions out of range";
@@ -77,11 +77,16 @@ int compile(bool f32, const char* sn, const char* source, int ns, int nc, int np
     prog += "namespace emi {\n";
     prog += source;
     prog += "\n}  // namespace emi\n";
-    char chk[400];
+    char chk[600];
     snprintf(chk, sizeof chk, "static_assert(emi::%s<double>::NS == %d && emi::%s<double>::NC == %d && emi::%s<double>::NV == %d && "
              "emi::%s<double>::NPATH == %d, \"model struct dimensions differ from emi_set_model_source(ns, nc, npath)\");\n", sn, ns,
              sn, nc, sn, ns + nc, sn, npath);
     prog += chk;
+    if (npath > 0) {
+        snprintf(chk, sizeof chk, "static_assert(emi::%s<double>::PW == %d, \"the model's traced rows depend on another number of "
+                 "variables than emi_set_model_source(n_path_vars) says\");\n", sn, pw);
+        prog += chk;
+    }
 
     hiprtcProgram p;
     if (hiprtcCreateProgram(&p, prog.c_str(), "emi_model_program.hip", emi_rtc_nfiles, emi_rtc_texts, emi_rtc_names) !=
@@ -141,11 +146,11 @@ hipError_t launch(hipFunction_t f, dim3 grid, dim3 block, size_t lds, hipStream_
 
 }  // namespace
 
-int rtc_check(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, std::string* log) {
+int rtc_check(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, int pw, std::string* log) {
     std::vector<char> code;
     std::vector<std::string> low;
     bool ring = false;
-    return compile(f32, struct_name, source, ns, nc, npath, &code, &low, &ring, log);
+    return compile(f32, struct_name, source, ns, nc, npath, pw, &code, &low, &ring, log);
 }
 
 namespace {
@@ -160,7 +165,7 @@ std::mutex g_cache_mutex;
 std::map<std::string, CachedProgram> g_cache;
 }  // namespace
 
-int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, RtcModel** out,
+int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int nc, int npath, int pw, RtcModel** out,
               std::string* log) {
     *out = nullptr;
     std::vector<char> code;
@@ -180,7 +185,7 @@ int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int
         }
     }
     if (!hit) {
-        const int st = compile(f32, struct_name, source, ns, nc, npath, &code, &low, &ring, log);
+        const int st = compile(f32, struct_name, source, ns, nc, npath, pw, &code, &low, &ring, log);
         if (st) return st;
         std::lock_guard<std::mutex> lk(g_cache_mutex);
         CachedProgram& cp = g_cache[key];

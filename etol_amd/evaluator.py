@@ -88,10 +88,13 @@ class Evaluator:
         self._ck(self.lib.emi_set_model(self.ctx, model, _dp(p) if p.size else None, p.size, int(maximize)),
                  "emi_set_model")
 
-    def set_model_source(self, struct_name, source, ns, nc, params=(), maximize=False, npath=0):
-        """Install a model given as the text of a model struct (compiled for gfx950 here)."""
+    def set_model_source(self, struct_name, source, ns, nc, params=(), maximize=False, npath=0, path_vars=()):
+        """Install a model given as the text of a model struct (compiled for gfx950 here).  npath rows traced from
+        constraint callbacks depend on the node variables path_vars (ascending; states first, then controls)."""
         p = np.ascontiguousarray(params, dtype=np.float64)
+        pv = np.ascontiguousarray(path_vars, dtype=np.int32)
         self._ck(self.lib.emi_set_model_source(self.ctx, struct_name.encode(), source.encode(), ns, nc, npath,
+                                               pv.ctypes.data_as(C.POINTER(C.c_int)) if pv.size else None, pv.size,
                                                _dp(p) if p.size else None, p.size, int(maximize)),
                  "emi_set_model_source")
 

@@ -228,24 +228,22 @@ void eMI355X::traceCallbacks() {
             }
         }
         P.npath_traced = path_nodes.size();
+        P.path_vars.clear();
         if (!path_nodes.empty()) {
-            // the two states the traced rows act on (the Jacobian layout holds two partials per row)
+            // Traced rows may depend on any states and controls of their node; the keep-out geometry (guess repair,
+            // bent starts) works on the two position states: those of the table rows, or else the first two states
+            // the traced rows use.
             mi355x::Trace& tr = mi355x::Trace::active();
             std::vector<int> used;
             for (int n : path_nodes)
                 for (int v : tr.dependencies(n, (int)getNStates(), (int)getNControls()))
                     if (std::find(used.begin(), used.end(), v) == used.end()) used.push_back(v);
             std::sort(used.begin(), used.end());
-            for (int v : used)
-                if (v >= (int)getNStates()) die("traced constraint rows may depend on states (and time), not on controls");
-            if (have_xy) {
-                for (int v : used)
-                    if (v != (int)P.px && v != (int)P.py) die("traced constraint rows must act on the states of the keep-out rows");
-            } else {
-                if (used.size() > 2) die("traced constraint rows may depend on two states; they use " + std::to_string(used.size()));
-                P.px = used.empty() ? 0 : used[0];
-                P.py = used.size() > 1 ? used[1] : (P.px + 1 < getNStates() ? P.px + 1 : (P.px > 0 ? P.px - 1 : 0));
-                if (P.py == P.px) die("a problem with one state cannot carry traced path rows");
+            if (!have_xy) {
+                std::vector<int> st;
+                for (int v : used) if (v < (int)getNStates()) st.push_back(v);
+                P.px = st.empty() ? 0 : st[0];
+                P.py = st.size() > 1 ? st[1] : (P.px + 1 < getNStates() ? P.px + 1 : (P.px > 0 ? P.px - 1 : 0));
             }
             // row normalisation (the iteration works on sigma_j c_j): largest value along the straight line between
             // the boundary states, which for a keep-out row is reached where the line passes closest to its centre
@@ -265,7 +263,7 @@ void eMI355X::traceCallbacks() {
             P.model_params.clear();
             std::string gerr;
             P.model_source = mi355x::Trace::active().generate_model("TracedModel", (int)getNStates(), (int)getNControls(), f_nodes,
-                                                                     cost_node, path_nodes, (int)P.px, (int)P.py, &gerr);
+                                                                     cost_node, path_nodes, &P.path_vars, &gerr);
             if (P.model_source.empty()) die(gerr);
         }
         // rows are evaluated table rows first, traced rows after them; bounds arrive in callback order
@@ -400,7 +398,8 @@ void eMI355X::configureDevice(Device* dev) {
         // compiled for gfx950 once per context; meshes come and go.  The call also fixes the objective sign.
         if (dev->installed_source != P.model_source || dev->installed_maximize != isMaximized())
             must(emi_set_model_source(c, "TracedModel", P.model_source.c_str(), (int)P.nstates, (int)P.ncontrols,
-                                      (int)P.npath_traced, nullptr, 0, isMaximized() ? 1 : 0), c, "emi_set_model_source");
+                                      (int)P.npath_traced, P.path_vars.data(), (int)P.path_vars.size(), nullptr, 0,
+                                      isMaximized() ? 1 : 0), c, "emi_set_model_source");
         dev->installed_source = P.model_source;
         dev->installed_maximize = isMaximized();
     } else {
@@ -527,6 +526,19 @@ NlpProblem make_nlp(const Prob& P, NlpEvaluator* ev) {
     NlpProblem nlp;
     nlp.ns = (int)ns; nlp.nc = (int)nc; nlp.np = (int)P.npath; nlp.M = (int)M;
     nlp.px = (int)P.px; nlp.py = (int)P.py;
+    // (variable, VALS entry) pairs of every path row: table rows two partials on (px, py), traced rows one per variable
+    // of the model's list
+    {
+        const int nv = (int)(P.nstates + P.ncontrols), base = (int)P.nstates * nv;
+        const int ntab = (int)(P.npath - P.npath_traced), pw = (int)P.path_vars.size();
+        nlp.row_vars.clear();
+        for (int j = 0; j < ntab; ++j) nlp.row_vars.push_back({{(int)P.px, base + 2 * j}, {(int)P.py, base + 2 * j + 1}});
+        for (int j = 0; j < (int)P.npath_traced; ++j) {
+            std::vector<std::pair<int, int>> rv;
+            for (int q = 0; q < pw; ++q) rv.push_back({P.path_vars[q], base + 2 * ntab + j * pw + q});
+            nlp.row_vars.push_back(rv);
+        }
+    }
     nlp.D = P.D;
     nlp.ev = ev;
     nlp.zl.resize(nv * M);

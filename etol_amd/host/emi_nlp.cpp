@@ -412,7 +412,14 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     NlpResult R;
     const int ns = P.ns, nc = P.nc, np = P.np, M = P.M, nv = ns + nc;
     const int nz = nv * M, md = ns * M, mc = np * M, nh = nv * (nv + 1) / 2;
-    const int nvals = ns * nv + 2 * np + nv;
+    // (variable, VALS entry) pairs of every path row
+    std::vector<std::vector<std::pair<int, int>>> rv = P.row_vars;
+    if (rv.empty())
+        for (int j = 0; j < np; ++j) rv.push_back({{P.px, ns * nv + 2 * j}, {P.py, ns * nv + 2 * j + 1}});
+    if ((int)rv.size() != np) { R.msg = "solve_nlp: row_vars has the wrong length"; return R; }
+    int npart = 0;
+    for (const auto& r : rv) npart += (int)r.size();
+    const int nvals = ns * nv + npart + nv;
     if (!P.ev || (int)P.zl.size() != nz || (int)P.zu.size() != nz || (int)P.D.size() != M * M ||
         (int)P.cl.size() != np || (int)P.cu.size() != np || (int)z0.size() != nz) {
         R.msg = "solve_nlp: inconsistent problem sizes";
@@ -527,7 +534,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     auto grad_and_jt = [&](const Iterate& I) {
         const double* V = E.VALS.data();
         for (int v = 0; v < nv; ++v)
-            for (int k = 0; k < M; ++k) gradf[v * M + k] = V[(size_t)(ns * nv + 2 * np + v) * M + k];
+            for (int k = 0; k < M; ++k) gradf[v * M + k] = V[(size_t)(ns * nv + npart + v) * M + k];
         std::fill(jtl.begin(), jtl.end(), 0.0);
         // J_d^T lam: off-diagonal D part, then the node blocks (which hold D_kk)
         for (int i = 0; i < ns; ++i)
@@ -543,8 +550,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         for (int j = 0; j < np; ++j)
             for (int k = 0; k < M; ++k) {
                 const double yy = I.y[j * M + k];
-                jtl[P.px * M + k] += V[(size_t)(ns * nv + 2 * j) * M + k] * yy;
-                jtl[P.py * M + k] += V[(size_t)(ns * nv + 2 * j + 1) * M + k] * yy;
+                for (const auto& ve : rv[j]) jtl[ve.first * M + k] += V[(size_t)ve.second * M + k] * yy;
             }
     };
     auto row_res = [&](const Eval& e, const std::vector<double>& s, const std::vector<double>& e1,
@@ -653,8 +659,8 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         for (int j = 0; j < np; ++j)
             for (int k = 0; k < M; ++k) {
                 const double t = sig_t[j * M + k] * r_t[j * M + k];
-                if (fidx[P.px * M + k] >= 0) out[P.px * M + k] -= V[(size_t)(ns * nv + 2 * j) * M + k] * t;
-                if (fidx[P.py * M + k] >= 0) out[P.py * M + k] -= V[(size_t)(ns * nv + 2 * j + 1) * M + k] * t;
+                for (const auto& ve : rv[j])
+                    if (fidx[ve.first * M + k] >= 0) out[ve.first * M + k] -= V[(size_t)ve.second * M + k] * t;
             }
         for (int r = 0; r < md; ++r) out[nz + r] = -defres[r];
     };
@@ -713,8 +719,8 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         for (int j = 0; j < np; ++j)
             for (int k = 0; k < M; ++k) {
                 const int r = j * M + k;
-                const double jcdz = V[(size_t)(ns * nv + 2 * j) * M + k] * dz[P.px * M + k] +
-                                    V[(size_t)(ns * nv + 2 * j + 1) * M + k] * dz[P.py * M + k];
+                double jcdz = 0.0;
+                for (const auto& ve : rv[j]) jcdz += V[(size_t)ve.second * M + k] * dz[ve.first * M + k];
                 dy[r] = sig_t[r] * (jcdz + r_t[r]);
                 ds[r] = (dy[r] - rhat_s[r]) / sig_s[r];
                 de1[r] = it.e1[r] / it.w1[r] * (dy[r] + it.y[r] - rho + mu / it.e1[r]);
@@ -870,20 +876,18 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                     }
                     Qblk[(size_t)(v * (v + 1) / 2 + v) * M + k] += sg + (fidx[qq] >= 0 ? dw_shift : 0.0);
                 }
-            {
-                const int hi = std::max(P.px, P.py), lo = std::min(P.px, P.py);
-                double* qxx = &Qblk[(size_t)(P.px * (P.px + 1) / 2 + P.px) * M];
-                double* qyy = &Qblk[(size_t)(P.py * (P.py + 1) / 2 + P.py) * M];
-                double* qxy = &Qblk[(size_t)(hi * (hi + 1) / 2 + lo) * M];
-                for (int j = 0; j < np; ++j)
-                    for (int k = 0; k < M; ++k) {
-                        const double gx = V[(size_t)(ns * nv + 2 * j) * M + k], gy = V[(size_t)(ns * nv + 2 * j + 1) * M + k];
-                        const double sg = sig_t[j * M + k];
-                        qxx[k] += sg * gx * gx;
-                        qyy[k] += sg * gy * gy;
-                        qxy[k] += sg * gx * gy;
+            // eliminated path rows: sum_j sig_j (grad c_j)(grad c_j)^T on the variables each row depends on
+            for (int j = 0; j < np; ++j)
+                for (size_t a = 0; a < rv[j].size(); ++a)
+                    for (size_t b = 0; b <= a; ++b) {
+                        const int va = rv[j][a].first, vb = rv[j][b].first;
+                        const int hi = std::max(va, vb), lo = std::min(va, vb);
+                        double* q = &Qblk[(size_t)(hi * (hi + 1) / 2 + lo) * M];
+                        const double* ga = &V[(size_t)rv[j][a].second * M];
+                        const double* gb = &V[(size_t)rv[j][b].second * M];
+                        const double* sg = &sig_t[(size_t)j * M];
+                        for (int k = 0; k < M; ++k) q[k] += sg[k] * ga[k] * gb[k];
                     }
-            }
             Qexact = Qblk;
             dw = convexify_node_blocks(Qblk.data(), fixed_mask.data(), nv, M, &mods);
             const auto tf0 = now();

@@ -18,6 +18,7 @@
 #define ETOL_MI355X_EMI_NLP_HPP_
 
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace ETOL {
@@ -54,7 +55,10 @@ class KktBackend {
 
 struct NlpProblem {
     int ns = 0, nc = 0, np = 0, M = 0;
-    int px = 0, py = 1;                 // states the path rows depend on
+    int px = 0, py = 1;                 // states the path rows depend on when row_vars is empty (two partials per row)
+    // per path row: (variable index, VALS entry) of every partial; empty = every row has the pair (px, py) at
+    // entries ns*nv + 2j, + 2j + 1
+    std::vector<std::vector<std::pair<int, int>>> row_vars;
     std::vector<double> D;              // M*M differentiation matrix (row-major)
     std::vector<double> zl, zu;         // (ns+nc)*M variable bounds, index v*M+k; zl==zu fixes a variable
     std::vector<double> cl, cu;         // np path-row bounds (same at every node)

@@ -282,45 +282,51 @@ std::vector<int> Trace::dependencies(int out, int ns, int nc) {
 }
 
 std::string Trace::generate_model(const std::string& name, int ns, int nc, const std::vector<int>& f, int L,
-                                  const std::vector<int>& paths, int px, int py, std::string* err) {
+                                  const std::vector<int>& paths, std::vector<int>* path_vars, std::string* err) {
     const int nv = ns + nc;
+    (void)err;
     auto in_node = [&](int v) { return v < ns ? input(IN_STATE, v) : input(IN_CONTROL, v - ns); };
-    // path rows: first and second derivatives w.r.t. the two path states
+    // path rows: first derivatives w.r.t. the union of the variables the rows depend on, second derivatives of
+    // psi = sum_j mu_j c_j w.r.t. the same set
     const int npath = (int)paths.size();
-    std::vector<int> cx(npath, -1), cy(npath, -1);
-    int hxx = -1, hxy = -1, hyy = -1;
+    std::vector<int> pv;                           // union of dependencies, ascending
+    for (int j = 0; j < npath; ++j)
+        for (int v : dependencies(paths[j], ns, nc))
+            if (std::find(pv.begin(), pv.end(), v) == pv.end()) pv.push_back(v);
+    std::sort(pv.begin(), pv.end());
+    if (npath > 0 && pv.empty()) pv.push_back(0);  // rows of time only: one (zero) column keeps the layout regular
+    const int pw = (int)pv.size();
+    if (path_vars) *path_vars = pv;
+    std::vector<std::vector<int>> cd(npath, std::vector<int>(pw, -1));
+    std::vector<int> PH;                           // Hessian entries of psi (packed positions of the full triangle)
+    std::vector<std::string> PHt;
     if (npath > 0) {
         for (int j = 0; j < npath; ++j) {
-            for (int v : dependencies(paths[j], ns, nc))
-                if (v != px && v != py) {
-                    if (err) *err = "traced constraint row " + std::to_string(j) + " depends on variable " + std::to_string(v) +
-                                    "; rows may depend on the two path states (" + std::to_string(px) + ", " + std::to_string(py) +
-                                    ") and on time";
-                    return std::string();
-                }
             const std::vector<int> adj = adjoints(paths[j]);
-            const int nx = in_node(px), ny = in_node(py);
-            cx[j] = nx < (int)adj.size() ? adj[nx] : -1;
-            cy[j] = ny < (int)adj.size() ? adj[ny] : -1;
+            for (int q = 0; q < pw; ++q) {
+                const int n = in_node(pv[q]);
+                cd[j][q] = n < (int)adj.size() ? adj[n] : -1;
+            }
         }
-        // psi = sum_j mu_j c_j  (mu_j = coefficient input j), second derivatives w.r.t. (px, py)
         int psi = -1;
         for (int j = 0; j < npath; ++j) {
             const int term = binary(MUL, input(IN_COEF, j), paths[j]);
             psi = psi < 0 ? term : binary(ADD, psi, term);
         }
         const std::vector<int> a1 = adjoints(psi);
-        const int nx = in_node(px), ny = in_node(py);
-        const int gx = nx < (int)a1.size() ? a1[nx] : -1, gy = ny < (int)a1.size() ? a1[ny] : -1;
-        if (gx >= 0) {
-            const std::vector<int> a2 = adjoints(gx);
-            hxx = nx < (int)a2.size() ? a2[nx] : -1;
-            hxy = ny < (int)a2.size() ? a2[ny] : -1;
-        }
-        if (gy >= 0) {
-            const std::vector<int> a2 = adjoints(gy);
-            hyy = ny < (int)a2.size() ? a2[ny] : -1;
-            if (hxy < 0) hxy = nx < (int)a2.size() ? a2[nx] : -1;
+        for (int qa = 0; qa < pw; ++qa) {
+            const int na = in_node(pv[qa]);
+            const int ga = na < (int)a1.size() ? a1[na] : -1;
+            if (ga < 0) continue;
+            const std::vector<int> a2 = adjoints(ga);
+            for (int qb = 0; qb <= qa; ++qb) {
+                const int nb = in_node(pv[qb]);
+                const int h = nb < (int)a2.size() ? a2[nb] : -1;
+                double c;
+                if (h < 0 || (is_const(h, &c) && c == 0.0)) continue;
+                PH.push_back(h);
+                PHt.push_back("H[" + std::to_string(pv[qa] * (pv[qa] + 1) / 2 + pv[qb]) + "]");     // pv ascending: qa >= qb
+            }
         }
     }
     // first derivatives
@@ -368,7 +374,14 @@ std::string Trace::generate_model(const std::string& name, int ns, int nc, const
 
     std::ostringstream o;
     o << "template <typename T> struct " << name << " {\n";
-    o << "    static constexpr int NS = " << ns << ", NC = " << nc << ", NV = " << nv << ", NPARAM = 0, NPATH = " << npath << ";\n";
+    o << "    static constexpr int NS = " << ns << ", NC = " << nc << ", NV = " << nv << ", NPARAM = 0, NPATH = " << npath
+      << ", PW = " << pw << ";\n";
+    if (npath > 0) {
+        // pvar(q): the q-th node variable the traced rows depend on
+        o << "    EMI_DEV static constexpr int pvar(int q) { return ";
+        for (int q = 0; q + 1 < pw; ++q) o << "q == " << q << " ? " << pv[q] << " : ";
+        o << pv[pw - 1] << "; }\n";
+    }
     // f
     o << "    EMI_DEV static void f(const ModelParams<T>&, const T* z, T tk, T* fo) {\n";
     {
@@ -417,35 +430,29 @@ std::string Trace::generate_model(const std::string& name, int ns, int nc, const
     o << emit(H, Ht, true, "        ");
     o << "        (void)tk; (void)z; (void)cc;\n    }\n";
     if (npath > 0) {
-        // path rows: values and partials w.r.t. the two path states
-        o << "    EMI_DEV static void path(const ModelParams<T>&, const T* z, T tk, T* c, T* cx, T* cy) {\n";
-        o << "        for (int j = 0; j < NPATH; ++j) { cx[j] = T(0); cy[j] = T(0); }\n";
+        // path rows: values and partials w.r.t. the PW variables of pvar()
+        o << "    EMI_DEV static void path(const ModelParams<T>&, const T* z, T tk, T* c, T* cd) {\n";
+        o << "        for (int j = 0; j < NPATH * PW; ++j) cd[j] = T(0);\n";
         {
             std::vector<int> outs;
             std::vector<std::string> t;
             for (int j = 0; j < npath; ++j) {
                 outs.push_back(paths[j]);
                 t.push_back("c[" + std::to_string(j) + "]");
-                if (cx[j] >= 0) { outs.push_back(cx[j]); t.push_back("cx[" + std::to_string(j) + "]"); }
-                if (cy[j] >= 0) { outs.push_back(cy[j]); t.push_back("cy[" + std::to_string(j) + "]"); }
+                for (int q = 0; q < pw; ++q) {
+                    double cc;
+                    if (cd[j][q] < 0 || (is_const(cd[j][q], &cc) && cc == 0.0)) continue;
+                    outs.push_back(cd[j][q]);
+                    t.push_back("cd[" + std::to_string(j * pw + q) + "]");
+                }
             }
             o << emit(outs, t, false, "        ");
         }
         o << "        (void)tk; (void)z;\n    }\n";
-        o << "    EMI_DEV static void path_hess(const ModelParams<T>&, const T* z, T tk, const T* cc, T* h) {\n";
-        {
-            std::vector<int> outs;
-            std::vector<std::string> t;
-            const int hs[3] = {hxx, hxy, hyy};
-            for (int e = 0; e < 3; ++e) {
-                double c;
-                if (hs[e] < 0 || (is_const(hs[e], &c) && c == 0.0)) continue;
-                outs.push_back(hs[e]);
-                t.push_back("h[" + std::to_string(e) + "]");
-            }
-            o << emit(outs, t, true, "        ");
-        }
-        o << "        (void)tk; (void)z; (void)cc; (void)h;\n    }\n";
+        // adds sum_j cc[j] c_j,zz into the packed lower triangle H of the node block
+        o << "    EMI_DEV static void path_hess(const ModelParams<T>&, const T* z, T tk, const T* cc, T* H) {\n";
+        o << emit(PH, PHt, true, "        ");
+        o << "        (void)tk; (void)z; (void)cc; (void)H;\n    }\n";
     }
     o << "};\n";
     return o.str();

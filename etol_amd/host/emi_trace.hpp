@@ -42,10 +42,13 @@ class Trace {
 
     // C++ source of  `template <typename T> struct <name> {...}`  with the Model interface of
     // etol_amd/csrc/emi_models.hpp for dynamics f[0..ns), integrand cost L (already sign-free)
-    // `paths`: traced path rows c_j; they may depend on the two states px, py (and on time) only -- that is what
-    // the Jacobian layout of include/emi355x.h holds per row; generate_model fails (empty string, *err set) otherwise
+    // `paths`: traced path rows c_j; they may depend on any of the node's states and controls (and on time).  The
+    // struct gets PW = the number of distinct variables any row depends on, pvar(q) = the q-th of them (ascending),
+    // path(P, z, t, c, cd) with cd[j * PW + q] = d c_j / d z_pvar(q), and path_hess(P, z, t, mu, H) adding
+    // sum_j mu_j c_j,zz into the packed lower triangle H.  *path_vars receives the variable list.
     std::string generate_model(const std::string& name, int ns, int nc, const std::vector<int>& f, int L,
-                               const std::vector<int>& paths = {}, int px = 0, int py = 1, std::string* err = nullptr);
+                               const std::vector<int>& paths = {}, std::vector<int>* path_vars = nullptr,
+                               std::string* err = nullptr);
     // the state / control inputs node `out` depends on (indices v < ns: states, else controls)
     std::vector<int> dependencies(int out, int ns, int nc);
 

@@ -75,6 +75,7 @@ struct Prob {
     std::vector<size_t> row_order;                 // evaluation-order row q is row row_order[q] of the callbacks
     std::vector<double> traced_scale;              // normalisation of the traced rows inside the NLP iteration
     size_t npath_traced = 0;                       // of npath: rows traced from constraint callbacks (they follow the table rows)
+    std::vector<int> path_vars;                    // node variables the traced rows depend on (ascending; PW partials per traced row)
     int model = -1;
     std::vector<double> model_params;
     std::string model_source;                      // model == EMI_MODEL_SOURCE: struct generated from the traced callbacks

@@ -59,8 +59,9 @@
  *   VALS  [B][nvals][M], nvals = ns*(ns+nc) + 2*np + (ns+nc):
  *           entry i*(ns+nc)+v        : d defect_(i,k) / d z_(v,k)
  *                                      = -h df_i/dz_v + (v==i ? D_kk : 0)
- *           entry ns*(ns+nc)+2j+{0,1}: d c_j / d (px, py) at node k
- *           entry ns*(ns+nc)+2np+v   : d cost / d z_(v,k) = sgn h w_k dL/dz_v
+ *           entry ns*(ns+nc)+2j+{0,1}: d c_j / d (px, py) at node k   (rows of the record table, emi_set_path)
+ *           then PW entries per row traced from callbacks (emi_set_model_source)
+ *           last ns+nc entries        : d cost / d z_(v,k) = sgn h w_k dL/dz_v
  *   COST  [B]          sgn h sum_k w_k L(x_k,u_k)   (sgn=-1 when maximising,
  *                      ePSOPT.cpp:212-213)
  *   h = (tf - t0)/2,  z_(v,k): v<ns -> state v, else control v-ns.
@@ -74,7 +75,7 @@
 extern "C" {
 #endif
 
-#define EMI_ABI_VERSION 1
+#define EMI_ABI_VERSION 2
 
 typedef struct emi_ctx_s* emi_ctx_t;
 
@@ -116,7 +117,7 @@ enum {
 typedef struct {
     int model, ns, nc, np, M, B;
     int nres;    /* ns + np                        */
-    int nvals;   /* ns*(ns+nc) + 2*np + (ns+nc)    */
+    int nvals;   /* ns*(ns+nc) + 2*np_table + PW*np_traced + (ns+nc) */
     int nhess;   /* (ns+nc)*(ns+nc+1)/2            */
     int real_bytes; /* 8 (f64) or 4 (f32)          */
     int px, py;  /* state indices the keep-outs act on */
@@ -166,16 +167,20 @@ int emi_set_model(emi_ctx_t ctx, int model, const double* params, int nparams,
  * library's kernel templates; on a compile error the status is EMI_ERR_ARG and
  * emi_last_error() holds the compiler log.  params (<= 16) reach the struct as
  * ModelParams<T>.  npath = number of path rows the struct computes itself
- * (NPATH, with path() / path_hess(): constraint callbacks traced by the host);
- * they follow the rows of emi_set_path in RES / VALS and act on its px, py.
+ * (NPATH, PW, pvar(), path() / path_hess(): constraint callbacks traced by the
+ * host); they follow the rows of emi_set_path in RES.  A traced row may depend on
+ * any states and controls of its node: path_vars[n_path_vars] (ascending variable
+ * indices, states first) is the union over the rows, and VALS holds n_path_vars
+ * partials per traced row (entry ns*(ns+nc) + 2*np_table + j*n_path_vars + q =
+ * d c_j / d z_path_vars[q]) between the table rows' pairs and the cost gradient.
  * Replaces a previous emi_set_model / emi_set_model_source.                    */
 int emi_set_model_source(emi_ctx_t ctx, const char* struct_name, const char* source,
-                         int ns, int nc, int npath, const double* params,
-                         int nparams, int maximize);
+                         int ns, int nc, int npath, const int* path_vars, int n_path_vars,
+                         const double* params, int nparams, int maximize);
 /* Compile-only check of such a text (no device needed): EMI_OK or EMI_ERR_ARG
  * with up to log_len-1 characters of the compiler log in log (may be NULL).   */
 int emi_check_model_source(const char* struct_name, const char* source, int ns,
-                           int nc, int npath, int f32, char* log, size_t log_len);
+                           int nc, int npath, int n_path_vars, int f32, char* log, size_t log_len);
 int emi_set_batch(emi_ctx_t ctx, int B);
 /* recs: [nsets][np][EMI_PATH_REC]; nsets is 1 (shared) or B (per instance) */
 int emi_set_path(emi_ctx_t ctx, int np, int nsets, const double* recs,

@@ -268,9 +268,10 @@ mx::Var traced_quad_cost(const std::vector<mx::Var>& u) { return 1.0 * u[0] * u[
 namespace {
 int g_traced = 0;               // 1: callbacks compute with mx::Var handles (traced model) instead of naming a built-in
 double g_quad_tau_max = 1.0;   // torque bound of the quadrotor test problem (harness_set_quad_tau_max)
+double g_speed_limit = 0.0;    // > 0 (traced callbacks only): rows vx^2 + vz^2 <= v^2 and T sin(theta) <= 0.6 v^2, traced
 struct QuadSetup {
     std::vector<std::array<double, 3>> discs;
-    ETOL::f_t obj, obs;
+    ETOL::f_t obj, obs, spd;
     std::vector<ETOL::f_t> grad;
     std::vector<double> params{1.0, 0.01, 9.81, 1.0, 1.0};
 };
@@ -317,13 +318,28 @@ void configure_quadrotor(ETOL::TrajectoryOptimizer* t, QuadSetup& q, int nsteps,
         q.obs = [discs](F_ARGS) -> ETOL::scalar_t {
             return mx::disc_rows(discs, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
         };
-        t->setConstraints({&q.obs});
     }
+    std::vector<ETOL::f_t*> cons;
+    if (ndiscs > 0) cons.push_back(&q.obs);
+    if (traced && g_speed_limit > 0) {
+        // rows on other variables than the keep-outs' positions, a control among them (traced, PW = 4: 2 3 4 6)
+        const double v2 = g_speed_limit * g_speed_limit;
+        t->addParams({std::pair<PARAM_PAIR>("speed_0", {ETOL::var_t::CONTINUOUS, -1000., 0., 0., nsteps * dt})});
+        t->addParams({std::pair<PARAM_PAIR>("tilt_0", {ETOL::var_t::CONTINUOUS, -1000., 0., 0., nsteps * dt})});
+        q.spd = [v2](F_ARGS) -> ETOL::scalar_t {
+            const mx::Var th = std::any_cast<mx::Var>(x.at(2)), vx = std::any_cast<mx::Var>(x.at(3)), vz = std::any_cast<mx::Var>(x.at(4));
+            const mx::Var T = std::any_cast<mx::Var>(u.at(0));
+            return ETOL::fout_mi355x_vars_t{vx * vx + vz * vz - v2, T * mx::sin(th) - 0.6 * v2};
+        };
+        cons.push_back(&q.spd);
+    }
+    if (!cons.empty()) t->setConstraints(cons);
 }
 }  // namespace
 
 extern "C" void harness_set_quad_tau_max(double v) { g_quad_tau_max = v; }
 extern "C" void harness_set_traced(int on) { g_traced = on; }
+extern "C" void harness_set_speed_limit(double v) { g_speed_limit = v; }
 int g_refine = -1;              // harness_solve_example1: -1 = the setup() default ("automatic"), 0 = "none", 1 = "automatic"
 extern "C" void harness_set_refine(int mode) { g_refine = mode; }
 extern "C" void harness_set_linear_solver(const char* name) { g_linear_solver = name; }
@@ -600,17 +616,24 @@ extern "C" const char* harness_traced_model_source(int which) {
             rows.push_back((k.r * k.r - (ox * ox + oy * oy)).node);
         }
         std::string err;
-        g_out = tr.generate_model("TracedModel", 2, 2, {u[0].node, u[1].node}, (u[0] * u[0] + u[1] * u[1]).node, rows, 0, 1, &err);
+        g_out = tr.generate_model("TracedModel", 2, 2, {u[0].node, u[1].node}, (u[0] * u[0] + u[1] * u[1]).node, rows, nullptr, &err);
         if (g_out.empty()) g_out = "ERROR: " + err;
     } else if (which == 3) {
-        // a row that uses a third variable: must be refused with a message
+        // rows on more than two variables, controls included: a disc keep-out on (x, z), a speed limit on (vx, vz),
+        // a thrust-tilt coupling on (theta, thrust) and a row of time and one state.  PW = 6: variables 0 1 2 3 4 6
         std::vector<mx::Var> x, u;
         for (size_t i = 0; i < 6; ++i) x.push_back(mx::Var(mx::Var::STATE, i));
         for (size_t j = 0; j < 2; ++j) u.push_back(mx::Var(mx::Var::CONTROL, j));
+        const mx::Var tk(mx::Var::TIME, 0);
         std::vector<int> f;
         for (int i = 0; i < 6; ++i) f.push_back(traced_quad_rhs(x, u, i).node);
+        std::vector<int> rows;
+        rows.push_back((0.64 - ((x[0] - 4.0) * (x[0] - 4.0) + (x[1] - 3.2) * (x[1] - 3.2))).node);
+        rows.push_back((x[3] * x[3] + x[4] * x[4] - 9.0).node);
+        rows.push_back((u[0] * mx::sin(x[2]) - 6.0).node);
+        rows.push_back((x[1] * mx::cos(0.3 * tk) - 9.5).node);
         std::string err;
-        g_out = tr.generate_model("TracedModel", 6, 2, f, traced_quad_cost(u).node, {(x[0] * x[1] + x[2]).node}, 0, 1, &err);
+        g_out = tr.generate_model("TracedModel", 6, 2, f, traced_quad_cost(u).node, rows, nullptr, &err);
         if (g_out.empty()) g_out = "ERROR: " + err;
     } else if (which == 2) {
         // quadrotor + path rows written as arithmetic: a disc (etol_psopt_example1.cpp:243-247) and the ellipse of the
@@ -634,7 +657,7 @@ extern "C" const char* harness_traced_model_source(int which) {
             rows.push_back((rec[5] * rec[6] - (rec[6] * mx::pow(delx, 2.) + rec[5] * mx::pow(dely, 2.))).node);
         }
         std::string err;
-        g_out = tr.generate_model("TracedModel", 6, 2, f, traced_quad_cost(u).node, rows, 0, 1, &err);
+        g_out = tr.generate_model("TracedModel", 6, 2, f, traced_quad_cost(u).node, rows, nullptr, &err);
         if (g_out.empty()) g_out = "ERROR: " + err;
     } else {
         mx::Var a(mx::Var::STATE, 0), b(mx::Var::STATE, 1), c(mx::Var::CONTROL, 0), t(mx::Var::TIME, 0);

@@ -22,7 +22,7 @@ def test_every_declared_symbol_is_exported(built):
     lib = L.load()
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.emi_abi_version() == 1
+    assert lib.emi_abi_version() == 2
     assert lib.emi_status_string(0) == b"ok"
     assert b"argument" in lib.emi_status_string(1)
 

@@ -561,3 +561,36 @@ def test_every_mfma_defect_kernel_variant_matches_the_oracle(built, sym_ct, shap
             again = ev.eval_host(X, U)
             assert np.array_equal(again[0], got2[0])          # fixed summation order: bitwise reproducible
     ev.close()
+
+
+def test_very_large_batches_are_evaluated_in_slices_with_the_same_results(built):
+    """emi_eval_dev cuts batches above 2048 instances into slices of 1024 (per-instance keep-out tables, cost partials
+    and outputs offset per slice); with per-kernel profiling on it evaluates the batch in one piece: same results."""
+    import torch
+    import etol_amd as E
+    M, B = 128, 2100
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 5.0)
+    ev.set_model(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS)
+    ev.set_batch(B)
+    X, U, recs = cases.W.quadrotor_batch(31, 60, M, 2)
+    reps = (B + 59) // 60
+    X, U, recs = np.tile(X, (reps, 1, 1))[:B], np.tile(U, (reps, 1, 1))[:B], np.tile(recs, (reps, 1, 1))[:B]
+    X = X + 1e-3 * np.arange(B)[:, None, None]               # every instance different
+    ev.set_path(recs, 0, 1)
+    dX, dU = torch.from_numpy(X).cuda(), torch.from_numpy(U).cuda()
+    a, b = ev.alloc_outputs(), ev.alloc_outputs()
+    ev.eval_dev(dX, dU, *a)                                   # sliced
+    ev.profile(1)
+    ev.eval_dev(dX, dU, *b)                                   # one piece
+    ev.profile_read()
+    ev.profile(0)
+    torch.cuda.synchronize()
+    # same values; not always the same bits: the defect kernel variant is chosen from the batch size of the piece it
+    # works on, and the split-K variants add the K slices in another (fixed) order
+    for p, q in zip(a, b):
+        assert (p - q).abs().max().item() <= 1e-12 * q.abs().max().item()
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])      # node kernel outputs: identical
+    ref = O.evaluate(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, 5.0, X[2090:2094], U[2090:2094], recs[2090:2094])
+    assert np.abs(a[2][2090:2094].cpu().numpy() - ref[2]).max() / np.abs(ref[2]).max() < 1e-13
+    ev.close()

@@ -293,6 +293,36 @@ def test_traced_callbacks_solve_like_the_builtin_models(H, xmls):
     assert np.abs(RES[0, :6]).max() < 1e-7 and RES[0, 6:].max() < 1e-7 and abs(COST[0] - trr[0]) < 1e-8
 
 
+def test_solve_with_traced_rows_on_velocities_and_a_control(H):
+    """A speed limit (vx^2 + vz^2 <= v^2) and a thrust-tilt coupling (T sin(theta) <= 0.6 v^2) written with the handles
+    in a constraint callback, next to the two disc keep-outs of the record table: rows on four variables that are not
+    the keep-outs' positions, one of them a control.  The solve must respect them (they are active) and cost more than
+    the same problem without them."""
+    H.harness_set_traced.argtypes = [C.c_int]
+    H.harness_set_speed_limit.argtypes = [C.c_double]
+    H.harness_set_traced(1)
+    try:
+        free = _solve_quadrotor(H, 40, 0.1, 2, refine=0)
+        vmax_free = np.sqrt(free[1][3] ** 2 + free[1][4] ** 2).max()
+        H.harness_set_speed_limit(0.8 * vmax_free)
+        lim = _solve_quadrotor(H, 40, 0.1, 2, refine=0)
+    finally:
+        H.harness_set_speed_limit(0.0)
+        H.harness_set_traced(0)
+    X, U = lim[1], lim[2]
+    v2 = (0.8 * vmax_free) ** 2
+    speed = X[3] ** 2 + X[4] ** 2 - v2
+    tilt = U[0] * np.sin(X[2]) - 0.6 * v2
+    print(f"speed-limited solve: cost {lim[0]:.6f} (free {free[0]:.6f}), max speed row {speed.max():.2e}, max tilt row {tilt.max():.2e}")
+    assert speed.max() < 1e-6 and tilt.max() < 1e-6            # feasible at every node
+    assert speed.max() > -1e-4                                   # and the limit binds
+    assert lim[0] > free[0] * (1 + 1e-4)
+    m = X.shape[1]
+    RES, _, COST = O.evaluate(1, [1.0, 0.01, 9.81, 1.0, 1.0], m, O.lgl(m), 0.0, 4.0, X[None], U[None],
+                              np.array([[1, 4.0, 3.2, 0.64, 0, 0, 0, 0], [1, 6.3, 4.4, 0.49, 0, 0, 0, 0]], dtype=float))
+    assert np.abs(RES[0, :6]).max() < 1e-7 and RES[0, 6:].max() < 1e-7 and abs(COST[0] - lim[0]) < 1e-7 * lim[0]
+
+
 def _set_linear_solver(H, name):
     H.harness_set_linear_solver.argtypes = [C.c_char_p]
     H.harness_last_linear_solver.restype = C.c_char_p

@@ -210,7 +210,7 @@ def test_traced_path_rows_match_the_table_rows(built):
     for front in ([], [extra]):
         tr = E.Evaluator(0)
         tr.set_mesh(M, 0.0, W.TF)
-        tr.set_model_source("TracedModel", src, 6, 2, npath=2)
+        tr.set_model_source("TracedModel", src, 6, 2, npath=2, path_vars=(0, 1))
         tr.set_batch(B)
         tr.set_path(np.array(front).reshape(len(front), L.PATH_REC), 0, 1)
         bi = E.Evaluator(0)
@@ -252,7 +252,7 @@ def test_traced_moving_disc_rows_match_the_track_table(built):
         X, U = W.pointmass_batch(3, B, M)
         tr = E.Evaluator(0)
         tr.set_mesh(M, 0.0, 16.0)
-        tr.set_model_source("TracedModel", src, 2, 2, npath=3)
+        tr.set_model_source("TracedModel", src, 2, 2, npath=3, path_vars=(0, 1))
         tr.set_batch(B)
         tr.set_path(np.zeros((0, L.PATH_REC)), 0, 1)
         bi = E.Evaluator(0)
@@ -273,3 +273,69 @@ def test_traced_moving_disc_rows_match_the_track_table(built):
         lamF = np.random.default_rng(1).standard_normal((B, 2, M))
         lamC = np.random.default_rng(2).standard_normal((B, 3, M))
         assert np.abs(tr.hess_host(X, U, lamF, lamC, 0.6) - bi.hess_host(X, U, lamF, lamC, 0.6)).max() < 1e-13
+
+
+def test_traced_rows_on_more_than_two_variables_on_the_device(built):
+    """Rows traced from callbacks may depend on any states and controls of their node: a disc on (x, z), a speed limit
+    on (vx, vz), a thrust-tilt coupling on (theta, thrust), a row of time and one state, behind one table row.  VALS
+    holds PW = 6 partials per traced row (variables 0 1 2 3 4 6): values, partials, Hessian blocks and the structure
+    query against numpy."""
+    import etol_amd as E
+    from etol_amd import _lib as L
+    from etol_amd import workloads as W
+    src = traced_source(3)
+    assert "NPATH = 4, PW = 6" in src
+    pv = [0, 1, 2, 3, 4, 6]
+    M, B = 64, 3
+    X, U, _ = W.quadrotor_batch(5, B, M, 0)
+    extra = np.zeros(L.PATH_REC); extra[:4] = [L.PATH_DISC, 6.3, 4.4, 0.49]
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 8.0)
+    ev.set_model_source("TracedModel", src, 6, 2, npath=4, path_vars=pv)
+    ev.set_batch(B)
+    ev.set_path(extra[None], 0, 1)
+    lay = ev.layout
+    assert lay.np == 5 and lay.nvals == 6 * 8 + 2 * 1 + 6 * 4 + 8
+    RES, VALS, COST = ev.eval_host(X, U)
+    t = ev.node_t
+    Z = np.concatenate([X, U], axis=1)
+    rows = [0.64 - ((Z[:, 0] - 4.0) ** 2 + (Z[:, 1] - 3.2) ** 2), Z[:, 3] ** 2 + Z[:, 4] ** 2 - 9.0,
+            Z[:, 6] * np.sin(Z[:, 2]) - 6.0, Z[:, 1] * np.cos(0.3 * t) - 9.5]
+    for j, r in enumerate(rows):
+        assert np.abs(RES[:, 6 + 1 + j] - r).max() < 1e-13 * (np.abs(r).max() + 1)
+    grads = {(0, 0): -2 * (Z[:, 0] - 4.0), (0, 1): -2 * (Z[:, 1] - 3.2), (1, 3): 2 * Z[:, 3], (1, 4): 2 * Z[:, 4],
+             (2, 2): Z[:, 6] * np.cos(Z[:, 2]), (2, 6): np.sin(Z[:, 2]), (3, 1): np.cos(0.3 * t) * np.ones_like(Z[:, 1])}
+    base = 48 + 2
+    for j in range(4):
+        for q, v in enumerate(pv):
+            ref = grads.get((j, v), np.zeros_like(Z[:, 0]))
+            assert np.abs(VALS[:, base + j * 6 + q] - ref).max() < 1e-13 * (np.abs(ref).max() + 1), (j, v)
+    # cost gradient sits behind the traced partials; the table row keeps its pair in front of them
+    q8 = ev.eval_host(X, U)[1]
+    assert np.array_equal(q8, VALS)
+    bi = E.Evaluator(0)
+    bi.set_mesh(M, 0.0, 8.0)
+    bi.set_model(E.MODEL_QUADROTOR2D, W.QUAD_PARAMS)
+    bi.set_batch(B)
+    bi.set_path(extra[None], 0, 1)
+    Rb, Vb, Cb = bi.eval_host(X, U)
+    assert np.abs(VALS[:, :50] - Vb[:, :50]).max() < 1e-12 and np.abs(VALS[:, 74:] - Vb[:, 50:]).max() < 1e-12
+    assert np.abs(COST - Cb).max() < 1e-12 * np.abs(Cb).max()
+    # structure query: traced entries name their own columns
+    r, c = ev.jac_structure()
+    for j in range(4):
+        for q, v in enumerate(pv):
+            e = (base + j * 6 + q) * M
+            assert c[e] == v * M and r[e] == 6 * M + 12 + (1 + j) * M
+    # Hessian blocks: multiplier-weighted second derivatives of the traced rows land in the packed triangle
+    rng = np.random.default_rng(8)
+    lamF = np.zeros((B, 6, M))
+    lamC = rng.standard_normal((B, 5, M))
+    lamC[:, 0] = 0.0
+    H = ev.hess_host(X, U, lamF, lamC, 0.0)
+    pk = lambda a, b: a * (a + 1) // 2 + b
+    ref = {pk(0, 0): -2 * lamC[:, 1], pk(1, 1): -2 * lamC[:, 1], pk(3, 3): 2 * lamC[:, 2], pk(4, 4): 2 * lamC[:, 2],
+           pk(2, 2): -lamC[:, 3] * Z[:, 6] * np.sin(Z[:, 2]), pk(6, 2): lamC[:, 3] * np.cos(Z[:, 2])}
+    for e in range(36):
+        want = ref.get(e, np.zeros((B, M)))
+        assert np.abs(H[:, e] - want).max() < 1e-12 * (np.abs(want).max() + 1), e

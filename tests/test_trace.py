@@ -108,17 +108,17 @@ def test_traced_every_operation_against_sympy(built, tmp_path):
         assert abs(L - ev(Lc)) < 1e-13 * (abs(ev(Lc)) + 1)
 
 
-def _check_source(src, ns, nc, f32=0, name="TracedModel", npath=0):
+def _check_source(src, ns, nc, f32=0, name="TracedModel", npath=0, pw=2):
     import torch  # noqa: F401
     from etol_amd import _lib
     lib = _lib.load()
     log = C.create_string_buffer(1 << 16)
-    st = lib.emi_check_model_source(name.encode(), src.encode(), ns, nc, npath, f32, log, len(log))
+    st = lib.emi_check_model_source(name.encode(), src.encode(), ns, nc, npath, pw, f32, log, len(log))
     return st, log.value.decode(errors="replace")
 
 
-@pytest.mark.parametrize("which,ns,nc,npath", [(0, 6, 2, 0), (1, 2, 1, 0), (2, 6, 2, 2)])
-def test_generated_model_compiles_against_the_kernel_templates(built, which, ns, nc, npath):
+@pytest.mark.parametrize("which,ns,nc,npath,pw", [(0, 6, 2, 0, 0), (1, 2, 1, 0, 0), (2, 6, 2, 2, 2), (3, 6, 2, 4, 6)])
+def test_generated_model_compiles_against_the_kernel_templates(built, which, ns, nc, npath, pw):
     """hiprtc cross-compiles for gfx950 without a GPU: the generated struct must instantiate the node,
     Hessian and even/odd MFMA defect kernels the library itself is built from."""
     import torch  # noqa: F401
@@ -126,11 +126,13 @@ def test_generated_model_compiles_against_the_kernel_templates(built, which, ns,
     lib.harness_traced_model_source.restype = C.c_char_p
     src = lib.harness_traced_model_source(which).decode()
     for f32 in (0, 1):
-        st, log = _check_source(src, ns, nc, f32, npath=npath)
+        st, log = _check_source(src, ns, nc, f32, npath=npath, pw=pw)
         assert st == 0, log
-    if npath:       # the number of traced rows is part of the contract
-        st, log = _check_source(src, ns, nc, 0, npath=npath + 1)
+    if npath:       # the number of traced rows and of the variables they depend on are part of the contract
+        st, log = _check_source(src, ns, nc, 0, npath=npath + 1, pw=pw)
         assert st == 1 and "dimensions differ" in log
+        st, log = _check_source(src, ns, nc, 0, npath=npath, pw=pw + 1)
+        assert st == 1 and "another number of variables" in log
 
 
 def test_model_source_errors_are_reported(built):
@@ -148,11 +150,21 @@ def test_model_source_errors_are_reported(built):
 
 PATH_POSTLUDE = r"""
 typedef TracedModel<double> TM;
-extern "C" void traced_path(const double* z, double t, const double* mu, double* c, double* cx, double* cy, double* h) {
+extern "C" int traced_pw(void) { return TM::PW; }
+extern "C" int traced_pvar(int q) { return TM::pvar(q); }
+// cd[NPATH][PW], H[NV (NV + 1) / 2] (packed lower triangle, accumulated into zeros)
+extern "C" void traced_path_full(const double* z, double t, const double* mu, double* c, double* cd, double* H) {
     ModelParams<double> P = {};
-    TM::path(P, z, t, c, cx, cy);
-    h[0] = h[1] = h[2] = 0;
-    TM::path_hess(P, z, t, mu, h);
+    TM::path(P, z, t, c, cd);
+    for (int q = 0; q < TM::NV * (TM::NV + 1) / 2; ++q) H[q] = 0;
+    TM::path_hess(P, z, t, mu, H);
+}
+// rows on the first two variables: cx, cy and the three second derivatives (xx, xy, yy)
+extern "C" void traced_path(const double* z, double t, const double* mu, double* c, double* cx, double* cy, double* h) {
+    double cd[TM::NPATH * TM::PW], H[TM::NV * (TM::NV + 1) / 2];
+    traced_path_full(z, t, mu, c, cd, H);
+    for (int j = 0; j < TM::NPATH; ++j) { cx[j] = cd[j * TM::PW]; cy[j] = cd[j * TM::PW + 1]; }
+    h[0] = H[0]; h[1] = H[1]; h[2] = H[2];
 }
 """
 
@@ -209,12 +221,52 @@ def test_traced_path_rows_against_the_reference_formulas(built, tmp_path):
         assert abs(h[0] - mu @ (cx2 - cx)) < 1e-12 and abs(h[1] - mu @ (cy2 - cy)) < 1e-12 and abs(h[2] - mu @ (cy3 - cy)) < 1e-12
 
 
-def test_traced_rows_may_only_depend_on_two_states(built):
+def test_traced_rows_on_more_than_two_variables(built, tmp_path):
+    """Traced rows may depend on any states and controls of their node (and on time): a disc keep-out on (x, z), a
+    speed limit on (vx, vz), a thrust-tilt coupling on (theta, thrust), a row of time and one state.  The generated
+    struct lists the union of the variables (PW = 6: 0 1 2 3 4 6); values, every partial and the multiplier-weighted
+    second derivatives against numpy / finite differences."""
     import torch  # noqa: F401
     lib = C.CDLL(os.path.join(HERE, "harness", "libetol_harness.so"))
     lib.harness_traced_model_source.restype = C.c_char_p
-    msg = lib.harness_traced_model_source(3).decode()
-    assert msg.startswith("ERROR") and "depends on variable" in msg
+    src = lib.harness_traced_model_source(3).decode()
+    assert "NPATH = 4, PW = 6" in src and not src.startswith("ERROR"), src[:300]
+    cpp = tmp_path / "path3.cpp"
+    cpp.write_text(PRELUDE + src + PATH_POSTLUDE)
+    so = tmp_path / "path3.so"
+    subprocess.check_call(["g++", "-O1", "-shared", "-fPIC", "-o", str(so), str(cpp)])
+    t = C.CDLL(str(so))
+    dp = C.POINTER(C.c_double)
+    t.traced_path_full.argtypes = [dp, C.c_double, dp, dp, dp, dp]
+    p = lambda a: a.ctypes.data_as(dp)
+    pv = [t.traced_pvar(q) for q in range(t.traced_pw())]
+    assert pv == [0, 1, 2, 3, 4, 6]
+
+    def rows(z, tk):
+        return np.array([0.64 - ((z[0] - 4.0) ** 2 + (z[1] - 3.2) ** 2), z[3] ** 2 + z[4] ** 2 - 9.0,
+                         z[6] * np.sin(z[2]) - 6.0, z[1] * np.cos(0.3 * tk) - 9.5])
+
+    rng = np.random.default_rng(4)
+    for _ in range(4):
+        z, mu, tk = rng.uniform(-2, 6, 8), rng.standard_normal(4), 1.7
+        c, cd, H = np.zeros(4), np.zeros(4 * 6), np.zeros(36)
+        t.traced_path_full(p(z), tk, p(mu), p(c), p(cd), p(H))
+        assert np.abs(c - rows(z, tk)).max() < 1e-14 * (np.abs(c).max() + 1)
+        cd = cd.reshape(4, 6)
+        e = 1e-6
+        for q, v in enumerate(pv):
+            zp, zm = z.copy(), z.copy()
+            zp[v] += e; zm[v] -= e
+            assert np.abs(cd[:, q] - (rows(zp, tk) - rows(zm, tk)) / (2 * e)).max() < 1e-8
+        # weighted second derivatives, packed lower triangle of the 8 x 8 node block
+        Href = np.zeros((8, 8))
+        Href[0, 0] = Href[1, 1] = -2 * mu[0]
+        Href[3, 3] = Href[4, 4] = 2 * mu[1]
+        Href[2, 2] = -mu[2] * z[6] * np.sin(z[2])
+        Href[6, 2] = Href[2, 6] = mu[2] * np.cos(z[2])
+        for a in range(8):
+            for b in range(a + 1):
+                assert abs(H[a * (a + 1) // 2 + b] - Href[a, b]) < 1e-12, (a, b)
 
 
 def test_traced_interp1_rows_against_numpy(built, tmp_path):
