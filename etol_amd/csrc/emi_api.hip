@@ -79,6 +79,7 @@ struct emi_ctx_s {
     DevBuf d_cost_part;
     DevBuf d_slab;              // partial sums of a split-K defect launch
     DevBuf d_ticket;            // [B] arrival counters of the in-kernel COST finish (zeroed once, self-resetting)
+    int sym_nst = 3;            // "sym_nst": ring stages of the one-launch pass (3 or 4)
     int slice_first = 0;        // first instance of the slice emi_eval_dev is working on (per-instance tables are offset by it)
     int sym_ksplit = 0;         // "sym_ksplit" option: K slices of an SW = NS launch (0: by batch size)
     // host-form staging
@@ -688,6 +689,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
                 plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 <= 96 ? 7 : 6, 1);        // SW = 1 / 2
             else if (plan.ring1) plan = emi::plan_symdefect(c->ns, c->B, c->M, 5, 1);
             plan.ks = 1;
+            plan.nst = c->sym_nst;
             if (emi::pass_supported(c->model, c->ns, c->B, c->M, plan)) {
                 if (c->d_ticket.bytes < (size_t)c->B * 4) {
                     int est = ensure(c, c->d_ticket, (size_t)c->B * 4);
@@ -1018,6 +1020,11 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
     }
     if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }
     if (strcmp(name, "sym_ablate") == 0) { c->sym_ablate = value; return EMI_OK; }   // diagnostics only
+    if (strcmp(name, "sym_nst") == 0) {
+        if (value != 3 && value != 4) return fail(c, EMI_ERR_ARG, "sym_nst must be 3 or 4");
+        c->sym_nst = value;
+        return EMI_OK;
+    }
     if (strcmp(name, "sym_ksplit") == 0) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, EMI_ERR_ARG, "sym_ksplit must be 0 (by batch size), 1, 2, 4 or 8");
         c->sym_ksplit = value;

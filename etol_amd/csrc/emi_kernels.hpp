@@ -34,6 +34,7 @@ struct SymPlan {
     bool ring1 = false;       // the one-workgroup-per-CU ring kernel / register-staged forms (sym_ct 1..3)
     int sw = 0;               // state-split ring: states per workgroup
     int ks = 1;               // ... and K slices per tile (> 1: partial sums through a slab + combine launch)
+    int nst = 3;              // ring stages of the one-launch pass (3 or 4: K tiles in flight = nst - 1)
     size_t slab_bytes = 0;
 };
 SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt);

@@ -136,7 +136,7 @@ static hipError_t launch_ring2_planned(const SymDefectArgs& a, hipStream_t s, co
 
 // ---------------------------------------------------------------------------------------------
 // the pass as one launch (emi_pass_f64_kernel): MFMA-role and node-role workgroups interleaved per XCD
-template <class Model, int SW>
+template <class Model, int SW, int NST>
 static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<double>& na, hipStream_t s) {
     constexpr int NS = Model::NS;
     PassArgs a;
@@ -149,10 +149,10 @@ static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<doub
     if (nm % 8 || nn % 8) return hipErrorInvalidConfiguration;
     a.nm8 = nm / 8;
     a.nn8 = nn / 8;
-    const size_t lds = (size_t)3 * ((2 * SW * FUSED_TI + 2 * 64 + 63) / 64 * 64) * 8 * sizeof(double);
+    const size_t lds = (size_t)NST * ((2 * SW * FUSED_TI + 2 * 64 + 63) / 64 * 64) * 8 * sizeof(double);
     static bool attr_done[2] = {false, false};
     const int st = na.store_mode == 2 ? 1 : 0;
-    auto kern = st ? emi_pass_f64_kernel<Model, SW, 2, 2> : emi_pass_f64_kernel<Model, SW, 2, 0>;
+    auto kern = st ? emi_pass_f64_kernel<Model, SW, 2, 2, NST> : emi_pass_f64_kernel<Model, SW, 2, 0, NST>;
     if (!attr_done[st]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -165,14 +165,14 @@ static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<doub
 template <class Model>
 static hipError_t launch_pass_planned(const SymDefectArgs& sa, const NodeArgs<double>& na, hipStream_t s, const SymPlan& p) {
     constexpr int NS = Model::NS;
-    if (p.sw == NS) return launch_pass_model<Model, NS>(sa, na, s);
+    if (p.sw == NS) return launch_pass_model<Model, NS, 3>(sa, na, s);
     if constexpr (NS > 2 && NS % 2 == 0) {
-        if (p.sw == 2) return launch_pass_model<Model, 2>(sa, na, s);
+        if (p.sw == 2) return p.nst > 3 ? launch_pass_model<Model, 2, 4>(sa, na, s) : launch_pass_model<Model, 2, 3>(sa, na, s);
     }
     if constexpr (NS > 3 && NS % 3 == 0) {
-        if (p.sw == 3) return launch_pass_model<Model, 3>(sa, na, s);
+        if (p.sw == 3) return launch_pass_model<Model, 3, 3>(sa, na, s);
     }
-    return launch_pass_model<Model, 1>(sa, na, s);
+    return p.nst > 3 ? launch_pass_model<Model, 1, 4>(sa, na, s) : launch_pass_model<Model, 1, 3>(sa, na, s);
 }
 
 // true if the pass can go out as one launch with this plan (state-split ring role, no K slices, whole XCD shares)

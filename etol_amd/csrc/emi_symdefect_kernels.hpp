@@ -394,10 +394,11 @@ EMI_DEV void ring_epilogue(const SymDefectArgs& a, const d4 (&acc_a)[SW], const 
 // a.ksplit > 1: the K range of a tile is cut into ksplit slices, one workgroup each (a shard of config 4 has 64
 // tiles for 256 CUs); a slice leaves its partial sums in a.slab[tile][slice][2 SW][4][256 threads] and
 // emi_symdefect_combine_kernel adds the slices IN SLICE ORDER (bitwise reproducible) and runs the epilogue.
-template <class Model, int SW>
+template <class Model, int SW, int NST = 3>
 EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-slice id, XCD-local runs */) {
     constexpr int NS = Model::NS;
-    constexpr int TI = FUSED_TI, TM = SW * TI, TN = 64, NST = 3, BK = 8, CH = 4, NSG = NS / SW;
+    constexpr int TI = FUSED_TI, TM = SW * TI, TN = 64, BK = 8, CH = 4, NSG = NS / SW;
+    constexpr int LOOK = NST - 1;                        // K tiles in flight ahead of the one being multiplied
     constexpr int ROWS = 2 * TM + 2 * TN;
     constexpr int ROWS_PAD = (ROWS + 63) / 64 * 64;      // a DMA wave instruction moves 16 rows: 4 waves x 16 rows
     constexpr int STAGE = ROWS_PAD * BK;                 // doubles per ring stage
@@ -463,8 +464,9 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     }
 
     const int nkt = (Hh / BK) / KS, kt0 = kslice * nkt;       // this slice's K tiles: kt0 .. kt0 + nkt - 1
-    issue(0, kt0);
-    if (nkt > 1) issue(1, kt0 + 1);
+#pragma unroll
+    for (int t = 0; t < LOOK; ++t)
+        if (t < nkt) issue(t, kt0 + t);
     // fragment addresses (doubles within a stage): B rows of this wave, A rows of every state
     const int rb = wid * 16 + r16;
     const int off_b = rb * BK + ((kq ^ ring_swz(rb)) << 1);
@@ -476,11 +478,11 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         off_m[s] = (TM + r) * BK + (((3 - kq) ^ ring_swz(r)) << 1);  // chunk 3-kq of the mirrored tile
     }
     for (int kt = 0; kt < nkt; ++kt) {
-        // tile kt has landed once all but this wave's L youngest DMA instructions are done
-        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        else              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");     // every wave's part landed; stage (kt-1)%3 is free
-        if (kt + 2 < nkt && !(a.ablate & 2)) issue((kt + 2) % NST, kt0 + kt + 2);
+        // tile kt has landed once all but the DMA instructions of the (up to LOOK - 1) younger tiles are done
+        if (kt + LOOK - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
+        else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tail: at most LOOK - 1 tiles early
+        asm volatile("s_barrier" ::: "memory");     // every wave's part landed; stage (kt-1) % NST is free
+        if (kt + LOOK < nkt && !(a.ablate & 2)) issue((kt + LOOK) % NST, kt0 + kt + LOOK);
         if (a.ablate & 1) continue;
         const double* S = smem + (size_t)(kt % NST) * STAGE;
         const double2 be = *reinterpret_cast<const double2*>(S + 2 * TM * BK + off_b);
@@ -575,12 +577,12 @@ struct PassArgs {
     int nbx;                // node chunks per instance
 };
 
-template <class Model, int SW, int VEC, int ST>
+template <class Model, int SW, int VEC, int ST, int NST = 3>
 __global__ __launch_bounds__(256, 2) void emi_pass_f64_kernel(PassArgs a) {
     const int g = blockIdx.x, xcd = g & 7, j = g >> 3, t8 = a.nm8 + a.nn8;
     const int m0 = (int)(((long long)j * a.nm8) / t8), m1 = (int)(((long long)(j + 1) * a.nm8) / t8);
     if (m1 > m0) {
-        emi_ring2_body<Model, SW>(a.s, xcd * a.nm8 + m0);
+        emi_ring2_body<Model, SW, NST>(a.s, xcd * a.nm8 + m0);
     } else {
         const int nid = xcd * a.nn8 + (j - m0);
         emi_nodes_body<double, Model, VEC, true, false, ST>(a.n, nid % a.nbx, nid / a.nbx, a.nbx);

@@ -41,6 +41,10 @@ VARIANTS = {
     "one_launch_sw2": dict(sym_ct=6, overlap_mode=3, node_store=-1),
     "one_launch_sw1": dict(sym_ct=7, overlap_mode=3, node_store=-1),
     "one_launch_sw2_plain": dict(sym_ct=6, overlap_mode=3, node_store=0),
+    "one_launch_sw1_nt": dict(sym_ct=7, overlap_mode=3, node_store=2),
+    "one_launch_sw1_nst4": dict(sym_ct=7, overlap_mode=3, node_store=-1, sym_nst=4),
+    "one_launch_sw2_nst4": dict(sym_ct=6, overlap_mode=3, node_store=-1, sym_nst=4),
+    "one_launch_sw1_nst4_nt": dict(sym_ct=7, overlap_mode=3, node_store=2, sym_nst=4),
     "ring2_sw2_conc_plain": dict(sym_ct=6, overlap_mode=2, node_store=0),
     "ring2_sw1_conc_plain": dict(sym_ct=7, overlap_mode=2, node_store=0),
     "ring2_auto_conc_nt": dict(sym_ct=4, overlap_mode=2, node_store=2),
@@ -83,6 +87,7 @@ def main():
         ev.set_option("overlap_mode", 2)
         ev.set_option("node_store", 0)
         ev.set_option("sym_ksplit", 0)
+        ev.set_option("sym_nst", 3)
         for k, v in opts.items():
             ev.set_option(k, v)
 
