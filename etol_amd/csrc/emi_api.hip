@@ -79,6 +79,7 @@ struct emi_ctx_s {
     DevBuf d_cost_part;
     DevBuf d_slab;              // partial sums of a split-K defect launch
     DevBuf d_ticket;            // [B] arrival counters of the in-kernel COST finish (zeroed once, self-resetting)
+    bool cost_in_kernel = true; // "cost_in_kernel": the node kernel of the overlapped pass finishes COST itself (ticket), no emi_cost_finish_kernel
     int sym_nst = 3;            // "sym_nst": ring stages of the one-launch pass (3 or 4)
     int slice_first = 0;        // first instance of the slice emi_eval_dev is working on (per-instance tables are offset by it)
     int sym_ksplit = 0;         // "sym_ksplit" option: K slices of an SW = NS launch (0: by batch size)
@@ -734,12 +735,23 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
                                                 : (c->sym_ct == 1 || c->sym_ct == 2 ? "emi_symdefect_f64_kernel" : "emi_symdefect_ring_f64_kernel");
         }
         if (plv == 1 || plv == 2) HIP_TRY(c, hipEventRecord(pe->k[1], s1));
+        // COST is finished inside the node kernel (last workgroup of an instance, by ticket, in chunk order): one launch
+        // and one kernel boundary less at the end of every pass (emi_cost_finish_kernel alone was 5 us)
+        if (c->cost_in_kernel) {
+            if (c->d_ticket.bytes < (size_t)c->B * 4) {
+                int est = ensure(c, c->d_ticket, (size_t)c->B * 4);
+                if (est) return est;
+                HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, (size_t)c->B * 4, s2));
+            }
+            na.cost_ticket = (unsigned*)c->d_ticket.p;
+        }
         if (plv == 1 || plv == 3) HIP_TRY(c, hipEventRecord(pe->k[2], s2));
         if (c->rtc) HIP_TRY(c, emi::rtc_launch_nodes<double>(c->rtc, na, jac, false, s2));
         else HIP_TRY(c, emi::launch_nodes<double>(c->model, na, jac, false, s2));
         if (plv == 1 || plv == 3) HIP_TRY(c, hipEventRecord(pe->k[3], s2));
-        HIP_TRY(c, emi::launch_cost_finish<double>(na.cost_part, na.cost, c->B, emi::node_chunks(c->M),
-                                                   na.sgn * na.h, s2));
+        if (!c->cost_in_kernel)
+            HIP_TRY(c, emi::launch_cost_finish<double>(na.cost_part, na.cost, c->B, emi::node_chunks(c->M),
+                                                       na.sgn * na.h, s2));
         if (two) {
             HIP_TRY(c, hipEventRecord(c->ev_join, s2));
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
@@ -1020,6 +1032,7 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
     }
     if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }
     if (strcmp(name, "sym_ablate") == 0) { c->sym_ablate = value; return EMI_OK; }   // diagnostics only
+    if (strcmp(name, "cost_in_kernel") == 0) { c->cost_in_kernel = value != 0; return EMI_OK; }
     if (strcmp(name, "sym_nst") == 0) {
         if (value != 3 && value != 4) return fail(c, EMI_ERR_ARG, "sym_nst must be 3 or 4");
         c->sym_nst = value;

@@ -35,6 +35,7 @@ VARIANTS = {
     "sw1_conc": dict(sym_ct=7, overlap_mode=2, node_store=-1),
     "auto": dict(sym_ct=0, overlap_mode=2, node_store=-1),
     "default": dict(sym_ct=0, overlap_mode=0, node_store=-1),
+    "default_cost_kernel": dict(sym_ct=0, overlap_mode=0, node_store=-1, cost_in_kernel=0),
     "one_launch_auto": dict(sym_ct=0, overlap_mode=3, node_store=-1),
     "one_launch_sw6": dict(sym_ct=5, overlap_mode=3, node_store=-1),
     "one_launch_sw3": dict(sym_ct=8, overlap_mode=3, node_store=-1),
@@ -88,6 +89,7 @@ def main():
         ev.set_option("node_store", 0)
         ev.set_option("sym_ksplit", 0)
         ev.set_option("sym_nst", 3)
+        ev.set_option("cost_in_kernel", 1)
         for k, v in opts.items():
             ev.set_option(k, v)
 
