@@ -78,6 +78,7 @@ struct emi_ctx_s {
     DevBuf d_trkx, d_trky;
     DevBuf d_cost_part;
     DevBuf d_slab;              // partial sums of a split-K defect launch
+    DevBuf d_cost_part2;        // cost partials of the values-only pre-kernel of the overlapped f32 pass (discarded)
     DevBuf d_ticket;            // [B] arrival counters of the in-kernel COST finish (zeroed once, self-resetting)
     bool cost_in_kernel = true; // "cost_in_kernel": the node kernel of the overlapped pass finishes COST itself (ticket), no emi_cost_finish_kernel
     int sym_nst = 3;            // "sym_nst": ring stages of the one-launch pass (3 or 4)
@@ -267,7 +268,7 @@ int emi_destroy(emi_ctx_t c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_w, &c->d_t, &c->d_Ddiag, &c->d_D, &c->d_De, &c->d_Do, &c->d_path, &c->d_trkx, &c->d_trky,
-                      &c->d_cost_part, &c->d_slab, &c->d_ticket, &c->s_X, &c->s_U, &c->s_RES, &c->s_VALS, &c->s_COST,
+                      &c->d_cost_part, &c->d_slab, &c->d_cost_part2, &c->d_ticket, &c->s_X, &c->s_U, &c->s_RES, &c->s_VALS, &c->s_COST,
                       &c->s_LF, &c->s_LC, &c->s_H};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -760,6 +761,40 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
                 HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join2, 0));
             }
         }
+        if (plv == 1) {
+            HIP_TRY(c, hipEventRecord(pe->e[1], c->stream));
+            HIP_TRY(c, hipEventRecord(pe->e[2], c->stream));
+        }
+        return EMI_OK;
+    }
+    if (c->f32 && nodes && defect && jac && !c->rtc && c->allow_fused && c->overlap_mode == 2 && emi::defect_f32_mfma_supported(c->M)) {
+        // fp32 contexts (config 5), only when asked for ("overlap_mode" 2): the f32 MFMA defect kernel ACCUMULATES onto
+        // -h f, so a values-only node kernel writes -h f first and the MFMA kernel follows it on the context's stream, while
+        // the full node kernel (Jacobian values, cost; no defect rows) runs beside them on the second stream.  Measured at
+        // B = 256, M = 4096: 1.076 ms against 1.082 ms back to back -- both kernels stretch (MFMA 0.93 -> 1.03 ms, node
+        // 0.16 -> 0.80 ms), nothing is gained, so the default stays sequential (profiles/r02_notes.md)
+        emi::NodeArgs<float> pre, full;
+        fill_node_args(c, pre, dX, dU, dRES, nullptr, dCOST);
+        fill_node_args(c, full, dX, dU, dRES, dVALS, dCOST);
+        int est = ensure(c, c->d_cost_part2, (size_t)c->B * emi::node_chunks(c->M) * 4);
+        if (est) return est;
+        pre.cost_part = (float*)c->d_cost_part2.p;      // its cost partials go nowhere
+        pre.np = 0;                                      // ... and it leaves the path rows to the full kernel
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        HIP_TRY(c, emi::launch_nodes<float>(c->model, pre, false, true, c->stream));
+        emi::DefectArgsF32 da{(const float*)dX, (const float*)c->d_D.p, (float*)dRES, c->B * c->ns, c->M, c->ns, nres_of(c)};
+        if (plv == 1 || plv == 2) HIP_TRY(c, hipEventRecord(pe->k[0], c->stream));
+        HIP_TRY(c, emi::launch_defect_f32_mfma(da, c->stream));
+        if (plv == 1 || plv == 2) HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
+        c->last_defect_kernel = "emi_defect_f32_mfma_kernel";
+        if (plv == 1 || plv == 3) HIP_TRY(c, hipEventRecord(pe->k[2], c->stream2));
+        HIP_TRY(c, emi::launch_nodes<float>(c->model, full, true, false, c->stream2));
+        if (plv == 1 || plv == 3) HIP_TRY(c, hipEventRecord(pe->k[3], c->stream2));
+        HIP_TRY(c, emi::launch_cost_finish<float>(full.cost_part, full.cost, c->B, emi::node_chunks(c->M), full.sgn * full.h, c->stream2));
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        if (pe) pe->fused = true;
         if (plv == 1) {
             HIP_TRY(c, hipEventRecord(pe->e[1], c->stream));
             HIP_TRY(c, hipEventRecord(pe->e[2], c->stream));

@@ -336,6 +336,7 @@ hipError_t launch_nodes(int model, const NodeArgs<T>& a, bool jac, bool defect_r
         switch (model) {
             case 0: return launch_nodes_model<T, PointMass2D<T>, false>(a, jac, s);
             case 1: return launch_nodes_model<T, Quadrotor2D<T>, false>(a, jac, s);
+            case 2: return launch_nodes_model<T, FixedWing12<T>, false>(a, jac, s);
         }
     }
     return hipErrorInvalidValue;
