@@ -594,3 +594,27 @@ def test_very_large_batches_are_evaluated_in_slices_with_the_same_results(built)
     ref = O.evaluate(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, 5.0, X[2090:2094], U[2090:2094], recs[2090:2094])
     assert np.abs(a[2][2090:2094].cpu().numpy() - ref[2]).max() / np.abs(ref[2]).max() < 1e-13
     ev.close()
+
+
+@pytest.mark.parametrize("sym_ct", [0, 3, 5, 7])
+def test_mfma_defect_kernel_variants_for_the_two_state_model(built, sym_ct):
+    """The 2-state point mass (the reference example's model) through the even/odd MFMA kernels: SW = 2 (all states),
+    SW = 1, the round-1 ring and the default choice, two streams and one launch, with ellipse and moving-disc rows."""
+    import etol_amd as E
+    M, B = 256, 40
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 16.0)
+    ev.set_model(E.MODEL_POINTMASS2D, [])
+    ev.set_batch(B)
+    X, U = cases.W.pointmass_batch(5, B, M)
+    recs, tx, ty = cases.ocp2d_tables(E.edge_ellipse, E.track_centres, ev.node_t)
+    ev.set_tracks(tx, ty)
+    ev.set_path(recs, 0, 1)
+    ev.set_option("sym_ct", sym_ct)
+    ref = O.evaluate(E.MODEL_POINTMASS2D, [], M, (ev.tau, ev.w, ev.D), 0.0, 16.0, X, U, recs, (tx, ty))
+    for mode in (2, 3, 0):
+        ev.set_option("overlap_mode", mode)
+        got = ev.eval_host(X, U)
+        assert ev.uses_fused_kernel
+        check(dict(X=X), ev, got, ref)
+    ev.close()
