@@ -48,6 +48,7 @@ struct KktTuning {
     std::atomic<int> batched_max_nodes{256};// "kkt_batched_max_nodes": largest mesh with the batched Schur-block build
     std::atomic<int> debug{0};              // "kkt_debug": 1 retries and fallbacks on stderr, 2 also the blocks around a failing pivot
     std::atomic<int> potrf_lock{0};         // "kkt_potrf_lock": serialise rocsolver_dpotrf calls of different host threads
+    std::atomic<int> sticky_reg{1};         // "kkt_sticky_reg": start the Schur path at the regularisation level that worked last on this mesh
 };
 static KktTuning g_tune;
 bool kkt_set_option(const char* name, int value) {
@@ -56,6 +57,7 @@ bool kkt_set_option(const char* name, int value) {
     if (!strcmp(name, "kkt_batched_max_nodes")) { g_tune.batched_max_nodes = value; return true; }
     if (!strcmp(name, "kkt_debug")) { g_tune.debug = value; return true; }
     if (!strcmp(name, "kkt_potrf_lock")) { g_tune.potrf_lock = value != 0; return true; }
+    if (!strcmp(name, "kkt_sticky_reg")) { g_tune.sticky_reg = value != 0; return true; }
     return false;
 }
 
@@ -91,6 +93,10 @@ struct KktWorkspace {
     size_t T_elems = 0, Cb_elems = 0;
     size_t cap_Pinv = 0, cap_G = 0, cap_Rk = 0, cap_Doff = 0, cap_W = 0;
     int* flag = nullptr;        // node kernel: a block was not positive definite
+    // dual-regularisation level the Schur path starts from (0: nominal, 1: x1e3, 2: x1e6, 3: straight to the LU): late
+    // interior-point iterations on one mesh fail at the same levels again and again, and every failed level costs a
+    // build of S and a Cholesky.  Kept per mesh shape; after reg_probe successes in a row one level lower is tried again.
+    int reg_level = 0, reg_hits = 0, reg_M = 0, reg_ns = 0, reg_nv = 0;
     double* chol_blk = nullptr;    // [64][64] + [64]: factorised diagonal block and reciprocal diagonal of the current block column
     double* chol_copy = nullptr;   // the matrix handed to dpotrf, kept until the factorisation is confirmed (potrf_checked)
     size_t cap_chol_copy = 0;
@@ -593,6 +599,15 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         // shift does, but the factor of such an S is too inaccurate for the refinement to repair: the 1024-node solve went
         // from 12 to 174 iterations.  Those few matrices belong to the LU below.)
         double dc_schur = dc > 1e-9 ? dc : 1e-9;
+        if (w->reg_M != M || w->reg_ns != ns || w->reg_nv != nv || !g_tune.sticky_reg.load()) {
+            w->reg_level = w->reg_hits = 0;
+            w->reg_M = M; w->reg_ns = ns; w->reg_nv = nv;
+        } else if (w->reg_level > 0 && w->reg_hits >= 4) {
+            --w->reg_level;
+            w->reg_hits = 0;
+        }
+        const int first_attempt = w->reg_level;
+        for (int a = 0; a < first_attempt && a < 3; ++a) dc_schur *= 1e3;
         if (batched && (w->ptrs_key[0] != w->Doff || w->ptrs_key[1] != w->W || w->ptrs_key[2] != w->S || w->ptrs_M != M ||
                         w->ptrs_ns != ns)) {
             std::vector<double*> hp(3 * (size_t)npairs);
@@ -608,7 +623,9 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
             w->ptrs_key[0] = w->Doff; w->ptrs_key[1] = w->W; w->ptrs_key[2] = w->S;
             w->ptrs_M = M; w->ptrs_ns = ns;
         }
-        for (int attempt = 0; attempt < 3; ++attempt, dc_schur *= 1e3) {
+        int attempt = first_attempt;
+        if (first_attempt >= 3) hinfo = 1;          // the last factorisations on this mesh all ended in the LU
+        for (; attempt < 3; ++attempt, dc_schur *= 1e3) {
             if (batched) {
                 // three launches for all ns (ns + 1) / 2 state pairs: small meshes are launch-bound here
                 hipLaunchKernelGGL(emi_kkt_scale_all_kernel, dim3(nb2, npairs), dim3(256), 0, stream, w->Doff, w->Pinv, w->W, M, nv);
@@ -638,13 +655,17 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
                         (int)hinfo, dc_schur, M);
         }
         if (hinfo == 0 && hflag == 0) {
+            if (attempt == first_attempt) ++w->reg_hits; else { w->reg_level = attempt; w->reg_hits = 0; }
             *info = 0;
             w->factored = true;
             w->method_used = 1;
             return EMI_OK;
         }
+        if (hflag == 0) {                           // S not positive definite at any level: the next factorisations start at the LU
+            if (first_attempt >= 3) ++w->reg_hits; else { w->reg_level = 3; w->reg_hits = 0; }
+        }
         // a block was not positive definite or S is not: not the quasi-definite case -- general path below
-        if (g_tune.debug.load() >= 2 && hinfo > 0) {
+        if (g_tune.debug.load() >= 2 && hinfo > 0 && first_attempt < 3) {
             // diagnosis: the node blocks around the failing pivot (diagonals of Q as uploaded and of P = Q^-1)
             const int kf = ((int)hinfo - 1) % M, i_f = ((int)hinfo - 1) / M;
             std::vector<double> hq((size_t)nh * M), hp((size_t)nv * nv * M);

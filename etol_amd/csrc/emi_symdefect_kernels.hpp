@@ -236,13 +236,18 @@ __global__ __launch_bounds__(256, 2) void emi_symdefect_ring_f64_kernel(SymDefec
             kdir[t] = 1;
         }
     }
+    // The DMA is issued from inline assembly: an LDS-DMA instruction the COMPILER knows about makes it put
+    // "s_waitcnt vmcnt(0)" in front of every later LDS read (it cannot tell which ring stage the DMA writes), i.e. right
+    // after the DMA of tile kt+LOOK is issued the wave waited for that very tile -- no tile in flight at all, every K tile
+    // paid a full DMA round trip (the ISA of rounds 1-2; profiles/r02_notes.md section 9).  The counted vmcnt waits of
+    // the K loop are the only synchronisation with the DMA the ring needs.  m0 = LDS address of the 1 KB the wave writes.
+    const unsigned lds0 = (unsigned)(unsigned long)(emi_lds_ptr_t)smem;          // LDS byte address of the ring
     auto issue = [&](int stage, int kt) {
-        double* base = smem + (size_t)stage * STAGE;
 #pragma unroll
         for (int t = 0; t < L; ++t) {
-            double* dst = base + (size_t)(wid + 4 * t) * 128;      // wave-uniform: 1 KB per instruction
+            const unsigned dst = lds0 + (unsigned)stage * (unsigned)(STAGE * 8) + (unsigned)(wid + 4 * t) * 1024u;   // wave-uniform
             const double* g = src[t] + (ptrdiff_t)kdir[t] * kt * BK;
-            __builtin_amdgcn_global_load_lds((emi_glb_ptr_t)g, (emi_lds_ptr_t)dst, 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
         }
     };
 
@@ -420,40 +425,54 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
 
-    const double* src[L];
-    int kdir[L];
+    // DMA addressing: an instruction of wave wid moves rows 16 (wid + 4t) .. +15 of the stage, which are all forward x,
+    // all mirrored x, all De or all Do -- so the 64-bit base and its advance per K tile are wave-uniform (scalar
+    // registers, SALU) and a lane contributes a 32-bit byte offset that never changes (saddr form of global_load_lds:
+    // no vector address arithmetic per tile; the 64-bit per-lane form cost two v_mul_lo_u32, a v_mad_u64_u32 and a
+    // v_add3_u32 per instruction and tile).
+    unsigned voff[L];                  // per lane: byte offset from the instruction's base
+    unsigned long long gbase[L];       // wave-uniform: base address at K tile 0
+    int gstep[L];                      // wave-uniform: bytes per K tile (+64 forward, -64 mirrored x, 0 padding)
 #pragma unroll
     for (int t = 0; t < L; ++t) {
-        const int q = (wid + 4 * t) * 64 + lane;       // 16-byte chunk id within the stage
-        const int row = q >> 2, p = q & 3;
-        if (row < 2 * TM) {
-            const bool mir = row >= TM;
-            const int rr = mir ? row - TM : row;
+        const int row0 = (wid + 4 * t) * 16;           // wave-uniform
+        const int row = row0 + (lane >> 2), p = lane & 3;
+        if (row0 < 2 * TM) {
+            const bool mir = row0 >= TM;
+            const int rr = row - (mir ? TM : 0);
             const int c = p ^ ring_swz(rr);
             int inst = inst0 + (rr & 15);
             inst = inst < B ? inst : B - 1;            // rows past the batch are never written out
-            const double* xr = a.X + ((size_t)inst * NS + s0 + (rr >> 4)) * M;
-            src[t] = mir ? xr + (M - BK) + 2 * c : xr + 2 * c;
-            kdir[t] = mir ? -1 : 1;
-        } else if (row < ROWS) {
-            const bool od = row >= 2 * TM + TN;
+            voff[t] = (unsigned)((((size_t)inst * NS + s0 + (rr >> 4)) * M + 2 * c) * sizeof(double));
+            gbase[t] = (unsigned long long)(a.X + (mir ? M - BK : 0));
+            gstep[t] = mir ? -(int)(BK * sizeof(double)) : (int)(BK * sizeof(double));
+        } else if (row0 < ROWS) {
+            const bool od = row0 >= 2 * TM + TN;
             const int rr = row - 2 * TM - (od ? TN : 0);
             const int c = p ^ ring_swz(rr);
-            src[t] = (od ? a.Do : a.De) + (size_t)(i0 + rr) * Hh + 2 * c;
-            kdir[t] = 1;
+            voff[t] = (unsigned)(((size_t)(i0 + rr) * Hh + 2 * c) * sizeof(double));
+            gbase[t] = (unsigned long long)(od ? a.Do : a.De);
+            gstep[t] = (int)(BK * sizeof(double));
         } else {                                       // padding rows of the last DMA instruction: never read
-            src[t] = a.De + 2 * p;
-            kdir[t] = 0;
+            voff[t] = (unsigned)(2 * p * sizeof(double));
+            gbase[t] = (unsigned long long)a.De;
+            gstep[t] = 0;
         }
     }
+    // The DMA is issued from inline assembly: an LDS-DMA instruction the COMPILER knows about makes it put
+    // "s_waitcnt vmcnt(0)" in front of every later LDS read (it cannot tell which ring stage the DMA writes), i.e. right
+    // after the DMA of tile kt+LOOK is issued the wave waited for that very tile -- no tile in flight at all, every K tile
+    // paid a full DMA round trip (the ISA of rounds 1-2; profiles/r02_notes.md section 9).  The counted vmcnt waits of
+    // the K loop are the only synchronisation with the DMA the ring needs.  m0 = LDS address of the 1 KB the wave writes.
+    const unsigned lds0 = (unsigned)(unsigned long)(emi_lds_ptr_t)smem;          // LDS byte address of the ring
+    auto issue_one = [&](int t, int stage, int kt) {
+        const unsigned dst = lds0 + (unsigned)stage * (unsigned)(STAGE * 8) + (unsigned)(wid + 4 * t) * 1024u;   // wave-uniform
+        const unsigned long long g = gbase[t] + (long long)gstep[t] * kt;
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[t]), "s"(g), "s"(dst) : "memory", "m0");
+    };
     auto issue = [&](int stage, int kt) {
-        double* base = smem + (size_t)stage * STAGE;
 #pragma unroll
-        for (int t = 0; t < L; ++t) {
-            double* dst = base + (size_t)(wid + 4 * t) * 128;      // wave-uniform: 1 KB per instruction
-            const double* g = src[t] + (ptrdiff_t)kdir[t] * kt * BK;
-            __builtin_amdgcn_global_load_lds((emi_glb_ptr_t)g, (emi_lds_ptr_t)dst, 16, 0, 0);
-        }
+        for (int t = 0; t < L; ++t) issue_one(t, stage, kt);
     };
 
     d4 acc_a[SW], acc_b[SW];
@@ -477,32 +496,94 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         off_f[s] = r * BK + ((kq ^ ring_swz(r)) << 1);               // chunk kq: x_(2kq), x_(2kq+1)
         off_m[s] = (TM + r) * BK + (((3 - kq) ^ ring_swz(r)) << 1);  // chunk 3-kq of the mirrored tile
     }
-    for (int kt = 0; kt < nkt; ++kt) {
-        // tile kt has landed once all but the DMA instructions of the (up to LOOK - 1) younger tiles are done
-        if (kt + LOOK - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
-        else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tail: at most LOOK - 1 tiles early
-        asm volatile("s_barrier" ::: "memory");     // every wave's part landed; stage (kt-1) % NST is free
-        if (kt + LOOK < nkt && !(a.ablate & 2)) issue((kt + LOOK) % NST, kt0 + kt + LOOK);
-        if (a.ablate & 1) continue;
+    // fragments of one K tile: De / Do rows of this wave (B operands), forward and mirrored x of every state (A operands)
+    struct Frag {
+        double2 be, bo, xf[SW], xm[SW];
+    };
+    constexpr int NR = 2 + 2 * SW, NM = 4 * SW;         // fragment reads / MFMAs per wave and K tile
+    auto read_one = [&](Frag& f, const double* S, int r) {
+        if (r == 0) f.be = *reinterpret_cast<const double2*>(S + 2 * TM * BK + off_b);
+        else if (r == 1) f.bo = *reinterpret_cast<const double2*>(S + (2 * TM + TN) * BK + off_b);
+        else if (r & 1) f.xm[(r - 2) >> 1] = *reinterpret_cast<const double2*>(S + off_m[(r - 2) >> 1]);
+        else f.xf[(r - 2) >> 1] = *reinterpret_cast<const double2*>(S + off_f[(r - 2) >> 1]);
+    };
+    auto read_frag = [&](Frag& f, int kt) {
         const double* S = smem + (size_t)(kt % NST) * STAGE;
-        const double2 be = *reinterpret_cast<const double2*>(S + 2 * TM * BK + off_b);
-        const double2 bo = *reinterpret_cast<const double2*>(S + (2 * TM + TN) * BK + off_b);
-        double2 xf[SW], xm[SW];
 #pragma unroll
-        for (int s = 0; s < SW; ++s) {
-            xf[s] = *reinterpret_cast<const double2*>(S + off_f[s]);
-            xm[s] = *reinterpret_cast<const double2*>(S + off_m[s]);
+        for (int r = 0; r < NR; ++r) read_one(f, S, r);
+    };
+    // MFMA i of a tile.  k = 2kq (+1): forward x_k in xf.x (.y), its mirror x_(N-k) at position 7-k of the mirrored tile:
+    // xm.y (.x); first the 2 SW MFMAs of the tile's first k-step, then those of the second
+    auto mfma_one = [&](const Frag& f, int i) {
+        const int s = (i % (2 * SW)) >> 1;
+        const bool second = i >= 2 * SW, odd = i & 1;
+        const double xa = second ? f.xf[s].y : f.xf[s].x, xb = second ? f.xm[s].x : f.xm[s].y;
+        if (!odd) acc_a[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa + xb, second ? f.be.y : f.be.x, acc_a[s], 0, 0, 0);
+        else      acc_b[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa - xb, second ? f.bo.y : f.bo.x, acc_b[s], 0, 0, 0);
+    };
+    auto multiply = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) mfma_one(f, i);
+    };
+    if constexpr (SW <= 3) {
+        // Software-pipelined K loop.  A wave issues in order and an MFMA waits for the matrix pipe (64 cycles per
+        // v_mfma_f64_16x16x4_f64), so whatever stands between two tiles' MFMAs in program order runs with the pipe idle:
+        // measured on a 128-instance shard (one wave per SIMD, nothing else to hide behind) skeleton 11 us + DMA issue 14
+        // + fragment reads and MFMAs 19 + epilogue 6, all serial (tools/small_batch_anatomy.py).  Here the DMA of tile
+        // kt+1+LOOK and the fragment reads of tile kt+1 are dealt into the gaps BETWEEN the MFMAs of tile kt, one DMA
+        // instruction or a few reads per gap; sched_barrier pins that order (the scheduler sinks the reads behind the
+        // MFMAs otherwise).  Stage (kt+1+LOOK) % NST is the stage of tile kt (NST = LOOK + 1), whose fragment reads every
+        // wave has completed before it arrives at the barrier (lgkmcnt(0) ahead of it).
+        constexpr int RPG = (NR + (NM - L) - 1) / (NM - L);     // reads per gap once the DMA instructions are out
+        static_assert(NM > L, "more MFMAs than DMA instructions per wave and tile");
+        auto step = [&](const Frag& cur, Frag& nxt, int kt) {   // kt + 1 < nkt: MFMAs of tile kt, tile kt+1 made ready
+            if (kt + LOOK < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
+            else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0), as an instruction the compiler's own wait counting sees
+            asm volatile("s_barrier" ::: "memory");     // tile kt+1 has landed for every wave; the stage of tile kt is free
+            const bool more = kt + 1 + LOOK < nkt;
+            const int st = (kt + 1 + LOOK) % NST, ktd = kt0 + kt + 1 + LOOK;
+            const double* S = smem + (size_t)((kt + 1) % NST) * STAGE;
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                mfma_one(cur, i);
+                if (i < L) {
+                    if (more) issue_one(i, st, ktd);
+                } else {
+#pragma unroll
+                    for (int r = (i - L) * RPG; r < (i - L + 1) * RPG && r < NR; ++r) read_one(nxt, S, r);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        Frag f0, f1;
+        if (nkt > LOOK - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
+        else                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (LOOK < nkt) issue(LOOK % NST, kt0 + LOOK);
+        // scalar loads of arguments the epilogue needs are still pending in the compiler's model here; with them pending it
+        // turns every fragment wait of the loop into lgkmcnt(0), i.e. waits for the reads it has just issued as well
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        read_frag(f0, 0);
+        int kt = 0;                                     // nkt is even (M % 128 == 0, ksplit a power of two <= 8)
+        for (; kt + 2 < nkt; kt += 2) {
+            step(f0, f1, kt);
+            step(f1, f0, kt + 1);
         }
-        // k = 2kq (+1): forward x_k in xf.x (.y), its mirror x_(N-k) at position 7-k of the mirrored tile: xm.y (.x)
-#pragma unroll
-        for (int s = 0; s < SW; ++s) {
-            acc_a[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[s].x + xm[s].y, be.x, acc_a[s], 0, 0, 0);
-            acc_b[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[s].x - xm[s].y, bo.x, acc_b[s], 0, 0, 0);
-        }
-#pragma unroll
-        for (int s = 0; s < SW; ++s) {
-            acc_a[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[s].y + xm[s].x, be.y, acc_a[s], 0, 0, 0);
-            acc_b[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xf[s].y - xm[s].x, bo.y, acc_b[s], 0, 0, 0);
+        step(f0, f1, kt);
+        multiply(f1);
+    } else {
+        // all states in one workgroup: two fragment sets (2 x 56 registers) beside 96 accumulator registers would spill;
+        // 24 MFMAs per wave and tile and two workgroups per CU hide the reads here
+        for (int kt = 0; kt < nkt; ++kt) {
+            // tile kt has landed once all but the DMA instructions of the (up to LOOK - 1) younger tiles are done
+            if (kt + LOOK - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
+            else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tail: at most LOOK - 1 tiles early
+            asm volatile("s_barrier" ::: "memory");     // every wave's part landed; stage (kt-1) % NST is free
+            if (kt + LOOK < nkt) issue((kt + LOOK) % NST, kt0 + kt + LOOK);
+            Frag f;
+            read_frag(f, kt);
+            multiply(f);
         }
     }
 
@@ -582,6 +663,9 @@ __global__ __launch_bounds__(256, 2) void emi_pass_f64_kernel(PassArgs a) {
     const int g = blockIdx.x, xcd = g & 7, j = g >> 3, t8 = a.nm8 + a.nn8;
     const int m0 = (int)(((long long)j * a.nm8) / t8), m1 = (int)(((long long)(j + 1) * a.nm8) / t8);
     if (m1 > m0) {
+        // the MFMA role is the latency chain of a small pass (64 dependent K tiles); the streaming role beside it on the
+        // same SIMDs waits on memory most of the time: instruction arbitration goes to the MFMA waves first
+        __builtin_amdgcn_s_setprio(3);
         emi_ring2_body<Model, SW, NST>(a.s, xcd * a.nm8 + m0);
     } else {
         const int nid = xcd * a.nn8 + (j - m0);

@@ -173,6 +173,17 @@ int main(int argc, char** argv) {
     int lo = (int)((long long)rank * nscen / world), hi = (int)((long long)(rank + 1) * nscen / world);
     if (env_int("EMI_MC_ONLY", -1) >= 0) { lo = env_int("EMI_MC_ONLY", 0); hi = lo + 1; }   // diagnostics: one scenario
 
+    // diagnostics: process-wide factorisation switches (emi_set_option "kkt_*"), e.g. EMI_MC_KKT_DEBUG=1 prints retries and
+    // fallbacks on stderr, EMI_MC_KKT_STICKY=0 starts every factorisation at the nominal regularisation again
+    const int kkt_debug = env_int("EMI_MC_KKT_DEBUG", 0), kkt_sticky = env_int("EMI_MC_KKT_STICKY", -1);
+    if (kkt_debug > 0 || kkt_sticky >= 0) {
+        emi_ctx_t sw = nullptr;
+        if (emi_create(device, &sw) == EMI_OK) {
+            if (kkt_debug > 0) emi_set_option(sw, "kkt_debug", kkt_debug);
+            if (kkt_sticky >= 0) emi_set_option(sw, "kkt_sticky_reg", kkt_sticky);
+            emi_destroy(sw);
+        }
+    }
     std::vector<Result> results(hi - lo);
     std::atomic<int> next(lo);
     const auto t0 = std::chrono::steady_clock::now();

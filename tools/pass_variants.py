@@ -53,6 +53,10 @@ VARIANTS = {
     "ring_bk16_sequential": dict(sym_ct=3, overlap_mode=1),
     "ring2_auto_seq_nt": dict(sym_ct=4, overlap_mode=1, node_store=2),
     "ring2_auto_sequential": dict(sym_ct=4, overlap_mode=1),
+    "ring2_sw6_sequential": dict(sym_ct=5, overlap_mode=1),
+    "ring2_sw2_sequential": dict(sym_ct=6, overlap_mode=1),
+    "ring2_sw1_sequential": dict(sym_ct=7, overlap_mode=1),
+    "ring2_sw3_sequential": dict(sym_ct=8, overlap_mode=1),
     "general_sequential": dict(overlap=0),
 }
 
