@@ -78,12 +78,14 @@ struct emi_ctx_s {
     DevBuf d_trkx, d_trky;
     DevBuf d_cost_part;
     DevBuf d_slab;              // partial sums of a split-K defect launch
+    DevBuf d_tile_ticket;       // ... and the tickets of its in-kernel combine (zero between launches)
     DevBuf d_cost_part2;        // cost partials of the values-only pre-kernel of the overlapped f32 pass (discarded)
     DevBuf d_ticket;            // [B] arrival counters of the in-kernel COST finish (zeroed once, self-resetting)
     bool cost_in_kernel = true; // "cost_in_kernel": the node kernel of the overlapped pass finishes COST itself (ticket), no emi_cost_finish_kernel
     int sym_nst = 3;            // "sym_nst": ring stages of the one-launch pass (3 or 4)
     int slice_first = 0;        // first instance of the slice emi_eval_dev is working on (per-instance tables are offset by it)
-    int sym_ksplit = 0;         // "sym_ksplit" option: K slices of an SW = NS launch (0: by batch size)
+    int sym_ksplit = 0;         // "sym_ksplit" option: K slices per tile of the state-split ring kernel (0: by batch size)
+    int sym_combine = 1;        // "sym_combine" option: 1 slices combined in-kernel by ticket, 0 by emi_symdefect_combine_kernel
     // host-form staging
     DevBuf s_X, s_U, s_RES, s_VALS, s_COST, s_LF, s_LC, s_H;
     // measurement
@@ -268,7 +270,7 @@ int emi_destroy(emi_ctx_t c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->d_w, &c->d_t, &c->d_Ddiag, &c->d_D, &c->d_De, &c->d_Do, &c->d_path, &c->d_trkx, &c->d_trky,
-                      &c->d_cost_part, &c->d_slab, &c->d_cost_part2, &c->d_ticket, &c->s_X, &c->s_U, &c->s_RES, &c->s_VALS, &c->s_COST,
+                      &c->d_cost_part, &c->d_slab, &c->d_tile_ticket, &c->d_cost_part2, &c->d_ticket, &c->s_X, &c->s_U, &c->s_RES, &c->s_VALS, &c->s_COST,
                       &c->s_LF, &c->s_LC, &c->s_H};
     for (DevBuf* b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -675,7 +677,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         emi::SymDefectArgs sa;
         sa.X = (const double*)dX; sa.U = (const double*)dU; sa.RES = (double*)dRES;
         sa.node_t = (const double*)c->d_t.p; sa.De = (const double*)c->d_De.p; sa.Do = (const double*)c->d_Do.p;
-        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0; sa.order = c->sym_order; sa.ablate = c->sym_ablate; sa.ksplit = 1; sa.slab = nullptr;
+        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0; sa.order = c->sym_order; sa.ablate = c->sym_ablate; sa.ksplit = 1; sa.slab = nullptr; sa.tile_ticket = nullptr;
         for (int i = 0; i < EMI_MAX_PARAMS; ++i) sa.P.p[i] = c->params[i];
         emi::NodeArgs<double> na;
         fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
@@ -690,9 +692,30 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             if (auto_mode && (c->sym_ct == 0 || c->sym_ct == 4))
                 plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 <= 96 ? 7 : 6, 1);        // SW = 1 / 2
             else if (plan.ring1) plan = emi::plan_symdefect(c->ns, c->B, c->M, 5, 1);
-            plan.ks = 1;
             plan.nst = c->sym_nst;
+            if (c->sym_ksplit > 1) {
+                // "sym_ksplit": the K range of a tile cut into slices, their partial sums combined in-kernel by ticket.
+                // Not chosen by itself: at 128 instances SW = 2 x 2 slices 0.0437 ms against SW = 1 unsplit 0.0446 -- the
+                // fixed parts of the MFMA role (launch, prologue, epilogue: ~15 us) are what a small pass waits for
+                const int ct_now = plan.sw == c->ns ? 5 : (plan.sw == 2 ? 6 : (plan.sw == 3 ? 8 : 7));
+                plan = emi::plan_symdefect(c->ns, c->B, c->M, ct_now, c->sym_ksplit);
+                plan.nst = c->sym_nst;
+            } else {
+                plan.ks = 1;
+            }
             if (emi::pass_supported(c->model, c->ns, c->B, c->M, plan)) {
+                if (plan.ks > 1) {
+                    int est = ensure(c, c->d_slab, plan.slab_bytes);
+                    if (est) return est;
+                    if (c->d_tile_ticket.bytes < (size_t)plan.tiles * 4) {
+                        est = ensure(c, c->d_tile_ticket, (size_t)plan.tiles * 4);
+                        if (est) return est;
+                        HIP_TRY(c, hipMemsetAsync(c->d_tile_ticket.p, 0, c->d_tile_ticket.bytes, c->stream));
+                    }
+                    sa.ksplit = plan.ks;
+                    sa.slab = (double*)c->d_slab.p;
+                    sa.tile_ticket = (unsigned*)c->d_tile_ticket.p;
+                }
                 if (c->d_ticket.bytes < (size_t)c->B * 4) {
                     int est = ensure(c, c->d_ticket, (size_t)c->B * 4);
                     if (est) return est;
@@ -703,7 +726,8 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
                 HIP_TRY(c, emi::launch_pass(c->model, sa, na, c->stream, plan));
                 if (plv) HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
                 if (pe) pe->level = -1;                 // one bracket: the pass kernel
-                c->last_defect_kernel = "emi_pass_f64_kernel<SW=" + std::to_string(plan.sw) + "> (MFMA + node roles, one launch)";
+                c->last_defect_kernel = "emi_pass_f64_kernel<SW=" + std::to_string(plan.sw) + "> (MFMA + node roles, one launch" +
+                                        (plan.ks > 1 ? ", " + std::to_string(plan.ks) + " K slices per tile" : "") + ")";
                 return EMI_OK;
             }
         }
@@ -729,10 +753,18 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             }
             sa.ksplit = plan.ring1 ? 1 : plan.ks;
             sa.slab = (double*)c->d_slab.p;
+            if (sa.ksplit > 1 && c->sym_combine) {
+                if (c->d_tile_ticket.bytes < (size_t)plan.tiles * 4) {
+                    int est = ensure(c, c->d_tile_ticket, (size_t)plan.tiles * 4);
+                    if (est) return est;
+                    HIP_TRY(c, hipMemsetAsync(c->d_tile_ticket.p, 0, c->d_tile_ticket.bytes, s1));
+                }
+                sa.tile_ticket = (unsigned*)c->d_tile_ticket.p;
+            }
             HIP_TRY(c, emi::launch_symdefect(c->model, sa, s1, !(c->fused_attr_mask & bit), c->sym_ct, plan));
             c->fused_attr_mask |= bit;
             c->last_defect_kernel = !plan.ring1 ? "emi_symdefect_ring2_f64_kernel<SW=" + std::to_string(plan.sw) + ">" +
-                                                      (plan.ks > 1 ? " x" + std::to_string(plan.ks) + " K slices + emi_symdefect_combine_kernel" : "")
+                                                      (plan.ks > 1 ? " x" + std::to_string(plan.ks) + (sa.tile_ticket ? " K slices (in-kernel combine)" : " K slices + emi_symdefect_combine_kernel") : "")
                                                 : (c->sym_ct == 1 || c->sym_ct == 2 ? "emi_symdefect_f64_kernel" : "emi_symdefect_ring_f64_kernel");
         }
         if (plv == 1 || plv == 2) HIP_TRY(c, hipEventRecord(pe->k[1], s1));
@@ -1073,6 +1105,7 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         c->sym_nst = value;
         return EMI_OK;
     }
+    if (strcmp(name, "sym_combine") == 0) { c->sym_combine = value != 0; return EMI_OK; }
     if (strcmp(name, "sym_ksplit") == 0) {
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, EMI_ERR_ARG, "sym_ksplit must be 0 (by batch size), 1, 2, 4 or 8");
         c->sym_ksplit = value;

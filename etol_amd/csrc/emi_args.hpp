@@ -77,6 +77,8 @@ struct SymDefectArgs {
     int ablate;             // diagnostics (results invalid): 1 skip MFMAs, 2 skip operand DMA, 4 skip epilogue
     int ksplit;             // state-split ring kernel: K slices per tile (1 = none); > 1 goes through `slab`
     double* slab;           // [tiles][ksplit][2 SW][4][256] partial sums of a split-K launch
+    unsigned* tile_ticket;  // [tiles] zero before the first launch, self-resetting: the slices of a tile are combined by the
+                            // workgroup that draws the tile's last ticket (nullptr: emi_symdefect_combine_kernel does it)
     double h;
     ModelParams<double> P;
 };

@@ -33,9 +33,10 @@ bool fused_supported(int model, int M, int ct);
 struct SymPlan {
     bool ring1 = false;       // the one-workgroup-per-CU ring kernel / register-staged forms (sym_ct 1..3)
     int sw = 0;               // state-split ring: states per workgroup
-    int ks = 1;               // ... and K slices per tile (> 1: partial sums through a slab + combine launch)
+    int ks = 1;               // ... and K slices per tile (> 1: partial sums through a slab, combined in-kernel by ticket or by a second launch)
     int nst = 3;              // ring stages of the one-launch pass (3 or 4: K tiles in flight = nst - 1)
     size_t slab_bytes = 0;
+    int tiles = 0;            // tiles of the launch (instance groups x column tiles x state groups): tickets of an in-kernel combine
 };
 SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt);
 hipError_t launch_symdefect(int model, const SymDefectArgs& a, hipStream_t s, bool set_attr, int ct, const SymPlan& plan);

@@ -86,7 +86,7 @@ static hipError_t launch_ring2_model(const SymDefectArgs& a, hipStream_t s) {
     }
     const int tiles = mtiles * ntiles * (NS / SW), ks = a.ksplit > 1 ? a.ksplit : 1;
     hipLaunchKernelGGL((emi_symdefect_ring2_f64_kernel<Model, SW>), dim3(tiles * ks), dim3(256), lds, s, a);
-    if (ks > 1) hipLaunchKernelGGL((emi_symdefect_combine_kernel<Model, SW>), dim3(tiles), dim3(256), 0, s, a);
+    if (ks > 1 && a.tile_ticket == nullptr) hipLaunchKernelGGL((emi_symdefect_combine_kernel<Model, SW>), dim3(tiles), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -98,7 +98,7 @@ static hipError_t launch_ring2_model(const SymDefectArgs& a, hipStream_t s) {
 //   192 .. 319 tiles (B = 512): the one-workgroup-per-CU ring kernel, whose grid is then a single round;
 //   fewer (the shard of config 4: 128 instances = 64 tiles for 256 CUs): SW = NS with the K range of a tile cut
 //      into 4 (<= 96 tiles) or 2 slices, combined in slice order by a second launch.
-// ct 5 / 6 / 7 / 8 force SW = NS / 2 / 1 / 3; ksplit_opt > 0 forces the slice count of an SW = NS launch.
+// ct 5 / 6 / 7 / 8 force SW = NS / 2 / 1 / 3; ksplit_opt > 0 forces the slice count.
 SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt) {
     SymPlan p;
     const int tiles = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64);
@@ -115,9 +115,10 @@ SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt) {
         p.ring1 = true;
         return p;
     }
-    if (ksplit_opt > 0 && p.sw == ns) p.ks = ksplit_opt;
-    while (p.ks > 1 && (nkt % p.ks != 0 || nkt / p.ks < 2)) p.ks >>= 1;
-    if (p.ks > 1) p.slab_bytes = (size_t)tiles * p.ks * (2 * p.sw * 4) * 256 * sizeof(double);
+    if (ksplit_opt > 0) p.ks = ksplit_opt;
+    while (p.ks > 1 && (nkt % p.ks != 0 || nkt / p.ks < 2 || (nkt / p.ks) % 2 != 0)) p.ks >>= 1;
+    p.tiles = tiles * (ns / p.sw);
+    if (p.ks > 1) p.slab_bytes = (size_t)p.tiles * p.ks * (2 * p.sw * 4) * 256 * sizeof(double);
     return p;
 }
 
@@ -143,7 +144,7 @@ static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<doub
     a.s = sa;
     a.n = na;
     const int mtiles = (sa.B + FUSED_TI - 1) / FUSED_TI, ntiles = (sa.M / 2) / 64;
-    const int nm = mtiles * ntiles * (NS / SW);
+    const int nm = mtiles * ntiles * (NS / SW) * (sa.ksplit > 1 ? sa.ksplit : 1);
     a.nbx = (na.M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS);
     const int nn = a.nbx * na.B;
     if (nm % 8 || nn % 8) return hipErrorInvalidConfiguration;
@@ -175,11 +176,12 @@ static hipError_t launch_pass_planned(const SymDefectArgs& sa, const NodeArgs<do
     return p.nst > 3 ? launch_pass_model<Model, 1, 4>(sa, na, s) : launch_pass_model<Model, 1, 3>(sa, na, s);
 }
 
-// true if the pass can go out as one launch with this plan (state-split ring role, no K slices, whole XCD shares)
+// true if the pass can go out as one launch with this plan (state-split ring role, K slices combined in-kernel by
+// ticket, whole XCD shares)
 bool pass_supported(int model, int ns, int B, int M, const SymPlan& p) {
-    if (p.ring1 || p.ks > 1 || p.sw < 1 || (model != EMI_MODEL_POINTMASS2D && model != EMI_MODEL_QUADROTOR2D)) return false;
+    if (p.ring1 || p.sw < 1 || (model != EMI_MODEL_POINTMASS2D && model != EMI_MODEL_QUADROTOR2D)) return false;
     if (M % 128 != 0 || ns % p.sw != 0) return false;
-    const int nm = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64) * (ns / p.sw);
+    const int nm = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64) * (ns / p.sw) * (p.ks > 1 ? p.ks : 1);
     const int nn = ((M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS)) * B;
     return nm % 8 == 0 && nn % 8 == 0;
 }

@@ -534,8 +534,9 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         // instruction or a few reads per gap; sched_barrier pins that order (the scheduler sinks the reads behind the
         // MFMAs otherwise).  Stage (kt+1+LOOK) % NST is the stage of tile kt (NST = LOOK + 1), whose fragment reads every
         // wave has completed before it arrives at the barrier (lgkmcnt(0) ahead of it).
-        constexpr int RPG = (NR + (NM - L) - 1) / (NM - L);     // reads per gap once the DMA instructions are out
-        static_assert(NM > L, "more MFMAs than DMA instructions per wave and tile");
+        constexpr int RPG = (NR + (NM - L) - 1) / (NM - L);     // fragment reads per gap
+        constexpr int GR = (NR + RPG - 1) / RPG;                // gaps that take reads: the first GR; then L gaps with a DMA each
+        static_assert(NM > L && GR + L <= NM, "a gap for every DMA instruction after the reads");
         auto step = [&](const Frag& cur, Frag& nxt, int kt) {   // kt + 1 < nkt: MFMAs of tile kt, tile kt+1 made ready
             if (kt + LOOK < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
             else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -544,14 +545,15 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
             const bool more = kt + 1 + LOOK < nkt;
             const int st = (kt + 1 + LOOK) % NST, ktd = kt0 + kt + 1 + LOOK;
             const double* S = smem + (size_t)((kt + 1) % NST) * STAGE;
+            // reads first: the next tile's first MFMA needs them, the DMA has LOOK tiles of slack
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
                 mfma_one(cur, i);
-                if (i < L) {
-                    if (more) issue_one(i, st, ktd);
-                } else {
+                if (i < GR) {
 #pragma unroll
-                    for (int r = (i - L) * RPG; r < (i - L + 1) * RPG && r < NR; ++r) read_one(nxt, S, r);
+                    for (int r = i * RPG; r < (i + 1) * RPG && r < NR; ++r) read_one(nxt, S, r);
+                } else if (i < GR + L) {
+                    if (more) issue_one(i - GR, st, ktd);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -589,14 +591,49 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
 
     if (KS > 1) {       // partial sums of this K slice -> slab (coalesced: one 2 KB row per register)
         double* sl = a.slab + ((size_t)tile * KS + kslice) * (2 * SW * 4) * 256 + tid;
+        if (a.tile_ticket == nullptr) {                 // emi_symdefect_combine_kernel adds the slices
+#pragma unroll
+            for (int s = 0; s < SW; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sl[(size_t)((2 * s) * 4 + i) * 256] = acc_a[s][i];
+                    sl[(size_t)((2 * s + 1) * 4 + i) * 256] = acc_b[s][i];
+                }
+            return;
+        }
+        // In-kernel combine: the workgroup that draws the last ticket of its tile adds the slices IN SLICE ORDER (its own
+        // from the slab as well: bitwise the result of the combine kernel) and runs the epilogue.  Partial sums travel
+        // write-through / cache-bypassing (agent-scope atomics: store, drain, then the ticket -- as the COST partials of
+        // the node kernel do); the ticket word resets itself.
 #pragma unroll
         for (int s = 0; s < SW; ++s)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                sl[(size_t)((2 * s) * 4 + i) * 256] = acc_a[s][i];
-                sl[(size_t)((2 * s + 1) * 4 + i) * 256] = acc_b[s][i];
+                __hip_atomic_store(sl + (size_t)((2 * s) * 4 + i) * 256, acc_a[s][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sl + (size_t)((2 * s + 1) * 4 + i) * 256, acc_b[s][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-        return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                // every thread's partial sums are out (and the ring is no longer read)
+        unsigned* flag = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) *flag = __hip_atomic_fetch_add(a.tile_ticket + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != (unsigned)KS - 1u) return;
+#pragma unroll
+        for (int s = 0; s < SW; ++s) {
+            acc_a[s] = d4{0.0, 0.0, 0.0, 0.0};
+            acc_b[s] = d4{0.0, 0.0, 0.0, 0.0};
+        }
+        for (int k = 0; k < KS; ++k) {                  // fixed order
+            const double* sk = a.slab + ((size_t)tile * KS + k) * (2 * SW * 4) * 256 + tid;
+#pragma unroll
+            for (int s = 0; s < SW; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc_a[s][i] += __hip_atomic_load(sk + (size_t)((2 * s) * 4 + i) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc_b[s][i] += __hip_atomic_load(sk + (size_t)((2 * s + 1) * 4 + i) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
+        if (tid == 0) __hip_atomic_store(a.tile_ticket + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     ring_epilogue<Model, SW>(a, acc_a, acc_b, inst0, i0, s0, wid, r16, kq);
 }

@@ -552,14 +552,32 @@ def test_every_mfma_defect_kernel_variant_matches_the_oracle(built, sym_ct, shap
     check(c, ev, one, ref)
     assert np.array_equal(ev.eval_host(X, U)[2], one[2])              # COST: fixed summation order
     ev.set_option("overlap_mode", 2)
-    if sym_ct == 5:          # split-K: partial sums through the slab, combined in slice order by the second launch
+    if sym_ct in (5, 6, 7, 8):
+        # split-K: partial sums through the slab, combined in slice order -- by the workgroup that draws a tile's last
+        # ticket (default) or by a second launch ("sym_combine" 0): bitwise the same, and reproducible
         for ks in (2, 4, 8):
             ev.set_option("sym_ksplit", ks)
+            ev.set_option("sym_combine", 1)
             got2 = ev.eval_host(X, U)
-            assert "K slices" in ev.last_defect_kernel or M // 16 // ks < 2
+            split = "K slices" in ev.last_defect_kernel
+            assert split or M // 16 // ks < 2 or (M // 16 // ks) % 2
+            assert not split or "in-kernel" in ev.last_defect_kernel
             check(c, ev, got2, ref)
             again = ev.eval_host(X, U)
             assert np.array_equal(again[0], got2[0])          # fixed summation order: bitwise reproducible
+            ev.set_option("sym_combine", 0)
+            got3 = ev.eval_host(X, U)
+            assert not split or "combine_kernel" in ev.last_defect_kernel
+            assert np.array_equal(got3[0], got2[0])
+            ev.set_option("sym_combine", 1)
+            ev.set_option("overlap_mode", 3)                  # ... and as one launch
+            got4 = ev.eval_host(X, U)
+            if M == 1024:
+                assert "one launch" in ev.last_defect_kernel and "K slices" in ev.last_defect_kernel, ev.last_defect_kernel
+                assert np.array_equal(got4[0], got2[0])
+            check(c, ev, got4, ref)
+            ev.set_option("overlap_mode", 2)
+        ev.set_option("sym_ksplit", 0)
     ev.close()
 
 

@@ -43,6 +43,14 @@ VARIANTS = {
     "one_launch_sw1": dict(sym_ct=7, overlap_mode=3, node_store=-1),
     "one_launch_sw2_plain": dict(sym_ct=6, overlap_mode=3, node_store=0),
     "one_launch_sw1_nt": dict(sym_ct=7, overlap_mode=3, node_store=2),
+    "one_launch_sw1_ks2": dict(sym_ct=7, overlap_mode=3, node_store=-1, sym_ksplit=2),
+    "one_launch_sw2_ks2": dict(sym_ct=6, overlap_mode=3, node_store=-1, sym_ksplit=2),
+    "one_launch_sw2_ks4": dict(sym_ct=6, overlap_mode=3, node_store=-1, sym_ksplit=4),
+    "one_launch_sw3_ks2": dict(sym_ct=8, overlap_mode=3, node_store=-1, sym_ksplit=2),
+    "one_launch_sw6_ks4": dict(sym_ct=5, overlap_mode=3, node_store=-1, sym_ksplit=4),
+    "one_launch_sw1_ks1": dict(sym_ct=7, overlap_mode=3, node_store=-1, sym_ksplit=1),
+    "sw2_ks2_conc_ticket": dict(sym_ct=6, sym_ksplit=2, overlap_mode=2, node_store=-1),
+    "sw6_ks4_conc_kernel": dict(sym_ct=5, sym_ksplit=4, overlap_mode=2, node_store=-1, sym_combine=0),
     "one_launch_sw1_nst4": dict(sym_ct=7, overlap_mode=3, node_store=-1, sym_nst=4),
     "one_launch_sw2_nst4": dict(sym_ct=6, overlap_mode=3, node_store=-1, sym_nst=4),
     "one_launch_sw1_nst4_nt": dict(sym_ct=7, overlap_mode=3, node_store=2, sym_nst=4),
@@ -94,6 +102,7 @@ def main():
         ev.set_option("sym_ksplit", 0)
         ev.set_option("sym_nst", 3)
         ev.set_option("cost_in_kernel", 1)
+        ev.set_option("sym_combine", 1)
         for k, v in opts.items():
             ev.set_option(k, v)
 
