@@ -95,7 +95,8 @@ def cpu_baseline(M, n_obs, budget_s=10.0):
 
 def measure(ev, dX, dU, outs, steps, warmup, barrier, torch):
     """W untimed passes (profiled at level 1 to find the dominant kernel), then exactly `steps` passes between
-    barrier + synchronize, with ONE pair of HIP events per pass around that kernel on its own launch stream."""
+    barrier + synchronize, with ONE pair of HIP events per pass around that kernel on its own launch stream (one-launch
+    pass: one pair around the whole region)."""
     ev.profile(1)
     for _ in range(max(warmup, 1)):
         ev.eval_dev(dX, dU, *outs)
@@ -104,18 +105,29 @@ def measure(ev, dX, dU, outs, steps, warmup, barrier, torch):
     node_w = p["node_ms"] / max(p["node_launches"], 1)
     def_w = p["defect_ms"] / max(p["defect_launches"], 1)
     level = 2 if def_w >= node_w else 3
-    ev.profile(level)
+    # The one-launch pass is ONE kernel per pass: its average duration comes from two HIP events on the launch stream
+    # around the whole timed region (emi_timer_start / emi_timer_stop), not from a bracket per pass -- two event records
+    # per pass cost ~8 us of a 44 us pass at 128 instances.  (The span includes the gaps between consecutive launches,
+    # 2-3 us each: it overstates the kernel's duration a little, never understates it.)
+    one_launch = "emi_pass_f64_kernel" in ev.last_defect_kernel
+    ev.profile(0 if one_launch else level)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if one_launch:
+        ev.timer_start()
     for _ in range(steps):
         ev.eval_dev(dX, dU, *outs)
+    span_ms = ev.timer_stop() if one_launch else None      # (synchronises the evaluator's stream)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-    q = ev.profile_read()
-    ev.profile(0)
-    dom_ms = (q["defect_ms"] / max(q["defect_launches"], 1)) if level == 2 else (q["node_ms"] / max(q["node_launches"], 1))
+    if one_launch:
+        dom_ms, level = span_ms / steps, 2
+    else:
+        q = ev.profile_read()
+        ev.profile(0)
+        dom_ms = (q["defect_ms"] / max(q["defect_launches"], 1)) if level == 2 else (q["node_ms"] / max(q["node_launches"], 1))
     return dict(seconds=t1 - t0, dominant="defect" if level == 2 else "node", dominant_ms=dom_ms,
                 warm_node_ms=node_w, warm_defect_ms=def_w, overlapped=p["overlapped_passes"] > 0)
 
@@ -275,11 +287,22 @@ def main():
             ach = flops / (m["dominant_ms"] * 1e-3) / 1e12
             roof = {"kernel": def_name, "bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": ach / peak_tf, "traffic": traffic.get(def_name.split("<")[0]), "avg_ms": m["dominant_ms"]}
+            if "emi_pass_f64_kernel" in def_name:
+                # the one-launch pass: the same kernel also moves the pass's bytes -- the roof it is closer to is reported as
+                # the bound, the other one beside it
+                hb = alg_bytes / (m["dominant_ms"] * 1e-3) / 1e9
+                other = {"bound": "hbm", "achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS}
+                if other["frac"] > roof["frac"]:
+                    mf = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+                    roof.update(other)
+                    other = mf
+                roof["second_roof"] = other
         roof["kernels_ms_warmup"] = {node_name: m["warm_node_ms"], def_name: m["warm_defect_ms"]}
         roof["concurrent"] = m["overlapped"]
         roof["pass_hbm_frac"] = alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
-        roof["note"] = ("avg_ms: HIP events around the dominant kernel on its launch stream, every pass of the timed region; "
-                        "kernels_ms_warmup: both kernels bracketed during the warm-up passes")
+        roof["note"] = ("avg_ms: HIP events on the launch stream -- around the dominant kernel in every pass of the timed region, "
+                        "or (one-launch pass: one kernel per pass) around the whole timed region / steps; "
+                        "kernels_ms_warmup: the kernels bracketed during the warm-up passes")
         if c5:
             workload = (f"config[4]: 12-state fixed-wing VGP, N={M} LGL nodes, fp32 path with MFMA D.X defect, "
                         f"{B} instances per GPU")

@@ -683,11 +683,14 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
         const int tiles16 = ((c->B + 15) / 16) * (c->M / 128);
         const bool auto_mode = c->overlap_mode == 0;
-        if ((c->overlap_mode == 3 || (auto_mode && tiles16 < 192)) && !c->rtc && jac) {
+        if ((c->overlap_mode == 3 || (auto_mode && (tiles16 < 192 || tiles16 >= 384))) && !c->rtc && jac) {
             // The pass as ONE launch: MFMA-role and node-role workgroups in one grid, COST finished in-kernel.
-            // Chosen by itself for small batches, where the fork / join of the two-stream form costs as much as a
-            // kernel (B = 128: 0.055 ms against 0.060; B = 256: 0.081 against 0.090; from B = 512 the two streams win,
-            // 0.130 against 0.167: profiles/r02_pass_variants.json).
+            // Chosen by itself for small batches, where the fork / join of the two-stream form costs as much as a kernel
+            // (B = 128: 0.044 ms against 0.055; B = 256: 0.074 against 0.077), and -- since the MFMA role is software-
+            // pipelined and needs 90 registers -- for large ones, where the two-stream form leaves the chip idle between
+            // passes and deals the two kernels' workgroups less evenly (one process, interleaved rounds, ms per pass:
+            // B = 896 0.218 against 0.251, B = 1024 0.246 against 0.277, B = 2048 0.470 against 0.514); in between
+            // (B = 512 .. 768) the two streams are level or ahead (0.119 against 0.128 at 512): profiles/r02_pass_variants.json.
             emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, 1);
             if (auto_mode && (c->sym_ct == 0 || c->sym_ct == 4))
                 plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 <= 96 ? 7 : 6, 1);        // SW = 1 / 2

@@ -96,8 +96,8 @@ static hipError_t launch_ring2_model(const SymDefectArgs& a, hipStream_t s) {
 //      kernel's waves the room they need on every CU (pass 0.24-0.25 ms against 0.26-0.27 with 60 KB workgroup pairs);
 //   320 .. 447 tiles (B = 768): SW = NS, all workgroups resident at once, two per CU (0.172 ms against 0.198);
 //   192 .. 319 tiles (B = 512): the one-workgroup-per-CU ring kernel, whose grid is then a single round;
-//   fewer (the shard of config 4: 128 instances = 64 tiles for 256 CUs): SW = NS with the K range of a tile cut
-//      into 4 (<= 96 tiles) or 2 slices, combined in slice order by a second launch.
+//   fewer (the shard of config 4: 128 instances = 64 tiles for 256 CUs): SW = 1 (<= 96 tiles) or 2, i.e. more workgroups
+//      than CUs (0.055 ms at 128 instances; SW = NS with 4 K slices, the choice before the K loop was software-pipelined: 0.089).
 // ct 5 / 6 / 7 / 8 force SW = NS / 2 / 1 / 3; ksplit_opt > 0 forces the slice count.
 SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt) {
     SymPlan p;
@@ -107,7 +107,7 @@ SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt) {
         if (tiles >= 448) p.sw = (ns % 2 == 0 && ns > 2) ? 2 : ns;
         else if (tiles >= 320) p.sw = ns;
         else if (tiles >= 192) { p.ring1 = true; return p; }
-        else { p.sw = ns; p.ks = tiles <= 96 ? 4 : 2; }
+        else p.sw = (tiles <= 96 || ns % 2 != 0 || ns <= 2) ? 1 : 2;
     } else if (ct >= 5 && ct <= 8) {
         p.sw = ct == 5 ? ns : (ct == 6 ? 2 : (ct == 8 ? 3 : 1));
         if (ns % p.sw != 0) p.sw = 1;

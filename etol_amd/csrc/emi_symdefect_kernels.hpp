@@ -358,10 +358,14 @@ __global__ __launch_bounds__(256, 2) void emi_symdefect_ring_f64_kernel(SymDefec
 EMI_DEV constexpr int ring_swz(int r) { return (0 - (r >> 2)) & 3; }
 
 // defect = D.X - h f at the tile's output nodes: forward node i (a + b) and mirrored node N-i (b - a), states
-// s0 .. s0+SW-1; lane (r16, kq) of wave wid holds half-index column 16 wid + r16 and instances kq + 4 i.
-template <class Model, int SW>
-EMI_DEV void ring_epilogue(const SymDefectArgs& a, const d4 (&acc_a)[SW], const d4 (&acc_b)[SW], int inst0, int i0,
-                           int s0, int wid, int r16, int kq) {
+// S0 .. S0+SW-1; lane (r16, kq) of wave wid holds half-index column 16 wid + r16 and instances kq + 4 i.
+// S0 is a template parameter: with the state group known at compile time only the components of f this workgroup
+// writes are computed and only the variables they depend on are loaded (6-state quadrotor, SW = 2: the group (x, y)
+// needs v_x, v_y and no sine / cosine at all; measured with the epilogue switched off, it was 13 % of the pass at 1024
+// instances when every group evaluated all of f: tools/diag/x_traffic_probe.py).
+template <class Model, int SW, int S0>
+EMI_DEV void ring_epilogue_s0(const SymDefectArgs& a, const d4 (&acc_a)[SW], const d4 (&acc_b)[SW], int inst0, int i0,
+                              int wid, int r16, int kq) {
     constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
     const int M = a.M, B = a.B;
     const int col = wid * 16 + r16;
@@ -384,15 +388,18 @@ EMI_DEV void ring_epilogue(const SymDefectArgs& a, const d4 (&acc_a)[SW], const 
             Model::f(a.P, z, a.node_t[node], f);
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
-                double fs = f[s];                       // f[s0 + s] without a runtime register index
-                if (SW < NS) {
-#pragma unroll
-                    for (int v = 0; v < NS; ++v) fs = (v == s0 + s) ? f[v] : fs;
-                }
                 const double dx = side == 0 ? acc_a[s][i] + acc_b[s][i] : acc_b[s][i] - acc_a[s][i];
-                Rb[(size_t)(s0 + s) * M + node] = dx - a.h * fs;
+                Rb[(size_t)(S0 + s) * M + node] = dx - a.h * f[S0 + s];
             }
         }
+    }
+}
+template <class Model, int SW, int SG = 0>
+EMI_DEV void ring_epilogue(const SymDefectArgs& a, const d4 (&acc_a)[SW], const d4 (&acc_b)[SW], int inst0, int i0,
+                           int s0, int wid, int r16, int kq) {
+    if constexpr (SG * SW < Model::NS) {
+        if (s0 == SG * SW) ring_epilogue_s0<Model, SW, SG * SW>(a, acc_a, acc_b, inst0, i0, wid, r16, kq);
+        else ring_epilogue<Model, SW, SG + 1>(a, acc_a, acc_b, inst0, i0, s0, wid, r16, kq);
     }
 }
 
@@ -443,6 +450,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
             const int c = p ^ ring_swz(rr);
             int inst = inst0 + (rr & 15);
             inst = inst < B ? inst : B - 1;            // rows past the batch are never written out
+            if (a.ablate & 8) inst &= 15;              // diagnostics: every tile reads the first 16 instances (X traffic ~ 0)
             voff[t] = (unsigned)((((size_t)inst * NS + s0 + (rr >> 4)) * M + 2 * c) * sizeof(double));
             gbase[t] = (unsigned long long)(a.X + (mir ? M - BK : 0));
             gstep[t] = mir ? -(int)(BK * sizeof(double)) : (int)(BK * sizeof(double));

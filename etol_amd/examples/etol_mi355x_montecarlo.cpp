@@ -142,7 +142,7 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
     if (ndiscs > 0) t->setConstraints({&obs});
     solver.getAlgorithm()->device = device;
     t->setup();
-    solver.getAlgorithm()->nlp_tolerance = 1e-7;
+    solver.getAlgorithm()->nlp_tolerance = getenv("EMI_MC_TOL") ? atof(getenv("EMI_MC_TOL")) : 1e-7;   // (ePSOPT.cpp:67 sets 1e-6)
     solver.getAlgorithm()->nlp_iter_max = 400;
     solver.getAlgorithm()->mesh_refinement = "none";
     solver.getAlgorithm()->print_level = env_int("EMI_MC_PRINT_LEVEL", 0);
