@@ -15,7 +15,7 @@ LIBDIR    := etol_amd/lib
 CSRC      := etol_amd/csrc
 HOST      := etol_amd/host
 
-HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-inline-asm
+HIPFLAGS  := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function -Wno-inline-asm $(EXTRA_HIPFLAGS)
 CXXFLAGS  := -O2 -std=c++17 -fPIC -Iinclude -Wall
 XML2_INC  := -I/usr/include/libxml2
 XML2_LIB  := -lxml2

@@ -370,6 +370,10 @@ EMI_DEV void ring_epilogue_s0(const SymDefectArgs& a, const d4 (&acc_a)[SW], con
     const int M = a.M, B = a.B;
     const int col = wid * 16 + r16;
     const int node_f = i0 + col, node_m = M - 1 - node_f;
+    const double t_f = a.node_t[node_f], t_m = a.node_t[node_m];
+    // one instance (two nodes: forward and mirrored) at a time: with all eight (instance, node) pairs of a lane in
+    // flight at once the kernel needs 184 registers instead of 90 (SW = 2) and loses more to occupancy than the single
+    // memory round trip gains (0.2475 against 0.2394 ms per pass at 1024 instances)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int inst = inst0 + kq + 4 * i;
@@ -377,6 +381,7 @@ EMI_DEV void ring_epilogue_s0(const SymDefectArgs& a, const d4 (&acc_a)[SW], con
         const double* __restrict__ Xb = a.X + (size_t)inst * NS * M;
         const double* __restrict__ Ub = a.U + (size_t)inst * NC * M;
         double* __restrict__ Rb = a.RES + (size_t)inst * a.nres * M;
+        double hf[2][SW];
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             const int node = side == 0 ? node_f : node_m;
@@ -385,11 +390,17 @@ EMI_DEV void ring_epilogue_s0(const SymDefectArgs& a, const d4 (&acc_a)[SW], con
             for (int v = 0; v < NS; ++v) z[v] = Xb[(size_t)v * M + node];
 #pragma unroll
             for (int v = 0; v < NC; ++v) z[NS + v] = Ub[(size_t)v * M + node];
-            Model::f(a.P, z, a.node_t[node], f);
+            Model::f(a.P, z, side == 0 ? t_f : t_m, f);
+#pragma unroll
+            for (int s = 0; s < SW; ++s) hf[side][s] = a.h * f[S0 + s];
+        }
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int node = side == 0 ? node_f : node_m;
 #pragma unroll
             for (int s = 0; s < SW; ++s) {
                 const double dx = side == 0 ? acc_a[s][i] + acc_b[s][i] : acc_b[s][i] - acc_a[s][i];
-                Rb[(size_t)(S0 + s) * M + node] = dx - a.h * f[S0 + s];
+                Rb[(size_t)(S0 + s) * M + node] = dx - hf[side][s];
             }
         }
     }
@@ -703,8 +714,16 @@ struct PassArgs {
     int nbx;                // node chunks per instance
 };
 
+#ifndef EMI_PASS_WAVES_PER_EU
+#define EMI_PASS_WAVES_PER_EU 0         // build-time experiment switch (tools/ab_build.sh): register cap of the pass kernel as waves per SIMD
+#endif
+#if EMI_PASS_WAVES_PER_EU > 0
+#define EMI_PASS_OCC __attribute__((amdgpu_waves_per_eu(EMI_PASS_WAVES_PER_EU, EMI_PASS_WAVES_PER_EU)))
+#else
+#define EMI_PASS_OCC
+#endif
 template <class Model, int SW, int VEC, int ST, int NST = 3>
-__global__ __launch_bounds__(256, 2) void emi_pass_f64_kernel(PassArgs a) {
+__global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs a) {
     const int g = blockIdx.x, xcd = g & 7, j = g >> 3, t8 = a.nm8 + a.nn8;
     const int m0 = (int)(((long long)j * a.nm8) / t8), m1 = (int)(((long long)(j + 1) * a.nm8) / t8);
     if (m1 > m0) {
