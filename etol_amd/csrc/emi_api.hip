@@ -85,6 +85,7 @@ struct emi_ctx_s {
     int sym_nst = 3;            // "sym_nst": ring stages of the one-launch pass (3 or 4)
     int slice_first = 0;        // first instance of the slice emi_eval_dev is working on (per-instance tables are offset by it)
     int sym_ksplit = 0;         // "sym_ksplit" option: K slices per tile of the state-split ring kernel (0: by batch size)
+    int sym_cpart = 0;          // "sym_cpart" option: column partitions of the tile order (0: by mesh size, -1: plain order, 1/2/4/8)
     int sym_combine = 1;        // "sym_combine" option: 1 slices combined in-kernel by ticket, 0 by emi_symdefect_combine_kernel
     // host-form staging
     DevBuf s_X, s_U, s_RES, s_VALS, s_COST, s_LF, s_LC, s_H;
@@ -677,7 +678,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         emi::SymDefectArgs sa;
         sa.X = (const double*)dX; sa.U = (const double*)dU; sa.RES = (double*)dRES;
         sa.node_t = (const double*)c->d_t.p; sa.De = (const double*)c->d_De.p; sa.Do = (const double*)c->d_Do.p;
-        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0; sa.order = c->sym_order; sa.ablate = c->sym_ablate; sa.ksplit = 1; sa.slab = nullptr; sa.tile_ticket = nullptr;
+        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0; sa.order = c->sym_order; sa.ablate = c->sym_ablate; sa.ksplit = 1; sa.slab = nullptr; sa.tile_ticket = nullptr; sa.cpart = sa.cx = 0;
         for (int i = 0; i < EMI_MAX_PARAMS; ++i) sa.P.p[i] = c->params[i];
         emi::NodeArgs<double> na;
         fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
@@ -691,22 +692,23 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             // passes and deals the two kernels' workgroups less evenly (one process, interleaved rounds, ms per pass:
             // B = 896 0.218 against 0.251, B = 1024 0.246 against 0.277, B = 2048 0.470 against 0.514); in between
             // (B = 512 .. 768) the two streams are level or ahead (0.119 against 0.128 at 512): profiles/r02_pass_variants.json.
-            emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, 1);
+            emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, 1, c->sym_cpart);
             if (auto_mode && (c->sym_ct == 0 || c->sym_ct == 4))
-                plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 <= 96 ? 7 : 6, 1);        // SW = 1 / 2
-            else if (plan.ring1) plan = emi::plan_symdefect(c->ns, c->B, c->M, 5, 1);
+                plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 <= 96 ? 7 : 6, 1, c->sym_cpart);        // SW = 1 / 2
+            else if (plan.ring1) plan = emi::plan_symdefect(c->ns, c->B, c->M, 5, 1, c->sym_cpart);
             plan.nst = c->sym_nst;
             if (c->sym_ksplit > 1) {
                 // "sym_ksplit": the K range of a tile cut into slices, their partial sums combined in-kernel by ticket.
                 // Not chosen by itself: at 128 instances SW = 2 x 2 slices 0.0437 ms against SW = 1 unsplit 0.0446 -- the
                 // fixed parts of the MFMA role (launch, prologue, epilogue: ~15 us) are what a small pass waits for
                 const int ct_now = plan.sw == c->ns ? 5 : (plan.sw == 2 ? 6 : (plan.sw == 3 ? 8 : 7));
-                plan = emi::plan_symdefect(c->ns, c->B, c->M, ct_now, c->sym_ksplit);
+                plan = emi::plan_symdefect(c->ns, c->B, c->M, ct_now, c->sym_ksplit, c->sym_cpart);
                 plan.nst = c->sym_nst;
             } else {
                 plan.ks = 1;
             }
             if (emi::pass_supported(c->model, c->ns, c->B, c->M, plan)) {
+                sa.cpart = plan.cpart; sa.cx = plan.cx;
                 if (plan.ks > 1) {
                     int est = ensure(c, c->d_slab, plan.slab_bytes);
                     if (est) return est;
@@ -749,13 +751,14 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             HIP_TRY(c, emi::rtc_launch_symdefect(c->rtc, sa, s1));
             c->last_defect_kernel = "emi_symdefect_ring_f64_kernel";
         } else {
-            const emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, c->sym_ksplit);
+            const emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, c->sym_ksplit, c->sym_cpart);
             if (plan.slab_bytes) {
                 int est = ensure(c, c->d_slab, plan.slab_bytes);
                 if (est) return est;
             }
             sa.ksplit = plan.ring1 ? 1 : plan.ks;
             sa.slab = (double*)c->d_slab.p;
+            sa.cpart = plan.cpart; sa.cx = plan.cx;
             if (sa.ksplit > 1 && c->sym_combine) {
                 if (c->d_tile_ticket.bytes < (size_t)plan.tiles * 4) {
                     int est = ensure(c, c->d_tile_ticket, (size_t)plan.tiles * 4);
@@ -1106,6 +1109,11 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
     if (strcmp(name, "sym_nst") == 0) {
         if (value != 3 && value != 4) return fail(c, EMI_ERR_ARG, "sym_nst must be 3 or 4");
         c->sym_nst = value;
+        return EMI_OK;
+    }
+    if (strcmp(name, "sym_cpart") == 0) {
+        if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, EMI_ERR_ARG, "sym_cpart must be -1 (plain order), 0 (by mesh size), 1, 2, 4 or 8");
+        c->sym_cpart = value;
         return EMI_OK;
     }
     if (strcmp(name, "sym_combine") == 0) { c->sym_combine = value != 0; return EMI_OK; }

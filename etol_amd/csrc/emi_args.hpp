@@ -74,12 +74,16 @@ struct SymDefectArgs {
     const double* Do;       // [M/2][M/2]  (D[i][j] - D[i][N-j]) / 2
     int M, B, nres;
     int order;              // block -> tile order within an XCD (see emi_symdefect.hip)
-    int ablate;             // diagnostics (results invalid): 4 skip epilogue, 8 all tiles read the X rows of the first 16 instances
+    int ablate;             // diagnostics (results invalid): 4 skip epilogue, 8 all tiles read the X rows of the first 16 instances,
+                            // 16 / 32 the MFMA / node role of the one-launch pass returns at once
                             // (1 skip MFMAs, 2 skip operand DMA: the round-1 ring kernel only)
     int ksplit;             // state-split ring kernel: K slices per tile (1 = none); > 1 goes through `slab`
     double* slab;           // [tiles][ksplit][2 SW][4][256] partial sums of a split-K launch
     unsigned* tile_ticket;  // [tiles] zero before the first launch, self-resetting: the slices of a tile are combined by the
                             // workgroup that draws the tile's last ticket (nullptr: emi_symdefect_combine_kernel does it)
+    int cpart, cx;          // tile order of the state-split ring kernel (plan_symdefect): the column tiles are cut into cpart
+                            // partitions, one per group of 8 / cpart XCDs, and cx column tiles of an X tile run as neighbours
+                            // (cpart = 0: plain order, the column tiles of an X tile as neighbours, X tiles dealt over the XCDs)
     double h;
     ModelParams<double> P;
 };

@@ -99,7 +99,7 @@ static hipError_t launch_ring2_model(const SymDefectArgs& a, hipStream_t s) {
 //   fewer (the shard of config 4: 128 instances = 64 tiles for 256 CUs): SW = 1 (<= 96 tiles) or 2, i.e. more workgroups
 //      than CUs (0.055 ms at 128 instances; SW = NS with 4 K slices, the choice before the K loop was software-pipelined: 0.089).
 // ct 5 / 6 / 7 / 8 force SW = NS / 2 / 1 / 3; ksplit_opt > 0 forces the slice count.
-SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt) {
+SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_opt) {
     SymPlan p;
     const int tiles = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64);
     const int nkt = (M / 2) / 8;
@@ -118,6 +118,21 @@ SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt) {
     if (ksplit_opt > 0) p.ks = ksplit_opt;
     while (p.ks > 1 && (nkt % p.ks != 0 || nkt / p.ks < 2 || (nkt / p.ks) % 2 != 0)) p.ks >>= 1;
     p.tiles = tiles * (ns / p.sw);
+    {   // tile order: the share of De / Do an XCD works on should stay in its 4 MB L2 beside everything else (<= 2 MB)
+        const int ntiles = (M / 2) / 64, ngrp = ((B + FUSED_TI - 1) / FUSED_TI) * (ns / p.sw);
+        const int target_cols = std::max(1, 4096 / M);          // column tiles whose two panels (512 M bytes each) make 2 MB
+        auto valid = [&](int cp) { return cp >= 1 && cp <= 8 && ntiles % cp == 0 && ngrp % (8 / cp) == 0 && (ngrp * ntiles) % 8 == 0; };
+        int cp = 0;
+        if (cpart_opt > 0) cp = valid(cpart_opt) ? cpart_opt : 0;
+        else if (cpart_opt == 0 && tiles >= 192)    // (small batches: an XCD's few tiles do not walk the panels often enough to matter)
+            for (int c = 1; c <= 8 && !cp; c *= 2)
+                if (valid(c) && (ntiles / c <= target_cols || c == 8 || !valid(2 * c))) cp = c;
+        if (cp > 0) {
+            p.cpart = cp;
+            p.cx = std::min(ntiles / cp, target_cols);
+            if (cp == 1 && p.cx == ntiles) p.cpart = p.cx = 0;   // that is the plain order
+        }
+    }
     if (p.ks > 1) p.slab_bytes = (size_t)p.tiles * p.ks * (2 * p.sw * 4) * 256 * sizeof(double);
     return p;
 }

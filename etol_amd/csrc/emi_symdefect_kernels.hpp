@@ -433,9 +433,31 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     const int M = a.M, Hh = M >> 1, B = a.B;
     const int ntiles = Hh / TN;
     const int KS = a.ksplit > 1 ? a.ksplit : 1;
-    const int kslice = bid % KS, tile = bid / KS;
-    // the ntiles workgroups that share one X tile (same instance group, same states) are neighbours: one XCD's L2
-    const int ntile = tile % ntiles, grp = tile / ntiles;
+    const int kslice = bid % KS;
+    // Which tile.  bid / KS counts tiles in XCD-local runs (an XCD gets a contiguous range).  Plain order: the ntiles
+    // column tiles of an X tile (same instance group, same states) are neighbours, so an XCD's L2 sees each X tile once --
+    // but every XCD then walks ALL of De / Do (4 MB at 1024 nodes = the whole L2 of an XCD), and beside the node role's
+    // store stream the panels are fetched again and again: 12 % of the pass at 1024 instances (tools/diag/x_traffic_probe.py:
+    // 0.2408 ms against 0.2107 with all tiles reading the same 64 rows).  Partitioned order (a.cpart > 0): XCD x works on
+    // column partition x % cpart only (its share of De / Do stays in L2) and on group partition x / cpart; X tiles are then
+    // read by cpart XCDs instead of one, which costs little (they come from the Infinity Cache).
+    int ntile, grp;
+    {
+        const int tl = bid / KS;
+        if (a.cpart > 0) {
+            const int ngrp = (B + TI - 1) / TI * NSG, per_xcd = ngrp * ntiles / 8;
+            const int x = tl / per_xcd, m = tl - x * per_xcd;
+            const int pc = x % a.cpart, pg = x / a.cpart;
+            const int ncol = ntiles / a.cpart, ng = ngrp / (8 / a.cpart);
+            const int cb = m / (ng * a.cx), r = m - cb * ng * a.cx;
+            grp = pg * ng + r / a.cx;
+            ntile = pc * ncol + cb * a.cx + r % a.cx;
+        } else {
+            ntile = tl % ntiles;
+            grp = tl / ntiles;
+        }
+    }
+    const int tile = grp * ntiles + ntile;              // slab / ticket index
     const int sg = grp % NSG, mtile = grp / NSG;
     const int inst0 = mtile * TI, i0 = ntile * TN, s0 = sg * SW;
 
@@ -469,7 +491,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
             const bool od = row0 >= 2 * TM + TN;
             const int rr = row - 2 * TM - (od ? TN : 0);
             const int c = p ^ ring_swz(rr);
-            voff[t] = (unsigned)(((size_t)(i0 + rr) * Hh + 2 * c) * sizeof(double));
+            voff[t] = (unsigned)(((size_t)((a.ablate & 64) ? rr : i0 + rr) * Hh + 2 * c) * sizeof(double));   // (64: diagnostics, all tiles read the first 64 rows)
             gbase[t] = (unsigned long long)(od ? a.Do : a.De);
             gstep[t] = (int)(BK * sizeof(double));
         } else {                                       // padding rows of the last DMA instruction: never read
@@ -726,6 +748,7 @@ template <class Model, int SW, int VEC, int ST, int NST = 3>
 __global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs a) {
     const int g = blockIdx.x, xcd = g & 7, j = g >> 3, t8 = a.nm8 + a.nn8;
     const int m0 = (int)(((long long)j * a.nm8) / t8), m1 = (int)(((long long)(j + 1) * a.nm8) / t8);
+    if (a.s.ablate & (m1 > m0 ? 16 : 32)) return;    // diagnostics: one of the two roles does nothing
     if (m1 > m0) {
         // the MFMA role is the latency chain of a small pass (64 dependent K tiles); the streaming role beside it on the
         // same SIMDs waits on memory most of the time: instruction arbitration goes to the MFMA waves first

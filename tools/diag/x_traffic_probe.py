@@ -18,8 +18,15 @@ def run(opts, n=300):
     for _ in range(n): ev.eval_dev(dX, dU, *outs)
     torch.cuda.synchronize(); return 1e3 * (time.perf_counter() - t0) / n
 for r in range(3):
-    for name, o in [("one_launch_sw2", dict(overlap_mode=3, sym_ct=6, sym_ablate=0)), ("one_launch_sw2 X->16 inst", dict(overlap_mode=3, sym_ct=6, sym_ablate=8)),
-                    ("one_launch_sw2 no epilogue", dict(overlap_mode=3, sym_ct=6, sym_ablate=4)), ("one_launch_sw2 both", dict(overlap_mode=3, sym_ct=6, sym_ablate=12)),
-                    ("two streams sw2", dict(overlap_mode=2, sym_ct=6, sym_ablate=0)), ("two streams sw2 X->16", dict(overlap_mode=2, sym_ct=6, sym_ablate=8)),
-                    ("sequential sw2", dict(overlap_mode=1, sym_ct=6, sym_ablate=0)), ("sequential sw2 X->16", dict(overlap_mode=1, sym_ct=6, sym_ablate=8))]:
-        print(f"B={B} {name:32s} {run(o):.4f} ms")
+    for name, o in [("one launch sw2", dict(overlap_mode=3, sym_ct=6, sym_ablate=0)),
+                    ("  X -> 16 instances", dict(overlap_mode=3, sym_ct=6, sym_ablate=8)),
+                    ("  De/Do -> first 64 rows", dict(overlap_mode=3, sym_ct=6, sym_ablate=64)),
+                    ("  both", dict(overlap_mode=3, sym_ct=6, sym_ablate=72)),
+                    ("  no epilogue stores", dict(overlap_mode=3, sym_ct=6, sym_ablate=4)),
+                    ("  node role only", dict(overlap_mode=3, sym_ct=6, sym_ablate=16)),
+                    ("  MFMA role only", dict(overlap_mode=3, sym_ct=6, sym_ablate=32)),
+                    ("  MFMA role only, no epilogue stores", dict(overlap_mode=3, sym_ct=6, sym_ablate=36)),
+                    ("  neither role (launch + dispatch)", dict(overlap_mode=3, sym_ct=6, sym_ablate=48)),
+                    ("two streams sw2", dict(overlap_mode=2, sym_ct=6, sym_ablate=0)),
+                    ("sequential sw2", dict(overlap_mode=1, sym_ct=6, sym_ablate=0))]:
+        print(f"B={B} {name:40s} {run(o):.4f} ms")

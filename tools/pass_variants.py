@@ -51,6 +51,17 @@ VARIANTS = {
     "one_launch_sw1_ks1": dict(sym_ct=7, overlap_mode=3, node_store=-1, sym_ksplit=1),
     "sw2_ks2_conc_ticket": dict(sym_ct=6, sym_ksplit=2, overlap_mode=2, node_store=-1),
     "sw6_ks4_conc_kernel": dict(sym_ct=5, sym_ksplit=4, overlap_mode=2, node_store=-1, sym_combine=0),
+    "one_launch_sw2_plain_order": dict(sym_ct=6, overlap_mode=3, node_store=-1, sym_cpart=-1),
+    "one_launch_sw2_cpart2": dict(sym_ct=6, overlap_mode=3, node_store=-1, sym_cpart=2),
+    "one_launch_sw2_cpart4": dict(sym_ct=6, overlap_mode=3, node_store=-1, sym_cpart=4),
+    "one_launch_sw2_cpart8": dict(sym_ct=6, overlap_mode=3, node_store=-1, sym_cpart=8),
+    "one_launch_sw3_cpart4": dict(sym_ct=8, overlap_mode=3, node_store=-1, sym_cpart=4),
+    "one_launch_sw1_plain_order": dict(sym_ct=7, overlap_mode=3, node_store=-1, sym_cpart=-1),
+    "one_launch_sw1_cpart4": dict(sym_ct=7, overlap_mode=3, node_store=-1, sym_cpart=4),
+    "one_launch_sw1_cpart8": dict(sym_ct=7, overlap_mode=3, node_store=-1, sym_cpart=8),
+    "sw2_conc_plain_order": dict(sym_ct=6, overlap_mode=2, node_store=2, sym_cpart=-1),
+    "sw2_conc_cpart4": dict(sym_ct=6, overlap_mode=2, node_store=2, sym_cpart=4),
+    "sw6_conc_cpart4": dict(sym_ct=5, overlap_mode=2, node_store=2, sym_cpart=4),
     "one_launch_sw1_nst4": dict(sym_ct=7, overlap_mode=3, node_store=-1, sym_nst=4),
     "one_launch_sw2_nst4": dict(sym_ct=6, overlap_mode=3, node_store=-1, sym_nst=4),
     "one_launch_sw1_nst4_nt": dict(sym_ct=7, overlap_mode=3, node_store=2, sym_nst=4),
@@ -103,6 +114,7 @@ def main():
         ev.set_option("sym_nst", 3)
         ev.set_option("cost_in_kernel", 1)
         ev.set_option("sym_combine", 1)
+        ev.set_option("sym_cpart", 0)
         for k, v in opts.items():
             ev.set_option(k, v)
 
