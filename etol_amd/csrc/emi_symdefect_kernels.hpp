@@ -374,6 +374,8 @@ EMI_DEV void ring_epilogue_s0(const SymDefectArgs& a, const d4 (&acc_a)[SW], con
     // one instance (two nodes: forward and mirrored) at a time: with all eight (instance, node) pairs of a lane in
     // flight at once the kernel needs 184 registers instead of 90 (SW = 2) and loses more to occupancy than the single
     // memory round trip gains (0.2475 against 0.2394 ms per pass at 1024 instances)
+    // (keeping this loop rolled -- a quarter of the code, 41 KB for the pass kernel otherwise -- changes nothing: 0.2314
+    // against 0.2318 ms, tools/ab_build.sh)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int inst = inst0 + kq + 4 * i;
