@@ -694,7 +694,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             // (B = 512 .. 768) the two streams are level or ahead (0.119 against 0.128 at 512): profiles/r02_pass_variants.json.
             emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, 1, c->sym_cpart);
             if (auto_mode && (c->sym_ct == 0 || c->sym_ct == 4))
-                plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 <= 96 ? 7 : 6, 1, c->sym_cpart);        // SW = 1 / 2
+                plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 < 192 ? 7 : 6, 1, c->sym_cpart);        // SW = 1 (small batches: more workgroups than CUs) / 2
             else if (plan.ring1) plan = emi::plan_symdefect(c->ns, c->B, c->M, 5, 1, c->sym_cpart);
             plan.nst = c->sym_nst;
             if (c->sym_ksplit > 1) {

@@ -278,9 +278,21 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * "overlap_mode": how the two kernels share the chip.  0 (default) = by batch size;
  * 2 = two streams (fork / join through events); 3 = ONE launch, MFMA-role and
  * node-role workgroups in one grid with COST finished in-kernel (chosen below 192
- * tiles, e.g. the 128-instance shard of config 4); 1 = one stream, back to back.
- * "sym_ksplit": K slices of a full-state tile (0 = by batch size; > 1 goes through
- * a slab and a combine launch, summed in slice order).
+ * tiles, e.g. the 128-instance shard of config 4, and from 384 tiles, i.e. from
+ * 768 instances at 1024 nodes); 1 = one stream, back to back.
+ * "sym_ksplit": K slices per tile of the state-split ring (0 = none unless forced;
+ * > 1: partial sums through a slab, summed in slice order).  "sym_combine": 1
+ * (default) the workgroup that draws a tile's last ticket adds the slices
+ * in-kernel, 0 a second launch does; bitwise the same result.
+ * "sym_cpart": tile order of the state-split ring.  0 (default) = by mesh and batch
+ * size; -1 = plain (the column tiles of an X tile are neighbours, X tiles dealt over
+ * the XCDs); 1 / 2 / 4 / 8 = the column tiles cut into that many partitions, each
+ * worked on by 8 / cpart XCDs, so that an XCD's share of De / Do stays in its L2.
+ * "sym_nst": ring stages of the one-launch pass (3 default, 4).
+ * "kkt_*": process-wide switches of emi_kkt_factor ("kkt_sticky_reg" 1 (default):
+ * the Schur path starts at the dual regularisation level that worked last on this
+ * mesh; "kkt_debug", "kkt_cholesky", "kkt_chol_panel", "kkt_batched_max_nodes",
+ * "kkt_potrf_lock": diagnostics, see csrc/emi_kkt.hip).
  * "sym_ablate": diagnostics only, results invalid.                             */
 int emi_set_option(emi_ctx_t ctx, const char* name, int value);
 /* 1 if emi_eval(EMI_EVAL_ALL) currently takes the overlapped path             */
