@@ -508,14 +508,26 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     // paid a full DMA round trip (the ISA of rounds 1-2; profiles/r02_notes.md section 9).  The counted vmcnt waits of
     // the K loop are the only synchronisation with the DMA the ring needs.  m0 = LDS address of the 1 KB the wave writes.
     const unsigned lds0 = (unsigned)(unsigned long)(emi_lds_ptr_t)smem;          // LDS byte address of the ring
-    auto issue_one = [&](int t, int stage, int kt) {
-        const unsigned dst = lds0 + (unsigned)stage * (unsigned)(STAGE * 8) + (unsigned)(wid + 4 * t) * 1024u;   // wave-uniform
-        const unsigned long long g = gbase[t] + (long long)gstep[t] * kt;
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[t]), "s"(g), "s"(dst) : "memory", "m0");
-    };
-    auto issue = [&](int stage, int kt) {
+    // running state of the ring, all wave-uniform (SALU): next tile to request, where it goes, where the next fragment
+    // reads come from -- an add per DMA instruction instead of a 64-bit multiply by the tile index and a modulo
+    const int nkt = (Hh / BK) / KS, kt0 = kslice * nkt;       // this slice's K tiles: kt0 .. kt0 + nkt - 1
+    unsigned long long gnext[L];
 #pragma unroll
-        for (int t = 0; t < L; ++t) issue_one(t, stage, kt);
+    for (int t = 0; t < L; ++t) gnext[t] = gbase[t] + (long long)gstep[t] * kt0;
+    unsigned st_dma = 0, st_rd = 0;     // byte offsets of the stage the next DMA tile / the next fragment reads use
+    int nd = 0;                         // tiles requested so far
+    auto issue_one = [&](int t) {       // instruction t of tile nd; the last one moves the ring on
+        const unsigned dst = lds0 + st_dma + (unsigned)(wid + 4 * t) * 1024u;   // wave-uniform
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[t]), "s"(gnext[t]), "s"(dst) : "memory", "m0");
+        gnext[t] += (long long)gstep[t];
+        if (t == L - 1) {
+            st_dma = st_dma == (unsigned)((NST - 1) * STAGE * 8) ? 0u : st_dma + (unsigned)(STAGE * 8);
+            ++nd;
+        }
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int t = 0; t < L; ++t) issue_one(t);
     };
 
     d4 acc_a[SW], acc_b[SW];
@@ -525,10 +537,9 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         acc_b[s] = d4{0.0, 0.0, 0.0, 0.0};
     }
 
-    const int nkt = (Hh / BK) / KS, kt0 = kslice * nkt;       // this slice's K tiles: kt0 .. kt0 + nkt - 1
 #pragma unroll
     for (int t = 0; t < LOOK; ++t)
-        if (t < nkt) issue(t, kt0 + t);
+        if (t < nkt) issue();
     // fragment addresses (doubles within a stage): B rows of this wave, A rows of every state
     const int rb = wid * 16 + r16;
     const int off_b = rb * BK + ((kq ^ ring_swz(rb)) << 1);
@@ -550,8 +561,13 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         else if (r & 1) f.xm[(r - 2) >> 1] = *reinterpret_cast<const double2*>(S + off_m[(r - 2) >> 1]);
         else f.xf[(r - 2) >> 1] = *reinterpret_cast<const double2*>(S + off_f[(r - 2) >> 1]);
     };
-    auto read_frag = [&](Frag& f, int kt) {
-        const double* S = smem + (size_t)(kt % NST) * STAGE;
+    auto rd_stage = [&]() -> const double* {            // stage of the next fragment set; moves on
+        const double* S = smem + (st_rd >> 3);
+        st_rd = st_rd == (unsigned)((NST - 1) * STAGE * 8) ? 0u : st_rd + (unsigned)(STAGE * 8);
+        return S;
+    };
+    auto read_frag = [&](Frag& f) {
+        const double* S = rd_stage();
 #pragma unroll
         for (int r = 0; r < NR; ++r) read_one(f, S, r);
     };
@@ -585,9 +601,8 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
             else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0), as an instruction the compiler's own wait counting sees
             asm volatile("s_barrier" ::: "memory");     // tile kt+1 has landed for every wave; the stage of tile kt is free
-            const bool more = kt + 1 + LOOK < nkt;
-            const int st = (kt + 1 + LOOK) % NST, ktd = kt0 + kt + 1 + LOOK;
-            const double* S = smem + (size_t)((kt + 1) % NST) * STAGE;
+            const bool more = nd < nkt;                 // (nd == kt + 1 + LOOK while there are tiles left)
+            const double* S = rd_stage();
             // reads first: the next tile's first MFMA needs them, the DMA has LOOK tiles of slack
 #pragma unroll
             for (int i = 0; i < NM; ++i) {
@@ -596,7 +611,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
 #pragma unroll
                     for (int r = i * RPG; r < (i + 1) * RPG && r < NR; ++r) read_one(nxt, S, r);
                 } else if (i < GR + L) {
-                    if (more) issue_one(i - GR, st, ktd);
+                    if (more) issue_one(i - GR);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -605,11 +620,11 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         if (nkt > LOOK - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
         else                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
-        if (LOOK < nkt) issue(LOOK % NST, kt0 + LOOK);
+        if (LOOK < nkt) issue();
         // scalar loads of arguments the epilogue needs are still pending in the compiler's model here; with them pending it
         // turns every fragment wait of the loop into lgkmcnt(0), i.e. waits for the reads it has just issued as well
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        read_frag(f0, 0);
+        read_frag(f0);
         int kt = 0;                                     // nkt is even (M % 128 == 0, ksplit a power of two <= 8)
         for (; kt + 2 < nkt; kt += 2) {
             step(f0, f1, kt);
@@ -625,9 +640,9 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
             if (kt + LOOK - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
             else                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the tail: at most LOOK - 1 tiles early
             asm volatile("s_barrier" ::: "memory");     // every wave's part landed; stage (kt-1) % NST is free
-            if (kt + LOOK < nkt) issue((kt + LOOK) % NST, kt0 + kt + LOOK);
+            if (kt + LOOK < nkt) issue();
             Frag f;
-            read_frag(f, kt);
+            read_frag(f);
             multiply(f);
         }
     }
