@@ -581,6 +581,40 @@ def test_every_mfma_defect_kernel_variant_matches_the_oracle(built, sym_ct, shap
     ev.close()
 
 
+@pytest.mark.parametrize("shape", [(1024, 40), (2048, 24), (512, 72), (256, 128)])
+def test_partitioned_tile_orders_of_the_mfma_role(built, shape):
+    """"sym_cpart": the column tiles of the state-split ring cut into 1 / 2 / 4 / 8 partitions over the XCDs (the default
+    for large batches), against the plain order and the oracle -- for meshes with 2 .. 16 column tiles, batch sizes whose
+    group counts do or do not divide over the XCD groups (the plan then falls back to the plain order), SW = 6 / 2 / 1,
+    two streams and one launch.  Every tile is visited exactly once or rows of the result stay unwritten / stale."""
+    import etol_amd as E
+    M, B = shape
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 9.0)
+    ev.set_model(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS)
+    ev.set_batch(B)
+    X, U, recs = cases.W.quadrotor_batch(23, B, M, 2)
+    ev.set_path(recs[:1], 0, 1)
+    ref = O.evaluate(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, 9.0, X, U, recs[:1])
+    c = dict(X=X)
+    for sym_ct in (5, 6, 7):
+        ev.set_option("sym_ct", sym_ct)
+        base = None
+        for mode in (2, 3):
+            ev.set_option("overlap_mode", mode)
+            for cpart in (-1, 1, 2, 4, 8, 0):
+                ev.set_option("sym_cpart", cpart)
+                poison = ev.eval_host(X + 1.0, U)              # another input first: a tile left out would keep these rows
+                got = ev.eval_host(X, U)
+                assert ev.uses_fused_kernel
+                check(c, ev, got, ref)
+                if base is None:
+                    base = got
+                assert np.array_equal(got[0], base[0]), (sym_ct, mode, cpart)      # the order of the tiles changes no bit
+                assert not np.array_equal(poison[0], got[0])
+    ev.close()
+
+
 def test_very_large_batches_are_evaluated_in_slices_with_the_same_results(built):
     """emi_eval_dev cuts batches above 2048 instances into slices of 1024 (per-instance keep-out tables, cost partials
     and outputs offset per slice); with per-kernel profiling on it evaluates the batch in one piece: same results."""
