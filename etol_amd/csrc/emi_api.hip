@@ -684,7 +684,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
         const int tiles16 = ((c->B + 15) / 16) * (c->M / 128);
         const bool auto_mode = c->overlap_mode == 0;
-        if ((c->overlap_mode == 3 || (auto_mode && (tiles16 < 192 || tiles16 >= 384))) && !c->rtc && jac) {
+        if ((c->overlap_mode == 3 || (auto_mode && (tiles16 < 192 || tiles16 >= 384))) && jac) {
             // The pass as ONE launch: MFMA-role and node-role workgroups in one grid, COST finished in-kernel.
             // Chosen by itself for small batches, where the fork / join of the two-stream form costs as much as a kernel
             // (B = 128: 0.044 ms against 0.055; B = 256: 0.074 against 0.077), and -- since the MFMA role is software-
@@ -707,7 +707,15 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             } else {
                 plan.ks = 1;
             }
-            if (emi::pass_supported(c->model, c->ns, c->B, c->M, plan)) {
+            if (c->rtc) {
+                // a run-time compiled model holds two instantiations of the pass kernel: SW = 1 with plain stores (small
+                // batches) and SW = 2 (1 for an odd number of states) with non-temporal stores (large ones)
+                const int swl = emi::rtc_pass_sw_large(c->rtc);
+                plan = emi::plan_symdefect(c->ns, c->B, c->M, (na.store_mode == 2 && swl == 2) ? 6 : 7, 1, c->sym_cpart);
+                plan.nst = 3;
+            }
+            if (c->rtc ? emi::rtc_pass_supported(c->rtc, c->B, c->M, plan.sw, plan.ks, na.store_mode)
+                       : emi::pass_supported(c->model, c->ns, c->B, c->M, plan)) {
                 sa.cpart = plan.cpart; sa.cx = plan.cx;
                 if (plan.ks > 1) {
                     int est = ensure(c, c->d_slab, plan.slab_bytes);
@@ -728,7 +736,8 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
                 }
                 na.cost_ticket = (unsigned*)c->d_ticket.p;
                 if (plv) HIP_TRY(c, hipEventRecord(pe->k[0], c->stream));
-                HIP_TRY(c, emi::launch_pass(c->model, sa, na, c->stream, plan));
+                if (c->rtc) HIP_TRY(c, emi::rtc_launch_pass(c->rtc, sa, na, plan.sw, c->stream));
+                else HIP_TRY(c, emi::launch_pass(c->model, sa, na, c->stream, plan));
                 if (plv) HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
                 if (pe) pe->level = -1;                 // one bracket: the pass kernel
                 c->last_defect_kernel = "emi_pass_f64_kernel<SW=" + std::to_string(plan.sw) + "> (MFMA + node roles, one launch" +
@@ -785,7 +794,8 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             na.cost_ticket = (unsigned*)c->d_ticket.p;
         }
         if (plv == 1 || plv == 3) HIP_TRY(c, hipEventRecord(pe->k[2], s2));
-        if (c->rtc) HIP_TRY(c, emi::rtc_launch_nodes<double>(c->rtc, na, jac, false, s2));
+        if (c->rtc && jac && na.store_mode == 2 && c->M % 2 == 0) HIP_TRY(c, emi::rtc_launch_nodes_nt(c->rtc, na, s2));
+        else if (c->rtc) HIP_TRY(c, emi::rtc_launch_nodes<double>(c->rtc, na, jac, false, s2));
         else HIP_TRY(c, emi::launch_nodes<double>(c->model, na, jac, false, s2));
         if (plv == 1 || plv == 3) HIP_TRY(c, hipEventRecord(pe->k[3], s2));
         if (!c->cost_in_kernel)

@@ -100,5 +100,12 @@ struct DefectArgsF32 {
     float* RES;
     int R, M, ns, nres;
 };
+// the whole pass as one launch (emi_pass_f64_kernel): both roles' arguments and how the grid is dealt between them
+struct PassArgs {
+    SymDefectArgs s;
+    NodeArgs<double> n;
+    int nm8, nn8;           // MFMA / node workgroups per XCD
+    int nbx;                // node chunks per instance
+};
 
 }  // namespace emi

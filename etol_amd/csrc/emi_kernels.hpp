@@ -55,6 +55,12 @@ template <typename T>
 hipError_t rtc_launch_nodes(RtcModel* m, const NodeArgs<T>& a, bool jac, bool defect_rows, hipStream_t s);
 template <typename T> hipError_t rtc_launch_hess(RtcModel* m, const HessArgs<T>& a, hipStream_t s);
 hipError_t rtc_launch_symdefect(RtcModel* m, const SymDefectArgs& a, hipStream_t s);
+// the one-launch pass of a run-time compiled model: which state split it was compiled with for large batches (small ones take
+// SW = 1), whether (sw, store mode) is available, and the launch
+int rtc_pass_sw_large(const RtcModel* m);
+bool rtc_pass_supported(const RtcModel* m, int B, int M, int sw, int ks, int store_mode);
+hipError_t rtc_launch_pass(RtcModel* m, const SymDefectArgs& sa, const NodeArgs<double>& na, int sw, hipStream_t s);
+hipError_t rtc_launch_nodes_nt(RtcModel* m, const NodeArgs<double>& a, hipStream_t s);   // vec2, Jacobian, no defect rows, non-temporal stores
 
 // Newton step on the device (emi_kkt.hip)
 struct KktWorkspace;

@@ -27,8 +27,11 @@ struct RtcModel {
     hipFunction_t nodes[2][2][2] = {};   // [vec2][jac][defect rows]
     hipFunction_t hess = nullptr;
     hipFunction_t ring = nullptr;        // even/odd MFMA defect kernel (f64, LDS permitting)
+    hipFunction_t pass_small = nullptr;  // the pass as one launch: SW = 1, plain stores (small batches)
+    hipFunction_t pass_large = nullptr;  //                          SW = sw_large, non-temporal stores (large batches)
+    hipFunction_t node_nt = nullptr;     // node kernel (vec2, Jacobian, no defect rows) with non-temporal stores
     bool f32 = false;
-    int ns = 0, nc = 0;
+    int ns = 0, nc = 0, sw_large = 0;
     size_t ring_lds = 0;
 };
 
@@ -46,10 +49,11 @@ size_t ring_lds_bytes(int ns) { return (size_t)3 * (2 * ns * FUSED_TI + 2 * 64) 
 bool ring_fits(int ns) { return ns <= 8 && ring_lds_bytes(ns) <= 160 * 1024; }
 
 struct Names {
-    std::string nodes[2][2][2], hess, ring;
+    std::string nodes[2][2][2], hess, ring, pass_small, pass_large, node_nt;
 };
+int pass_sw_large(int ns) { return (ns % 2 == 0 && ns > 2) ? 2 : 1; }
 
-Names kernel_names(const char* sn, bool f32, bool with_ring) {
+Names kernel_names(const char* sn, bool f32, bool with_ring, int ns) {
     Names n;
     const std::string T = f32 ? "float" : "double";
     const std::string model = std::string("emi::") + sn + "<" + T + ">";
@@ -59,12 +63,17 @@ Names kernel_names(const char* sn, bool f32, bool with_ring) {
                 n.nodes[v][j][d] = "emi::emi_nodes_kernel<" + T + ", " + model + ", " + (v ? "2" : "1") + ", " +
                                    (j ? "true" : "false") + ", " + (d ? "true" : "false") + ">";
     n.hess = "emi::emi_hess_kernel<" + T + ", " + model + ">";
-    if (with_ring) n.ring = "emi::emi_symdefect_ring_f64_kernel<" + model + ">";
+    if (with_ring) {
+        n.ring = "emi::emi_symdefect_ring_f64_kernel<" + model + ">";
+        n.pass_small = "emi::emi_pass_f64_kernel<" + model + ", 1, 2, 0, 3>";
+        n.pass_large = "emi::emi_pass_f64_kernel<" + model + ", " + std::to_string(pass_sw_large(ns)) + ", 2, 2, 3>";
+        n.node_nt = "emi::emi_nodes_kernel<double, " + model + ", 2, true, false, 2>";
+    }
     return n;
 }
 
 // compile; on success *code holds the gfx950 code object and *lowered the mangled kernel names in
-// the order nodes[0][0][0..1], nodes[0][1][..], nodes[1][..][..], hess, ring
+// the order nodes[0][0][0..1], nodes[0][1][..], nodes[1][..][..], hess, ring, pass (small, large), node kernel with nt stores
 int compile(bool f32, const char* sn, const char* source, int ns, int nc, int npath, int pw, std::vector<char>* code,
             std::vector<std::string>* lowered, bool* has_ring, std::string* log) {
     if (!valid_identifier(sn) || !source || ns < 1 || nc < 0 || ns + nc > 64) {
@@ -94,13 +103,18 @@ int compile(bool f32, const char* sn, const char* source, int ns, int nc, int np
         if (log) *log = "hiprtcCreateProgram failed";
         return EMI_ERR_HIP;
     }
-    const Names nm = kernel_names(sn, f32, with_ring);
+    const Names nm = kernel_names(sn, f32, with_ring, ns);
     std::vector<const std::string*> order;
     for (int v = 0; v < 2; ++v)
         for (int j = 0; j < 2; ++j)
             for (int d = 0; d < 2; ++d) order.push_back(&nm.nodes[v][j][d]);
     order.push_back(&nm.hess);
-    if (with_ring) order.push_back(&nm.ring);
+    if (with_ring) {
+        order.push_back(&nm.ring);
+        order.push_back(&nm.pass_small);
+        order.push_back(&nm.pass_large);
+        order.push_back(&nm.node_nt);
+    }
     for (const std::string* s : order) hiprtcAddNameExpression(p, s->c_str());
 
     const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-function"};
@@ -206,6 +220,10 @@ int rtc_build(bool f32, const char* struct_name, const char* source, int ns, int
     if (e == hipSuccess && ring) {
         e = hipModuleGetFunction(&m->ring, m->mod, low[i++].c_str());
         m->ring_lds = ring_lds_bytes(ns);
+        if (e == hipSuccess) e = hipModuleGetFunction(&m->pass_small, m->mod, low[i++].c_str());
+        if (e == hipSuccess) e = hipModuleGetFunction(&m->pass_large, m->mod, low[i++].c_str());
+        if (e == hipSuccess) e = hipModuleGetFunction(&m->node_nt, m->mod, low[i++].c_str());
+        m->sw_large = pass_sw_large(ns);
     }
     if (e != hipSuccess) {
         if (log) *log = std::string("loading the model code object failed: ") + hipGetErrorString(e);
@@ -244,6 +262,38 @@ template hipError_t rtc_launch_hess<float>(RtcModel*, const HessArgs<float>&, hi
 hipError_t rtc_launch_symdefect(RtcModel* m, const SymDefectArgs& a, hipStream_t s) {
     const int mtiles = (a.B + FUSED_TI - 1) / FUSED_TI, ntiles = (a.M / 2) / 64;
     return launch(m->ring, dim3(mtiles * ntiles), dim3(256), m->ring_lds, s, &a, sizeof a);
+}
+
+int rtc_pass_sw_large(const RtcModel* m) { return m ? m->sw_large : 0; }
+
+// as pass_supported (emi_symdefect.hip) for the two instantiations a model program holds
+bool rtc_pass_supported(const RtcModel* m, int B, int M, int sw, int ks, int store_mode) {
+    if (!m || !m->pass_small || ks > 1 || M % 128 != 0) return false;
+    if (!((sw == 1 && store_mode != 2) || (sw == m->sw_large && store_mode == 2))) return false;
+    const int nm = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64) * (m->ns / sw);
+    const int nn = ((M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS)) * B;
+    return nm % 8 == 0 && nn % 8 == 0;
+}
+
+hipError_t rtc_launch_pass(RtcModel* m, const SymDefectArgs& sa, const NodeArgs<double>& na, int sw, hipStream_t s) {
+    PassArgs a;
+    a.s = sa;
+    a.n = na;
+    const int mtiles = (sa.B + FUSED_TI - 1) / FUSED_TI, ntiles = (sa.M / 2) / 64;
+    const int nm = mtiles * ntiles * (m->ns / sw);
+    a.nbx = (na.M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS);
+    const int nn = a.nbx * na.B;
+    if (nm % 8 || nn % 8) return hipErrorInvalidConfiguration;
+    a.nm8 = nm / 8;
+    a.nn8 = nn / 8;
+    const size_t lds = (size_t)3 * ((2 * sw * FUSED_TI + 2 * 64 + 63) / 64 * 64) * 8 * sizeof(double);     // 3 ring stages
+    return launch(na.store_mode == 2 ? m->pass_large : m->pass_small, dim3(nm + nn), dim3(256), lds, s, &a, sizeof a);
+}
+
+hipError_t rtc_launch_nodes_nt(RtcModel* m, const NodeArgs<double>& a, hipStream_t s) {
+    if (!m->node_nt || a.M % 2) return hipErrorInvalidDeviceFunction;
+    dim3 grid((a.M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS), a.B), block(EMI_NODE_THREADS);
+    return launch(m->node_nt, grid, block, 0, s, &a, sizeof a);
 }
 
 }  // namespace emi

@@ -746,12 +746,6 @@ __global__ __launch_bounds__(256) void emi_symdefect_combine_kernel(SymDefectArg
 // roles are resident on every CU throughout, and the MFMA blocks of an XCD are a contiguous run of tiles (they
 // share X and De/Do panels in that XCD's L2).  Requires nm % 8 == 0 and nn % 8 == 0 (the launcher checks).
 // ---------------------------------------------------------------------------------------------
-struct PassArgs {
-    SymDefectArgs s;
-    NodeArgs<double> n;
-    int nm8, nn8;           // MFMA / node workgroups per XCD
-    int nbx;                // node chunks per instance
-};
 
 #ifndef EMI_PASS_WAVES_PER_EU
 #define EMI_PASS_WAVES_PER_EU 0         // build-time experiment switch (tools/ab_build.sh): register cap of the pass kernel as waves per SIMD

@@ -102,6 +102,44 @@ def _custom_reference(X, U, tn, D, w, h):
     return RES.astype(np.float64), J.astype(np.float64), g.astype(np.float64), cost.astype(np.float64)
 
 
+def test_traced_quadrotor_takes_the_one_launch_pass(built):
+    """A run-time compiled model holds the pass kernel in the two forms the policy uses (SW = 1 with plain stores for small
+    batches, SW = 2 with non-temporal stores for large ones) and the node kernel with non-temporal stores for the
+    two-stream form: same results as the oracle and as the built-in instantiation on each of those paths."""
+    import etol_amd as E
+    M, B = 1024, 8
+    X, U, recs = cases.W.quadrotor_batch(11, B, M, 3)
+    evs = []
+    for traced in (True, False):
+        ev = E.Evaluator(0)
+        ev.set_mesh(M, 0.0, cases.W.TF)
+        if traced:
+            ev.set_model_source("TracedModel", traced_source(0), 6, 2)
+        else:
+            ev.set_model(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS)
+        ev.set_batch(B)
+        ev.set_path(recs, 0, 1)
+        evs.append(ev)
+    tr, bi = evs
+    ref = O.evaluate(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (tr.tau, tr.w, tr.D), 0.0, cases.W.TF, X, U, recs)
+    c = dict(X=X)
+    for opts, expect in ((dict(), "SW=1"), (dict(overlap_mode=3, node_store=2), "SW=2"), (dict(overlap_mode=2, node_store=2), "ring")):
+        for ev in (tr, bi):
+            ev.set_option("overlap_mode", 0)
+            ev.set_option("node_store", -1)
+            for k, v in opts.items():
+                ev.set_option(k, v)
+        got = tr.eval_host(X, U)
+        assert expect in tr.last_defect_kernel, tr.last_defect_kernel
+        assert ("one launch" in tr.last_defect_kernel) == (expect != "ring")
+        check(c, tr, got, ref)
+        hand = bi.eval_host(X, U)
+        for a, b in zip(got, hand):
+            assert np.abs(a - b).max() / (np.abs(b).max() + 1.0) < 1e-13
+    tr.close()
+    bi.close()
+
+
 @pytest.mark.parametrize("M,B,ring", [(128, 20, True), (20, 3, False), (384, 33, True)])
 def test_custom_traced_model_against_numpy(built, M, B, ring):
     """A model the library has no kernel for (2 states, 1 control, explicit time dependence, every
