@@ -131,8 +131,8 @@ def measure(ev, dX, dU, outs, steps, warmup, barrier, torch):
         ev.eval_dev(dX, dU, *outs)
     span_ms = ev.timer_stop() if one_launch else None      # (synchronises the evaluator's stream)
     torch.cuda.synchronize()
-    barrier()
-    t1 = time.perf_counter()
+    t1 = time.perf_counter()      # this rank's K steps are done; the closing barrier follows (its own latency -- an all-reduce
+    barrier()                     # over 8 GPUs is as long as a 128-instance pass -- is not part of the work; MAX over ranks below)
     if one_launch:
         dom_ms, level = span_ms / steps, 2
     else:
