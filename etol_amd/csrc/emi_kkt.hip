@@ -93,9 +93,11 @@ struct KktWorkspace {
     size_t T_elems = 0, Cb_elems = 0;
     size_t cap_Pinv = 0, cap_G = 0, cap_Rk = 0, cap_Doff = 0, cap_W = 0;
     int* flag = nullptr;        // node kernel: a block was not positive definite
-    // dual-regularisation level the Schur path starts from (0: nominal, 1: x1e3, 2: x1e6, 3: straight to the LU): late
-    // interior-point iterations on one mesh fail at the same levels again and again, and every failed level costs a
-    // build of S and a Cholesky.  Kept per mesh shape; after reg_probe successes in a row one level lower is tried again.
+    // dual-regularisation level the Schur path starts from (0: nominal, 1: x1e3, 2: x1e6): late interior-point iterations
+    // on one mesh fail at the same levels again and again, and every failed level costs a build of S and a Cholesky.
+    // Kept per mesh shape; after two successes in a row one level lower is tried again.  The LU is never the starting point:
+    // a wandering solve (inertia search: many trial matrices per iteration) stuck there with 209 of 585 factorisations
+    // at 85 ms each where the Cholesky path, tried, takes 10 ms (513 nodes, profiles/r02_notes.md section 12).
     int reg_level = 0, reg_hits = 0, reg_M = 0, reg_ns = 0, reg_nv = 0;
     double* chol_blk = nullptr;    // [64][64] + [64]: factorised diagonal block and reciprocal diagonal of the current block column
     double* chol_copy = nullptr;   // the matrix handed to dpotrf, kept until the factorisation is confirmed (potrf_checked)
@@ -602,7 +604,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         if (w->reg_M != M || w->reg_ns != ns || w->reg_nv != nv || !g_tune.sticky_reg.load()) {
             w->reg_level = w->reg_hits = 0;
             w->reg_M = M; w->reg_ns = ns; w->reg_nv = nv;
-        } else if (w->reg_level > 0 && w->reg_hits >= 4) {
+        } else if (w->reg_level > 0 && w->reg_hits >= 2) {
             --w->reg_level;
             w->reg_hits = 0;
         }
@@ -661,8 +663,9 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
             w->method_used = 1;
             return EMI_OK;
         }
-        if (hflag == 0) {                           // S not positive definite at any level: the next factorisations start at the LU
-            if (first_attempt >= 3) ++w->reg_hits; else { w->reg_level = 3; w->reg_hits = 0; }
+        if (hflag == 0) {                           // S not positive definite at any level
+            w->reg_level = 2;                           // (the next factorisation starts at the last level, not at the LU)
+            w->reg_hits = 0;
         }
         // a block was not positive definite or S is not: not the quasi-definite case -- general path below
         if (g_tune.debug.load() >= 2 && hinfo > 0 && first_attempt < 3) {

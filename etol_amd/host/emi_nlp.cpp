@@ -893,6 +893,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             const auto tf0 = now();
             const int info = kkt->factor(Qblk.data(), V, fixed_mask.data(), dc);
             R.t_factor += secs(tf0, now());
+            ++R.n_factor;
             if (info < 0) { R.msg = "KKT factorisation failed: " + kkt->last_error(); return R; }
             if (info > 0) {   // exactly singular: the defect Jacobian lost rank; regularise the dual block
                 dc = dc == 0.0 ? 1e-8 * std::pow(mu, 0.25) : dc * 100.0;
@@ -934,6 +935,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             const auto ts0 = now();
             const int sst = kkt->solve(rhs_full.data(), 1);
             R.t_solve += secs(ts0, now());
+            ++R.n_solve;
             if (sst != 0) { R.msg = "KKT solve failed: " + kkt->last_error(); return R; }
             bool finite = true;
             for (size_t r = 0; r < NN && finite; ++r) finite = std::isfinite(rhs_full[r]);
@@ -1209,8 +1211,8 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     R.rho = rho;
     R.t_total = secs(tstart, now());
     if (opt.print_level >= 5)
-        printf("time: total %.2f s = evaluator %.2f + KKT factor %.2f + KKT solves %.2f + low-rank/refinement (host) %.2f + rest\n",
-               R.t_total, R.t_eval, R.t_factor, R.t_solve, R.t_lowrank);
+        printf("time: total %.2f s = evaluator %.2f + KKT factor %.2f (%d factorisations) + KKT solves %.2f (%d calls) + low-rank/refinement (host) %.2f + rest\n",
+               R.t_total, R.t_eval, R.t_factor, R.n_factor, R.t_solve, R.n_solve, R.t_lowrank);
     R.z = it.z;
     R.lamF = it.lam;
     R.lamC.resize(mc);
