@@ -129,7 +129,9 @@ SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_o
                 if (valid(c) && (ntiles / c <= target_cols || c == 8 || !valid(2 * c))) cp = c;
         if (cp > 0) {
             p.cpart = cp;
-            p.cx = std::min(ntiles / cp, target_cols);
+            p.cx = 1;                                            // largest divisor of the partition's column count within the target
+            for (int d = 1; d <= std::min(ntiles / cp, target_cols); ++d)
+                if ((ntiles / cp) % d == 0) p.cx = d;
             if (cp == 1 && p.cx == ntiles) p.cpart = p.cx = 0;   // that is the plain order
         }
     }

@@ -581,10 +581,10 @@ def test_every_mfma_defect_kernel_variant_matches_the_oracle(built, sym_ct, shap
     ev.close()
 
 
-@pytest.mark.parametrize("shape", [(1024, 40), (2048, 24), (512, 72), (256, 128)])
+@pytest.mark.parametrize("shape", [(1024, 40), (2048, 24), (512, 72), (256, 128), (1280, 32), (768, 48)])
 def test_partitioned_tile_orders_of_the_mfma_role(built, shape):
     """"sym_cpart": the column tiles of the state-split ring cut into 1 / 2 / 4 / 8 partitions over the XCDs (the default
-    for large batches), against the plain order and the oracle -- for meshes with 2 .. 16 column tiles, batch sizes whose
+    for large batches), against the plain order and the oracle -- for meshes with 2 .. 16 column tiles (10 and 6 among them: partitions of 5 and 3 columns), batch sizes whose
     group counts do or do not divide over the XCD groups (the plan then falls back to the plain order), SW = 6 / 2 / 1,
     two streams and one launch.  Every tile is visited exactly once or rows of the result stay unwritten / stale."""
     import etol_amd as E
