@@ -1,4 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the CPU oracle.  -m gpu"""
+import os
+
 import numpy as np
 import pytest
 
@@ -6,6 +8,7 @@ import cases
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # fp64 tolerances, relative to the row scale (written here on purpose):
 #   node functions / Jacobian values: a handful of roundings          -> 1e-13
@@ -613,6 +616,19 @@ def test_partitioned_tile_orders_of_the_mfma_role(built, shape):
                 assert np.array_equal(got[0], base[0]), (sym_ct, mode, cpart)      # the order of the tiles changes no bit
                 assert not np.array_equal(poison[0], got[0])
     ev.close()
+
+
+def test_default_dispatch_on_random_shapes_matches_the_general_path(built):
+    """tools/gpu_stress.py with a fixed seed: 30 random (mesh, batch, keep-out count, model) shapes through whatever the
+    policy of emi_eval_dev picks, against the sequential general path (which the tests above pin to the oracle).  (This is
+    the check that found the 5-column partition bug of the tile order.)"""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gpu_stress", os.path.join(ROOT, "tools", "gpu_stress.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    worst, kinds = mod.run(argparse.Namespace(cases=30, seed=7, big=False))
+    assert worst < 1e-11 and len(kinds) >= 3, (worst, kinds)
 
 
 def test_very_large_batches_are_evaluated_in_slices_with_the_same_results(built):

@@ -23,6 +23,11 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="a fixed list of large shapes (the one-launch pass for large batches, slices)")
     a = ap.parse_args()
+    run(a)
+
+
+def run(a):
+    """a.cases, a.seed, a.big as the command line gives them; returns (worst relative difference, {path: count})"""
     rng = np.random.default_rng(a.seed)
     Ms = [128, 256, 384, 512, 640, 768, 896, 1024, 1152, 1280, 1536, 1792, 2048]
     worst = 0.0
@@ -76,6 +81,7 @@ def main():
         torch.cuda.empty_cache()
     print("worst relative difference", worst)
     print("paths taken:", kinds)
+    return worst, kinds
 
 
 if __name__ == "__main__":
