@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--big", action="store_true", help="a fixed list of large shapes (the one-launch pass for large batches, slices)")
+    ap.add_argument("--traced", action="store_true", help="the quadrotor as a run-time compiled (traced) model instead of the built-in one")
     a = ap.parse_args()
     run(a)
 
@@ -45,7 +46,15 @@ def run(a):
         model = E.MODEL_QUADROTOR2D if rng.random() < 0.8 else E.MODEL_POINTMASS2D
         ev = E.Evaluator(0)
         ev.set_mesh(M, 0.0, W.TF)
-        if model == E.MODEL_QUADROTOR2D:
+        if getattr(a, "traced", False):
+            model = E.MODEL_QUADROTOR2D
+        if model == E.MODEL_QUADROTOR2D and getattr(a, "traced", False):
+            import ctypes as C
+            h = C.CDLL(os.path.join(ROOT, "tests", "harness", "libetol_harness.so"))
+            h.harness_traced_model_source.restype = C.c_char_p
+            ev.set_model_source("TracedModel", h.harness_traced_model_source(0).decode(), 6, 2)
+            X, U, recs = W.quadrotor_batch(int(rng.integers(1, 200)), min(B, 32), M, max(nobs, 1))
+        elif model == E.MODEL_QUADROTOR2D:
             ev.set_model(model, W.QUAD_PARAMS)
             X, U, recs = W.quadrotor_batch(int(rng.integers(1, 200)), min(B, 32), M, max(nobs, 1))
         else:
