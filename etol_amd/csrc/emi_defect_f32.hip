@@ -24,7 +24,10 @@ namespace emi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256, 2) void emi_defect_f32_mfma_kernel(DefectArgsF32 a) {
+#ifndef EMI_F32_WGS_PER_CU
+#define EMI_F32_WGS_PER_CU 2
+#endif
+__global__ __launch_bounds__(256, EMI_F32_WGS_PER_CU) void emi_defect_f32_mfma_kernel(DefectArgsF32 a) {
     constexpr int TM = 64, TN = 128, BK = 32, LDK = BK + 1;
     __shared__ float As[2][TM][LDK];
     __shared__ float Bs[2][TN][LDK];
@@ -92,17 +95,35 @@ __global__ __launch_bounds__(256, 2) void emi_defect_f32_mfma_kernel(DefectArgsF
     gload(0);
     lstore(0);
     __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0) the compiler's wait counting sees: no scalar load stays pending into the loop
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) gload((kt + 1) * BK);
         const float* Ar = &As[cur][wr * 32 + l32][lk];
         const float* B0 = &Bs[cur][wc * 64 + l32][lk];
         const float* B1 = &Bs[cur][wc * 64 + 32 + l32][lk];
-#pragma unroll 8
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const float av = Ar[2 * ks];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av - shift[0], B0[2 * ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av - shift[1], B1[2 * ks], acc[1], 0, 0, 0);
+        // Fragments one group (two k-steps, four MFMAs) ahead of the matrix pipe, in registers: read just in time, every
+        // group waited for its LDS reads with the pipe idle (the ISA had s_waitcnt lgkmcnt(0) in front of two of every four
+        // MFMAs).  sched_barrier pins the reads ahead of the MFMAs (the scheduler sinks them otherwise).
+        struct Frag { float a[2], b0[2], b1[2]; };
+        auto read_frag = [&](Frag& f, int g) {
+            f.a[0] = Ar[4 * g];  f.a[1] = Ar[4 * g + 2];
+            f.b0[0] = B0[4 * g]; f.b0[1] = B0[4 * g + 2];
+            f.b1[0] = B1[4 * g]; f.b1[1] = B1[4 * g + 2];
+        };
+        Frag fr[2];
+        read_frag(fr[0], 0);
+#pragma unroll
+        for (int g = 0; g < BK / 4; ++g) {
+            if (g + 1 < BK / 4) read_frag(fr[(g + 1) & 1], g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const Frag& f = fr[g & 1];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q] - shift[0], f.b0[q], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q] - shift[1], f.b1[q], acc[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kt + 1 < nkt) {
             lstore(cur ^ 1);
