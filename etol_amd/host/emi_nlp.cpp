@@ -739,7 +739,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         }
     };
 
-    grad_and_jt(it);
+    { const auto tj = now(); grad_and_jt(it); R.t_jt += secs(tj, now()); }
     int n_acceptable = 0;
     bool force_modified = false;
     bool search_on = false, last_step_reflected = false;
@@ -829,8 +829,11 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
 
         // exact Lagrangian Hessian blocks from the device
         for (int r = 0; r < mc; ++r) y_unscaled[r] = sig[r / M] * it.y[r];
-        if (P.ev->hess(it.z.data(), it.z.data() + (size_t)ns * M, it.lam.data(), np ? y_unscaled.data() : nullptr, 1.0,
-                       E.H.data()) != 0) {
+        const auto th0 = now();
+        const int hess_rc = P.ev->hess(it.z.data(), it.z.data() + (size_t)ns * M, it.lam.data(), np ? y_unscaled.data() : nullptr, 1.0,
+                                       E.H.data());
+        R.t_hess += secs(th0, now());
+        if (hess_rc != 0) {
             R.msg = "Hessian evaluation failed: " + P.ev->last_error();
             break;
         }
@@ -865,6 +868,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             // convergence is kept); if not, the step of K~ is the inertia-corrected one.  Y = K~^-1 U and
             // the factor of C live with the backend (KktBackend::lowrank): on the device for eMI355X.
             const double* V = E.VALS.data();
+            const auto tb0 = now();
             std::copy(E.H.begin(), E.H.end(), Qblk.begin());
             for (int v = 0; v < nv; ++v)
                 for (int k = 0; k < M; ++k) {
@@ -890,6 +894,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                     }
             Qexact = Qblk;
             dw = convexify_node_blocks(Qblk.data(), fixed_mask.data(), nv, M, &mods);
+            R.t_blocks += secs(tb0, now());
             const auto tf0 = now();
             const int info = kkt->factor(Qblk.data(), V, fixed_mask.data(), dc);
             R.t_factor += secs(tf0, now());
@@ -949,7 +954,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 for (size_t r = 0; r < NN; ++r) bmax = std::max(bmax, std::fabs(rhs_keep[r]));
                 double prev = 1e300;
                 for (int ir = 0; ir < 3; ++ir) {
-                    kkt_matvec(Qm.data(), rhs_full.data(), resid.data(), dc);
+                    { const auto tm = now(); kkt_matvec(Qm.data(), rhs_full.data(), resid.data(), dc); R.t_matvec += secs(tm, now()); }
                     double rmax = 0;
                     for (size_t r = 0; r < NN; ++r) { resid[r] = rhs_keep[r] - resid[r]; rmax = std::max(rmax, std::fabs(resid[r])); }
                     if (!(rmax > 1e-14 * std::max(1.0, bmax)) || !(rmax < 0.5 * prev)) break;
@@ -1068,7 +1073,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 if (hasU(q)) it.zU[q] = clampm(it.zU[q], P.zu[q] - it.z[q]);
             }
             if (!evaluate(it.z, E, true)) return false;
-            grad_and_jt(it);
+            { const auto tj = now(); grad_and_jt(it); R.t_jt += secs(tj, now()); }
             return true;
         };
         // backtracking
@@ -1211,8 +1216,9 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     R.rho = rho;
     R.t_total = secs(tstart, now());
     if (opt.print_level >= 5)
-        printf("time: total %.2f s = evaluator %.2f + KKT factor %.2f (%d factorisations) + KKT solves %.2f (%d calls) + low-rank/refinement (host) %.2f + rest\n",
-               R.t_total, R.t_eval, R.t_factor, R.n_factor, R.t_solve, R.n_solve, R.t_lowrank);
+        printf("time: total %.2f s = evaluator %.2f + KKT factor %.2f (%d factorisations) + KKT solves %.2f (%d calls) + low-rank/refinement (host) %.2f + rest"
+               " (of the host part: J^T lambda %.2f, refinement matvecs %.2f, node blocks %.2f; Hessian calls %.2f)\n",
+               R.t_total, R.t_eval, R.t_factor, R.n_factor, R.t_solve, R.n_solve, R.t_lowrank, R.t_jt, R.t_matvec, R.t_blocks, R.t_hess);
     R.z = it.z;
     R.lamF = it.lam;
     R.lamC.resize(mc);

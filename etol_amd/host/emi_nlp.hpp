@@ -97,6 +97,7 @@ struct NlpResult {
     std::vector<double> lamF, lamC;     // multipliers of the defect and path rows
     double t_eval = 0, t_factor = 0, t_solve = 0, t_lowrank = 0, t_total = 0;   // seconds: evaluator, KKT factor, KKT solves, host low-rank algebra
     int n_factor = 0, n_solve = 0;      // factorisations (inertia-search trials included) and solve calls
+    double t_jt = 0, t_matvec = 0, t_blocks = 0, t_hess = 0;   // host: J^T lambda, refinement matvecs, node-block assembly + eigen-decompositions; Hessian calls
     double rho = 0;                     // penalty weight the solve ended with (warm start of the next mesh)
 };
 
