@@ -1153,6 +1153,22 @@ int emi_last_path(emi_ctx_t c, int* fused) {
 }
 
 /* name of the kernel that produced the defect rows in the last emi_eval_dev of this context (for reports) */
+int emi_debug_tile_order(int ns, int B, int M, int sym_ct, int sym_cpart, int* out_tile, int out_cap, int* ntiles_total, int* cpart,
+                         int* cx) {
+    if (ns < 1 || B < 1 || M < 128 || M % 128 != 0 || !ntiles_total) return EMI_ERR_ARG;
+    const emi::SymPlan p = emi::plan_symdefect(ns, B, M, sym_ct, 1, sym_cpart);
+    if (p.ring1 || p.sw < 1) return EMI_ERR_UNSUPPORTED;
+    const int ntiles = (M / 2) / 64, ngrp = ((B + 15) / 16) * (ns / p.sw), total = ntiles * ngrp;
+    *ntiles_total = total;
+    if (cpart) *cpart = p.cpart;
+    if (cx) *cx = p.cx;
+    for (int t = 0; t < total && t < out_cap && out_tile; ++t) {
+        const emi::RingTile rt = emi::ring_tile_of(t, ntiles, ngrp, p.cpart, p.cx);
+        out_tile[t] = rt.ntile + ntiles * rt.grp;
+    }
+    return EMI_OK;
+}
+
 const char* emi_last_defect_kernel(emi_ctx_t c) {
     if (!c) return "";
     return c->last_defect_kernel.c_str();

@@ -100,6 +100,31 @@ struct DefectArgsF32 {
     float* RES;
     int R, M, ns, nres;
 };
+// Which tile a workgroup of the state-split ring kernel works on.  tl counts tiles in XCD-local runs (an XCD gets a contiguous
+// range of the launch); ntiles column tiles, ngrp (instance group x state group) rows of tiles.  cpart = 0: plain order, the
+// column tiles of a group are neighbours.  cpart > 0: XCD x works on column partition x % cpart (ntiles / cpart columns, cx of
+// them interleaved at a time: cx divides that count) and on group partition x / cpart (ngrp cpart / 8 groups).  One function for
+// the kernel and for the host-side check that every tile is visited exactly once (emi_debug_tile_order, tests/test_abi.py).
+struct RingTile { int ntile, grp; };
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline RingTile ring_tile_of(int tl, int ntiles, int ngrp, int cpart, int cx) {
+    RingTile t;
+    if (cpart > 0) {
+        const int per_xcd = ngrp * ntiles / 8;
+        const int x = tl / per_xcd, m = tl - x * per_xcd;
+        const int pc = x % cpart, pg = x / cpart;
+        const int ncol = ntiles / cpart, ng = ngrp / (8 / cpart);
+        const int cb = m / (ng * cx), r = m - cb * ng * cx;
+        t.grp = pg * ng + r / cx;
+        t.ntile = pc * ncol + cb * cx + r % cx;
+    } else {
+        t.ntile = tl % ntiles;
+        t.grp = tl / ntiles;
+    }
+    return t;
+}
 // the whole pass as one launch (emi_pass_f64_kernel): both roles' arguments and how the grid is dealt between them
 struct PassArgs {
     SymDefectArgs s;

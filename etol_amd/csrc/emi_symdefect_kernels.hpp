@@ -443,22 +443,8 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     // 0.2408 ms against 0.2107 with all tiles reading the same 64 rows).  Partitioned order (a.cpart > 0): XCD x works on
     // column partition x % cpart only (its share of De / Do stays in L2) and on group partition x / cpart; X tiles are then
     // read by cpart XCDs instead of one, which costs little (they come from the Infinity Cache).
-    int ntile, grp;
-    {
-        const int tl = bid / KS;
-        if (a.cpart > 0) {
-            const int ngrp = (B + TI - 1) / TI * NSG, per_xcd = ngrp * ntiles / 8;
-            const int x = tl / per_xcd, m = tl - x * per_xcd;
-            const int pc = x % a.cpart, pg = x / a.cpart;
-            const int ncol = ntiles / a.cpart, ng = ngrp / (8 / a.cpart);
-            const int cb = m / (ng * a.cx), r = m - cb * ng * a.cx;
-            grp = pg * ng + r / a.cx;
-            ntile = pc * ncol + cb * a.cx + r % a.cx;
-        } else {
-            ntile = tl % ntiles;
-            grp = tl / ntiles;
-        }
-    }
+    const RingTile rt = ring_tile_of(bid / KS, ntiles, (B + TI - 1) / TI * NSG, a.cpart, a.cx);
+    const int ntile = rt.ntile, grp = rt.grp;
     const int tile = grp * ntiles + ntile;              // slab / ticket index
     const int sg = grp % NSG, mtile = grp / NSG;
     const int inst0 = mtile * TI, i0 = ntile * TN, s0 = sg * SW;

@@ -297,6 +297,12 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
 int emi_set_option(emi_ctx_t ctx, const char* name, int value);
 /* 1 if emi_eval(EMI_EVAL_ALL) currently takes the overlapped path             */
 int emi_last_path(emi_ctx_t ctx, int* fused);
+/* Diagnostics, no device needed: the tile order the state-split MFMA defect kernel would use for (ns states, B instances,
+ * M nodes) with sym_ct (0 / 5..8) and sym_cpart as emi_set_option takes them.  out_tile[t] = column_tile + ncoltiles * group
+ * for every tile slot t of the launch (out_cap entries at most); *ntiles_total = number of slots, *cpart / *cx = the plan.
+ * Every value 0 .. ntiles_total-1 must occur exactly once (tests/test_abi.py).                                               */
+int emi_debug_tile_order(int ns, int B, int M, int sym_ct, int sym_cpart, int* out_tile, int out_cap, int* ntiles_total,
+                         int* cpart, int* cx);
 /* name of the kernel that produced the defect rows in this context's last
  * emi_eval_dev (what a rocprofv3 kernel trace will show); "" before the first  */
 const char* emi_last_defect_kernel(emi_ctx_t ctx);
