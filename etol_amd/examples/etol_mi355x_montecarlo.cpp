@@ -145,6 +145,8 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
     solver.getAlgorithm()->nlp_tolerance = getenv("EMI_MC_TOL") ? atof(getenv("EMI_MC_TOL")) : 1e-7;   // (ePSOPT.cpp:67 sets 1e-6)
     solver.getAlgorithm()->nlp_iter_max = 400;
     solver.getAlgorithm()->mesh_refinement = "none";
+    if (getenv("EMI_MC_WARM_MU")) solver.getAlgorithm()->warm_mu_init = atof(getenv("EMI_MC_WARM_MU"));      // experiments
+    if (getenv("EMI_MC_WARM_PUSH")) solver.getAlgorithm()->warm_bound_push = atof(getenv("EMI_MC_WARM_PUSH"));
     solver.getAlgorithm()->print_level = env_int("EMI_MC_PRINT_LEVEL", 0);
     t->solve();
     const mx::Sol* sol = solver.getSolution();

@@ -744,28 +744,33 @@ void eMI355X::solve() {
     _solution.nlp_iterations_total = 0;
     _solution.ode_error = 0;
     bool sequenced = false;             // the requested mesh is started from the sequencing ladder's solution
+    std::function<bool(double)> climb;  // the ladder from its coarsest mesh with the straight-line guess bent by so much: true if every rung converged
+    double ladder_span = 0;
+    bool ladder_first_rung_failed = false;
+    const double ladder_bends[4] = {0.15, -0.15, 0.35, -0.35};
 
     // Mesh sequencing: a fine global mesh is reached through coarse ones (33, 65, 129, ... nodes), each
     // solve started from the interpolated previous solution.  An interior-point iteration from a cold
     // straight-line guess needs hundreds of Newton steps on a 1000-node mesh; from the interpolant of the
     // next-coarser solution it needs a few dozen, and the coarse solves cost next to nothing.
     // (PSOPT's own remedy is the same idea driven by the error estimate: start coarse, refine.)
+    // (function scope: the ladder is climbed again, from another guess, if the warm start on the requested mesh fails)
+    const size_t target = P.nodes;
+    std::vector<size_t> ladder;
+    const std::vector<double> true_records = P.path_records;
+    double span = 0;
     if (_algorithm.mesh_sequencing && P.nodes > 80 && P.guess_states.empty()) {
-        const size_t target = P.nodes;
-        std::vector<size_t> ladder;
         for (size_t m = 33; m < target; m = 2 * m - 1) ladder.push_back(m);
         // Constraints hold at the nodes only, so a coarse mesh can step over a thin keep-out ("tunnelling") and leave
         // the finer meshes a start on the wrong side of it.  On the ladder the keep-outs of the record table are
         // therefore inflated by half the largest node spacing of the straight line between the boundary positions
         // (LGL nodes are (pi/2) / (m-1) of the span apart at mid-horizon); the requested mesh gets the true sizes back.
-        const std::vector<double> true_records = P.path_records;
-        double span = 0;
         if (P.event_lower.size() == 2 * ns) {
             const double dx = 0.5 * (P.event_lower[ns + P.px] + P.event_upper[ns + P.px]) - 0.5 * (P.event_lower[P.px] + P.event_upper[P.px]);
             const double dy = 0.5 * (P.event_lower[ns + P.py] + P.event_upper[ns + P.py]) - 0.5 * (P.event_lower[P.py] + P.event_upper[P.py]);
             span = std::sqrt(dx * dx + dy * dy);
         }
-        auto inflate_records = [&](size_t m) {
+        auto inflate_records = [&, this](size_t m) {
             P.path_records = true_records;
             if (!_algorithm.inflate_keepouts || !(span > 0)) return;
             const double delta = 0.5 * span * 1.5707963267948966 / (double)(m - 1);
@@ -778,24 +783,54 @@ void eMI355X::solve() {
                 else grow(rec[2]);
             }
         };
-        bool chain_ok = true;
-        for (size_t li = 0; li < ladder.size() && chain_ok; ++li) {
-            inflate_records(ladder[li]);
-            if (li == 0) setMesh(ladder[0]);
-            configureDevice(_dev.get());
-            mi355x::NlpOptions o = li == 0 ? opt : warm;
-            o.tol = std::max(opt.tol, 1e-6);          // intermediate meshes only feed the next guess
-            if (li == 0) solve_cold_with_retries(o); else solve_current_mesh(o);
-            ++_solution.mesh_iterations;
-            if (_algorithm.print_level >= 5)
-                printf("mesh sequencing: %zu nodes, %d iterations, cost %.10e (%s)\n", P.nodes, r.iterations, r.cost,
-                       r.msg.c_str());
-            chain_ok = r.ok;
-            warm.rho_init = std::max(warm.rho_init, r.rho);     // a penalty weight found too small stays raised
-            if (chain_ok) {
-                if (li + 1 == ladder.size()) P.path_records = true_records;       // the guess repair below sees the true sizes
-                remesh_with_guess(li + 1 < ladder.size() ? ladder[li + 1] : target);
+        // A rung that fails after the coarsest one converged (the interpolant runs into a corner the coarse mesh did not
+        // see) sends the whole ladder back to its start with the straight-line guess bent to one side: a cold start on
+        // 33 nodes costs a quarter of a second, whereas the fallback below -- cold starts on the requested mesh -- spent
+        // 4 x 400 iterations of a 513-node problem on one Monte-Carlo scenario (36 of its 41 s, profiles/r02_notes.md).
+        const int ladder_tries = (P.npath > 0 && span > 0) ? 1 + std::min(4, std::max(0, _algorithm.guess_retries)) : 1;
+        ladder_span = ladder_tries > 1 ? span : 0.0;
+        climb = [&, this, inflate_records](double bend) -> bool {
+            P.guess_states.clear();
+            P.guess_controls.clear();
+            P.guess_lamF.clear();
+            P.guess_lamC.clear();
+            warm.rho_init = opt.rho_init;
+            bool ok = true;
+            for (size_t li = 0; li < ladder.size() && ok; ++li) {
+                inflate_records(ladder[li]);
+                if (li == 0) setMesh(ladder[0]);
+                configureDevice(_dev.get());
+                mi355x::NlpOptions o = li == 0 ? opt : warm;
+                o.tol = std::max(opt.tol, 1e-6);          // intermediate meshes only feed the next guess
+                if (li == 0) {
+                    P.guess_bend = bend;
+                    solve_cold_with_retries(o);
+                    P.guess_bend = 0;
+                } else {
+                    solve_current_mesh(o);
+                }
+                ++_solution.mesh_iterations;
+                if (_algorithm.print_level >= 5)
+                    printf("mesh sequencing: %zu nodes, %d iterations, cost %.10e (%s)\n", P.nodes, r.iterations, r.cost,
+                           r.msg.c_str());
+                ok = r.ok;
+                warm.rho_init = std::max(warm.rho_init, r.rho);     // a penalty weight found too small stays raised
+                if (ok) {
+                    if (li + 1 == ladder.size()) P.path_records = true_records;       // the guess repair below sees the true sizes
+                    remesh_with_guess(li + 1 < ladder.size() ? ladder[li + 1] : target);
+                } else if (li == 0) {
+                    ladder_first_rung_failed = true;                   // the cold start already went through its own bends
+                }
             }
+            P.path_records = true_records;
+            return ok;
+        };
+        bool chain_ok = false;
+        for (int ca = 0; ca < ladder_tries && !chain_ok && !ladder_first_rung_failed; ++ca) {
+            if (ca > 0 && _algorithm.print_level >= 5)
+                printf("mesh sequencing: a rung failed (%s), ladder restarted from the line bent by %+.3f\n", r.msg.c_str(),
+                       ladder_bends[ca - 1] * span);
+            chain_ok = climb(ca > 0 ? ladder_bends[ca - 1] * span : 0.0);
         }
         P.path_records = true_records;
         if (chain_ok) {
@@ -821,6 +856,20 @@ void eMI355X::solve() {
         if (!r.ok && sequenced && mr == 0) {
             // the ladder led into a corner (typically an interpolant cutting through a keep-out the coarse meshes
             // did not see): start over on the requested mesh from the default guess
+            const size_t target_nodes = P.nodes;
+            for (int ca = 0; climb && ca < 4 && ca < _algorithm.guess_retries && ladder_span > 0 && !r.ok && !ladder_first_rung_failed; ++ca) {
+                if (_algorithm.print_level >= 5)
+                    printf("mesh sequencing: warm start on %zu nodes failed (%s), ladder restarted from the line bent by %+.3f\n",
+                           target_nodes, r.msg.c_str(), ladder_bends[ca] * ladder_span);
+                if (climb(ladder_bends[ca] * ladder_span)) {
+                    solve_current_mesh(warm);
+                    ++_solution.mesh_iterations;
+                } else {
+                    r.ok = false;
+                }
+            }
+            if (r.ok) goto target_solved;
+            if (P.nodes != target_nodes) { setMesh(target_nodes); configureDevice(_dev.get()); }
             if (_algorithm.print_level >= 5) printf("mesh sequencing: warm start failed (%s), cold start on %zu nodes\n", r.msg.c_str(), P.nodes);
             P.guess_states.clear();
             P.guess_controls.clear();
@@ -829,6 +878,7 @@ void eMI355X::solve() {
             solve_cold_with_retries(opt);
             ++_solution.mesh_iterations;
         }
+    target_solved:
         if (!r.ok && mr > 0 && r_good.ok) {
             // a refinement solve that fails does not take the converged coarser solution with it
             if (_algorithm.print_level >= 5) printf("mesh iteration %d failed (%s): keeping the %zu-node solution\n", mr, r.msg.c_str(), M_good);
