@@ -675,6 +675,22 @@ void eMI355X::solve() {
         r = mi355x::solve_nlp(nlp, o, mi355x::initial_guess(P));
         _solution.nlp_iterations_total += r.iterations;
     };
+    // A warm start that wanders (no failure, just hundreds of regularised steps along a flat valley; Monte-Carlo scenario 10 of
+    // profiles/r02_notes.md section 12) is cut off after Alg::warm_patience iterations and repeated from the same interpolated
+    // guess with a 10 x larger barrier parameter
+    auto solve_warm = [&](const mi355x::NlpOptions& o) {
+        if (_algorithm.warm_patience <= 0 || _algorithm.warm_patience >= o.max_iter) { solve_current_mesh(o); return; }
+        mi355x::NlpOptions first = o;
+        first.max_iter = _algorithm.warm_patience;
+        solve_current_mesh(first);
+        if (r.ok || r.iterations < first.max_iter) return;                  // converged, or ended for another reason
+        if (_algorithm.print_level >= 5)
+            printf("warm start still running after %d iterations: again from the same guess with barrier parameter %.1e\n",
+                   first.max_iter, 10.0 * o.mu_init);
+        mi355x::NlpOptions again = o;
+        again.mu_init = 10.0 * o.mu_init;
+        solve_current_mesh(again);
+    };
     // A cold start that ends locally infeasible (the path rows stay violated whatever the penalty weight: the iterate
     // sits on the wrong side of a keep-out) is repeated from the straight line bent to either side, by 15 % and 35 %
     // of its length.  IPOPT's restoration phase does this job for ePSOPT; here it is a search over homotopy classes,
@@ -807,7 +823,7 @@ void eMI355X::solve() {
                     solve_cold_with_retries(o);
                     P.guess_bend = 0;
                 } else {
-                    solve_current_mesh(o);
+                    solve_warm(o);
                 }
                 ++_solution.mesh_iterations;
                 if (_algorithm.print_level >= 5)
@@ -851,7 +867,9 @@ void eMI355X::solve() {
     mi355x::NlpResult r_good;           // last converged solution and its mesh
     size_t M_good = 0;
     for (int mr = 0;; ++mr) {
-        if (mr == 0 && !sequenced) solve_cold_with_retries(opt); else solve_current_mesh(sequenced && mr == 0 ? warm : opt);
+        if (mr == 0 && !sequenced) solve_cold_with_retries(opt);
+        else if (sequenced && mr == 0) solve_warm(warm);
+        else solve_current_mesh(opt);
         ++_solution.mesh_iterations;
         if (!r.ok && sequenced && mr == 0) {
             // the ladder led into a corner (typically an interpolant cutting through a keep-out the coarse meshes
@@ -862,7 +880,7 @@ void eMI355X::solve() {
                     printf("mesh sequencing: warm start on %zu nodes failed (%s), ladder restarted from the line bent by %+.3f\n",
                            target_nodes, r.msg.c_str(), ladder_bends[ca] * ladder_span);
                 if (climb(ladder_bends[ca] * ladder_span)) {
-                    solve_current_mesh(warm);
+                    solve_warm(warm);
                     ++_solution.mesh_iterations;
                 } else {
                     r.ok = false;

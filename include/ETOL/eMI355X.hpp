@@ -37,6 +37,8 @@ struct Alg {
                                                    // Monte-Carlo sets, off by default)
     bool mesh_sequencing = true;                   // meshes above 80 nodes are reached through 33, 65, 129, ... nodes
     int guess_retries = 4;                         // a locally infeasible cold start is repeated from up to this many bent lines
+    int warm_patience = 0;                         // > 0: a warm start (interpolated guess) still running after this many iterations is
+                                                   // started again from the same guess with a 10 x larger barrier parameter (0: off)
     bool warm_multipliers = false;                 // carry costate-mapped multipliers to the next mesh (measured: no gain, profiles/r01_notes.md)
     double warm_mu_init = 1e-5;                    // barrier parameter of a solve started from an interpolated solution
     double warm_bound_push = 1e-4;                 // ... and its bound push / fraction
