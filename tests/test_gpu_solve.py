@@ -494,6 +494,23 @@ def test_montecarlo_scenario_without_a_feasible_path_on_its_side_ends_early(buil
     assert iters < 700, line
 
 
+def test_a_failed_rung_restarts_the_ladder_from_a_bent_guess(built):
+    """Scenario 27 of the 513-node / 20 keep-out set: its 257-node rung ends locally infeasible.  The ladder must then start
+    again on 33 nodes from the straight line bent to one side -- not cold-start the 513-node mesh, which took four attempts of
+    400 iterations (41 s) before -- and solve the scenario."""
+    exe = os.path.join(ROOT, "etol_amd", "lib", "etol_mi355x_montecarlo")
+    env = dict(os.environ, EMI_MC_ONLY="27", EMI_MC_PRINT_LEVEL="5", EMI_MC_GATHER="0", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([exe, "32", "512", "20", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.split("\n") if l.startswith("scenario")][0]
+    f = line.split()
+    rc, iters, nodes = int(f[f.index("rc") + 1]), int(f[f.index("iterations") + 1]), int(f[f.index("nodes") + 1])
+    assert rc == 0 and nodes == 513, line
+    assert "ladder restarted from the line bent by" in r.stdout
+    assert "cold start on 513 nodes" not in r.stdout
+    assert iters < 1200, line
+
+
 def test_shipped_example_with_traced_obstacle_rows(H, xmls):
     """The obstacle rows of src/Examples/PSOPT/etol_psopt_example1.cpp:153-190 computed with mi355x::Var
     arithmetic in the callback (nine ellipse rows), traced and compiled into the kernels, next to the
