@@ -147,6 +147,7 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
     solver.getAlgorithm()->mesh_refinement = "none";
     if (getenv("EMI_MC_WARM_MU")) solver.getAlgorithm()->warm_mu_init = atof(getenv("EMI_MC_WARM_MU"));      // experiments
     if (getenv("EMI_MC_WARM_PATIENCE")) solver.getAlgorithm()->warm_patience = atoi(getenv("EMI_MC_WARM_PATIENCE"));
+    if (getenv("EMI_MC_MU_RESTART")) solver.getAlgorithm()->mu_restart = atof(getenv("EMI_MC_MU_RESTART"));
     if (getenv("EMI_MC_WARM_PUSH")) solver.getAlgorithm()->warm_bound_push = atof(getenv("EMI_MC_WARM_PUSH"));
     solver.getAlgorithm()->print_level = env_int("EMI_MC_PRINT_LEVEL", 0);
     t->solve();

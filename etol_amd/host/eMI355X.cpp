@@ -756,6 +756,7 @@ void eMI355X::solve() {
     mi355x::NlpOptions warm = opt;      // started from an interpolated solution: stay close to it
     warm.mu_init = _algorithm.warm_mu_init;               // (1e-3 .. 1e-5 measured, profiles/r01_notes.md)
     warm.bound_push = warm.bound_frac = _algorithm.warm_bound_push;
+    warm.mu_restart = _algorithm.mu_restart;
     _solution.mesh_iterations = 0;
     _solution.nlp_iterations_total = 0;
     _solution.ode_error = 0;

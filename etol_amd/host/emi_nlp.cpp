@@ -755,6 +755,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         return ++futile >= opt.max_futile_escalations;
     };
     int stagn = 0, crawl = 0;
+    bool mu_restarted = false;
     // (experiments, profiles/r01_notes.md) max_shift_trials = 0 switches the inertia search off, crawl_limit = 1000 the crawl rule
     const int max_shift_trials = opt.max_shift_trials;
     const int stagn_limit = opt.stagnation_iters;
@@ -792,7 +793,17 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         {
             const double err_mu_now = kkt_error(it, mu, nullptr, nullptr);
             if (last_step_reflected && err_mu_now > 0.9 * stagn_ref) {
-                if (++stagn >= stagn_limit) search_on = true;
+                if (++stagn >= stagn_limit) {
+                    search_on = true;
+                    if (opt.mu_restart > 1.0 && !mu_restarted && mu < 1e-4) {
+                        mu_restarted = true;
+                        mu = std::min(1e-3, mu * opt.mu_restart);
+                        nu = 1.0;
+                        stagn = 0;
+                        stagn_ref = 1e300;
+                        if (opt.print_level >= 5) printf("stagnation at a small barrier parameter: raised to %.1e\n", mu);
+                    }
+                }
             } else {
                 stagn = 0;
                 stagn_ref = err_mu_now;

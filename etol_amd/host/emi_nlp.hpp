@@ -77,6 +77,8 @@ struct NlpOptions {
     double max_cpu_time = 1e9;          // seconds
     int max_futile_escalations = 3;     // tenfold raises of the penalty weight beyond 1e5 without halving the largest elastic before giving up
     int max_shift_trials = 6;           // inertia search: trial shifts delta_w per iteration before the reflected step is taken (0: search off)
+    double mu_restart = 0.0;            // > 0: the first time the iteration stagnates (below) with a barrier parameter under 1e-4, the parameter is
+                                        // multiplied by this (capped at 1e-3) once per solve: a warm start sliding along its active keep-outs
     int stagnation_iters = 12;          // iterations without 10 % progress of the barrier KKT residual before the inertia search starts
     int crawl_limit = 3;                // consecutive short steps (alpha < crawl_frac * alpha_max) before the crawl rule acts
     double crawl_frac = 0.3;
