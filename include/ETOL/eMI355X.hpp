@@ -37,8 +37,8 @@ struct Alg {
                                                    // Monte-Carlo sets, off by default)
     bool mesh_sequencing = true;                   // meshes above 80 nodes are reached through 33, 65, 129, ... nodes
     int guess_retries = 4;                         // a locally infeasible cold start is repeated from up to this many bent lines
-    double mu_restart = 0.0;                       // NlpOptions::mu_restart of the warm starts: barrier parameter x this (at most 1e-3), once, when a warm
-                                                   // start stagnates at a small parameter (0: off; 100 measured: profiles/r02_notes.md section 12)
+    double mu_restart = 10.0;                      // NlpOptions::mu_restart of the warm starts: barrier parameter x this (at most 1e-3), once, when a warm
+                                                   // start stagnates at a small parameter (0: off; 10 and 100 measured: profiles/r02_notes.md section 12)
     int warm_patience = 0;                         // > 0: a warm start (interpolated guess) still running after this many iterations is
                                                    // started again from the same guess with a 10 x larger barrier parameter (0: off)
     bool warm_multipliers = false;                 // carry costate-mapped multipliers to the next mesh (measured: no gain, profiles/r01_notes.md)
