@@ -86,6 +86,8 @@ struct emi_ctx_s {
     int slice_first = 0;        // first instance of the slice emi_eval_dev is working on (per-instance tables are offset by it)
     int sym_ksplit = 0;         // "sym_ksplit" option: K slices per tile of the state-split ring kernel (0: by batch size)
     int sym_cpart = 0;          // "sym_cpart" option: column partitions of the tile order (0: by mesh size, -1: plain order, 1/2/4/8)
+    int pass_order = -1;        // "pass_order" option: one-launch pass, MFMA workgroups of an XCD first (1), interleaved with the node
+                                // workgroups (0), or by batch size (-1: first for small batches)
     int sym_combine = 1;        // "sym_combine" option: 1 slices combined in-kernel by ticket, 0 by emi_symdefect_combine_kernel
     // host-form staging
     DevBuf s_X, s_U, s_RES, s_VALS, s_COST, s_LF, s_LC, s_H;
@@ -678,7 +680,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         emi::SymDefectArgs sa;
         sa.X = (const double*)dX; sa.U = (const double*)dU; sa.RES = (double*)dRES;
         sa.node_t = (const double*)c->d_t.p; sa.De = (const double*)c->d_De.p; sa.Do = (const double*)c->d_Do.p;
-        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0; sa.order = c->sym_order; sa.ablate = c->sym_ablate; sa.ksplit = 1; sa.slab = nullptr; sa.tile_ticket = nullptr; sa.cpart = sa.cx = 0;
+        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0; sa.order = c->sym_order; sa.ablate = c->sym_ablate; sa.ksplit = 1; sa.slab = nullptr; sa.tile_ticket = nullptr; sa.cpart = sa.cx = 0; sa.mfma_first = 0;
         for (int i = 0; i < EMI_MAX_PARAMS; ++i) sa.P.p[i] = c->params[i];
         emi::NodeArgs<double> na;
         fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
@@ -714,6 +716,11 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
                 plan = emi::plan_symdefect(c->ns, c->B, c->M, (na.store_mode == 2 && swl == 2) ? 6 : 7, 1, c->sym_cpart);
                 plan.nst = 3;
             }
+            // Small batches: the MFMA workgroups of an XCD come first in its share of the grid, so that the 64-tile dependency
+            // chains start at once and the streaming workgroups fill in behind them (128 instances: 0.0340 ms against 0.0386
+            // interleaved; 64: 0.0249 / 0.0264; 224: 0.0583 / 0.0686).  From 256 instances the even interleave wins (0.0727 / 0.0748), at 1024 by far
+            // (0.226 / 0.292: the node role would start when the MFMA role is half done).
+            sa.mfma_first = c->pass_order >= 0 ? c->pass_order : (tiles16 < 128);
             if (c->rtc ? emi::rtc_pass_supported(c->rtc, c->B, c->M, plan.sw, plan.ks, na.store_mode)
                        : emi::pass_supported(c->model, c->ns, c->B, c->M, plan)) {
                 sa.cpart = plan.cpart; sa.cx = plan.cx;
@@ -1114,6 +1121,7 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         return EMI_OK;
     }
     if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }
+    if (strcmp(name, "pass_order") == 0) { c->pass_order = value < 0 ? -1 : (value != 0); return EMI_OK; }
     if (strcmp(name, "sym_ablate") == 0) { c->sym_ablate = value; return EMI_OK; }   // diagnostics only
     if (strcmp(name, "cost_in_kernel") == 0) { c->cost_in_kernel = value != 0; return EMI_OK; }
     if (strcmp(name, "sym_nst") == 0) {

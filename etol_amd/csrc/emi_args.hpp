@@ -81,6 +81,8 @@ struct SymDefectArgs {
     double* slab;           // [tiles][ksplit][2 SW][4][256] partial sums of a split-K launch
     unsigned* tile_ticket;  // [tiles] zero before the first launch, self-resetting: the slices of a tile are combined by the
                             // workgroup that draws the tile's last ticket (nullptr: emi_symdefect_combine_kernel does it)
+    int mfma_first;         // one-launch pass: 1 the MFMA workgroups of an XCD come first in its share of the grid, 0 evenly interleaved
+                            // with the node workgroups
     int cpart, cx;          // tile order of the state-split ring kernel (plan_symdefect): the column tiles are cut into cpart
                             // partitions, one per group of 8 / cpart XCDs, and cx column tiles of an X tile run as neighbours
                             // (cpart = 0: plain order, the column tiles of an X tile as neighbours, X tiles dealt over the XCDs)

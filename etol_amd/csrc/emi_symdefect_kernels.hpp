@@ -744,7 +744,14 @@ __global__ __launch_bounds__(256) void emi_symdefect_combine_kernel(SymDefectArg
 template <class Model, int SW, int VEC, int ST, int NST = 3>
 __global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs a) {
     const int g = blockIdx.x, xcd = g & 7, j = g >> 3, t8 = a.nm8 + a.nn8;
-    const int m0 = (int)(((long long)j * a.nm8) / t8), m1 = (int)(((long long)(j + 1) * a.nm8) / t8);
+    int m0, m1;
+    if (a.s.mfma_first) {       // the MFMA workgroups of an XCD first, its node workgroups after them (small batches: the chain starts at once)
+        m0 = j < a.nm8 ? j : a.nm8;
+        m1 = j < a.nm8 ? j + 1 : a.nm8;
+    } else {
+        m0 = (int)(((long long)j * a.nm8) / t8);
+        m1 = (int)(((long long)(j + 1) * a.nm8) / t8);
+    }
     if (a.s.ablate & (m1 > m0 ? 16 : 32)) return;    // diagnostics: one of the two roles does nothing
     if (m1 > m0) {
         // the MFMA role is the latency chain of a small pass (64 dependent K tiles); the streaming role beside it on the

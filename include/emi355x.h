@@ -288,7 +288,9 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * size; -1 = plain (the column tiles of an X tile are neighbours, X tiles dealt over
  * the XCDs); 1 / 2 / 4 / 8 = the column tiles cut into that many partitions, each
  * worked on by 8 / cpart XCDs, so that an XCD's share of De / Do stays in its L2.
- * "sym_nst": ring stages of the one-launch pass (3 default, 4).
+ * "sym_nst": ring stages of the one-launch pass (3 default, 4).  "pass_order": the MFMA workgroups of an
+ * XCD first in its share of the one-launch grid (1), interleaved with the node workgroups (0), or -1
+ * (default) by batch size: first for small batches (fewer than 128 tiles).
  * "kkt_*": process-wide switches of emi_kkt_factor ("kkt_sticky_reg" 1 (default):
  * the Schur path starts at the dual regularisation level that worked last on this
  * mesh; "kkt_debug", "kkt_cholesky", "kkt_chol_panel", "kkt_batched_max_nodes",

@@ -62,6 +62,9 @@ VARIANTS = {
     "sw2_conc_plain_order": dict(sym_ct=6, overlap_mode=2, node_store=2, sym_cpart=-1),
     "sw2_conc_cpart4": dict(sym_ct=6, overlap_mode=2, node_store=2, sym_cpart=4),
     "sw6_conc_cpart4": dict(sym_ct=5, overlap_mode=2, node_store=2, sym_cpart=4),
+    "one_launch_sw1_interleaved": dict(sym_ct=7, overlap_mode=3, node_store=-1, pass_order=0),
+    "one_launch_sw1_mfma_first": dict(sym_ct=7, overlap_mode=3, node_store=-1, pass_order=1),
+    "one_launch_sw2_mfma_first": dict(sym_ct=6, overlap_mode=3, node_store=-1, pass_order=1),
     "one_launch_sw1_nst4": dict(sym_ct=7, overlap_mode=3, node_store=-1, sym_nst=4),
     "one_launch_sw2_nst4": dict(sym_ct=6, overlap_mode=3, node_store=-1, sym_nst=4),
     "one_launch_sw1_nst4_nt": dict(sym_ct=7, overlap_mode=3, node_store=2, sym_nst=4),
@@ -115,6 +118,7 @@ def main():
         ev.set_option("cost_in_kernel", 1)
         ev.set_option("sym_combine", 1)
         ev.set_option("sym_cpart", 0)
+        ev.set_option("pass_order", -1)
         for k, v in opts.items():
             ev.set_option(k, v)
 
