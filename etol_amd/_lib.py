@@ -82,6 +82,7 @@ SYMBOLS = {
     "emi_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "emi_last_path": (C.c_int, [_P, _I]),
     "emi_last_defect_kernel": (C.c_char_p, [_P]),
+    "emi_debug_pass_roles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "emi_debug_tile_order": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "emi_comm_unique_id": (C.c_int, [_P]),
     "emi_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),

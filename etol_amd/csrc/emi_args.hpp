@@ -127,6 +127,32 @@ inline RingTile ring_tile_of(int tl, int ntiles, int ngrp, int cpart, int cx) {
     }
     return t;
 }
+// Role of block j of an XCD's share of the one-launch pass grid (nm MFMA-role and nn node-role blocks): {is_mfma, index within
+// the role}.  order 0: evenly interleaved; 1: all MFMA blocks first; >= 100: interleaved with the MFMA blocks at order / 100 times
+// the even density until they are used up, node blocks at the tail (the launcher clamps the density to one MFMA block per
+// block, which keeps the map a bijection).  One function for the kernel and for the host-side check (emi_debug_pass_roles).
+struct PassRole { int mfma, index; };
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline PassRole pass_role_of(int j, int nm, int nn, int order) {
+    const long long t = (long long)nm + nn;
+    long long m0, m1;
+    if (order == 1) {
+        m0 = j < nm ? j : nm;
+        m1 = j < nm ? j + 1 : nm;
+    } else {
+        const long long d = order >= 100 ? order : 100;
+        m0 = ((long long)j * nm * d) / (100 * t);
+        m1 = ((long long)(j + 1) * nm * d) / (100 * t);
+        if (m0 > nm) m0 = nm;
+        if (m1 > nm) m1 = nm;
+    }
+    PassRole r;
+    r.mfma = m1 > m0;
+    r.index = (int)(r.mfma ? m0 : j - m0);
+    return r;
+}
 // the whole pass as one launch (emi_pass_f64_kernel): both roles' arguments and how the grid is dealt between them
 struct PassArgs {
     SymDefectArgs s;

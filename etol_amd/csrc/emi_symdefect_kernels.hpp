@@ -743,23 +743,16 @@ __global__ __launch_bounds__(256) void emi_symdefect_combine_kernel(SymDefectArg
 #endif
 template <class Model, int SW, int VEC, int ST, int NST = 3>
 __global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs a) {
-    const int g = blockIdx.x, xcd = g & 7, j = g >> 3, t8 = a.nm8 + a.nn8;
-    int m0, m1;
-    if (a.s.mfma_first) {       // the MFMA workgroups of an XCD first, its node workgroups after them (small batches: the chain starts at once)
-        m0 = j < a.nm8 ? j : a.nm8;
-        m1 = j < a.nm8 ? j + 1 : a.nm8;
-    } else {
-        m0 = (int)(((long long)j * a.nm8) / t8);
-        m1 = (int)(((long long)(j + 1) * a.nm8) / t8);
-    }
-    if (a.s.ablate & (m1 > m0 ? 16 : 32)) return;    // diagnostics: one of the two roles does nothing
-    if (m1 > m0) {
+    const int g = blockIdx.x, xcd = g & 7, j = g >> 3;
+    const PassRole role = pass_role_of(j, a.nm8, a.nn8, a.s.mfma_first);
+    if (a.s.ablate & (role.mfma ? 16 : 32)) return;    // diagnostics: one of the two roles does nothing
+    if (role.mfma) {
         // the MFMA role is the latency chain of a small pass (64 dependent K tiles); the streaming role beside it on the
         // same SIMDs waits on memory most of the time: instruction arbitration goes to the MFMA waves first
         __builtin_amdgcn_s_setprio(3);
-        emi_ring2_body<Model, SW, NST>(a.s, xcd * a.nm8 + m0);
+        emi_ring2_body<Model, SW, NST>(a.s, xcd * a.nm8 + role.index);
     } else {
-        const int nid = xcd * a.nn8 + (j - m0);
+        const int nid = xcd * a.nn8 + role.index;
         emi_nodes_body<double, Model, VEC, true, false, ST>(a.n, nid % a.nbx, nid / a.nbx, a.nbx);
     }
 }

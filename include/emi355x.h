@@ -289,8 +289,9 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * the XCDs); 1 / 2 / 4 / 8 = the column tiles cut into that many partitions, each
  * worked on by 8 / cpart XCDs, so that an XCD's share of De / Do stays in its L2.
  * "sym_nst": ring stages of the one-launch pass (3 default, 4).  "pass_order": the MFMA workgroups of an
- * XCD first in its share of the one-launch grid (1), interleaved with the node workgroups (0), or -1
- * (default) by batch size: first for small batches (fewer than 128 tiles).
+ * XCD first in its share of the one-launch grid (1), interleaved with the node workgroups (0), interleaved
+ * at value / 100 times the even MFMA density with the node workgroups at the tail (>= 100), or -1 (default)
+ * by batch size: first for small batches (fewer than 128 tiles).
  * "kkt_*": process-wide switches of emi_kkt_factor ("kkt_sticky_reg" 1 (default):
  * the Schur path starts at the dual regularisation level that worked last on this
  * mesh; "kkt_debug", "kkt_cholesky", "kkt_chol_panel", "kkt_batched_max_nodes",
@@ -305,6 +306,10 @@ int emi_last_path(emi_ctx_t ctx, int* fused);
  * Every value 0 .. ntiles_total-1 must occur exactly once (tests/test_abi.py).                                               */
 int emi_debug_tile_order(int ns, int B, int M, int sym_ct, int sym_cpart, int* out_tile, int out_cap, int* ntiles_total,
                          int* cpart, int* cx);
+/* Diagnostics, no device needed: how the one-launch pass deals an XCD's nm MFMA-role and nn node-role blocks ("pass_order":
+ * 0 evenly interleaved, 1 MFMA blocks first, >= 100 interleaved at order / 100 times the even MFMA density).  out_role[j] =
+ * MFMA block index (>= 0) or -1 - node block index; every index of either role must occur exactly once.                      */
+int emi_debug_pass_roles(int nm, int nn, int order, int* out_role, int out_cap);
 /* name of the kernel that produced the defect rows in this context's last
  * emi_eval_dev (what a rocprofv3 kernel trace will show); "" before the first  */
 const char* emi_last_defect_kernel(emi_ctx_t ctx);

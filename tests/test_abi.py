@@ -157,3 +157,26 @@ def test_every_tile_order_of_the_mfma_defect_kernel_is_a_permutation():
                             partitioned += 1
                         checked += 1
     assert checked > 5000 and partitioned > 500, (checked, partitioned)
+
+
+def test_every_role_map_of_the_one_launch_pass_is_a_bijection():
+    """emi_debug_pass_roles (no device needed): for many (MFMA blocks, node blocks) per XCD and every "pass_order" -- interleaved,
+    MFMA first, front-loaded densities up to far beyond the clamp -- each MFMA block index and each node block index is dealt
+    exactly once (pass_role_of in csrc/emi_args.hpp, one function for host and device).  A first version of the front-loaded
+    order was not a bijection above one MFMA block per block and sent node workgroups out of range: a GPU memory fault."""
+    import ctypes as C
+    from etol_amd import _lib as L
+    lib = L.load()
+    n = 0
+    for nm in (0, 1, 6, 8, 48, 96, 192, 384, 768):
+        for nn in (1, 2, 16, 32, 64, 256, 512):
+            for order in (0, 1, 100, 105, 110, 125, 150, 200, 400, 1000, 100000):
+                out = (C.c_int * (nm + nn))()
+                assert lib.emi_debug_pass_roles(nm, nn, order, out, nm + nn) == 0
+                roles = list(out)
+                assert sorted(r for r in roles if r >= 0) == list(range(nm)), (nm, nn, order)
+                assert sorted(-1 - r for r in roles if r < 0) == list(range(nn)), (nm, nn, order)
+                if order == 1:
+                    assert all(r >= 0 for r in roles[:nm])
+                n += 1
+    assert n > 500

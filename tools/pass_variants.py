@@ -62,6 +62,10 @@ VARIANTS = {
     "sw2_conc_plain_order": dict(sym_ct=6, overlap_mode=2, node_store=2, sym_cpart=-1),
     "sw2_conc_cpart4": dict(sym_ct=6, overlap_mode=2, node_store=2, sym_cpart=4),
     "sw6_conc_cpart4": dict(sym_ct=5, overlap_mode=2, node_store=2, sym_cpart=4),
+    "one_launch_sw2_front105": dict(sym_ct=6, overlap_mode=3, node_store=-1, pass_order=105),
+    "one_launch_sw2_front110": dict(sym_ct=6, overlap_mode=3, node_store=-1, pass_order=110),
+    "one_launch_sw2_front115": dict(sym_ct=6, overlap_mode=3, node_store=-1, pass_order=115),
+    "one_launch_sw2_front125": dict(sym_ct=6, overlap_mode=3, node_store=-1, pass_order=125),
     "one_launch_sw1_interleaved": dict(sym_ct=7, overlap_mode=3, node_store=-1, pass_order=0),
     "one_launch_sw1_mfma_first": dict(sym_ct=7, overlap_mode=3, node_store=-1, pass_order=1),
     "one_launch_sw2_mfma_first": dict(sym_ct=6, overlap_mode=3, node_store=-1, pass_order=1),
