@@ -30,16 +30,21 @@ FP64_MFMA_PEAK_TF = 78.6                               # MI355X fp64 matrix (SUR
 FP32_MFMA_PEAK_TF = 157.3                              # MI355X_MICROARCH.md: f32-input MFMA
 
 
-def load_pmc_traffic():
-    """HBM bytes per launch from the PMC passes of tools/pmc_traffic.sh (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE), if a summary of this round exists."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        return json.load(open(path)).get("bytes_per_launch", {})
-    except (OSError, ValueError):
-        return {}
+def load_pmc_traffic(kernel, B, M):
+    """HBM bytes per launch of `kernel` at THIS batch size and mesh from the PMC passes of tools/pmc_traffic.sh (separate
+    FETCH_SIZE / WRITE_SIZE passes, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950), if this round's summary
+    under profiles/ holds an entry for exactly that (kernel, B, M) -- a figure collected at another batch size is not this
+    run's traffic.  Returns (bytes or None, provenance or None); the counters are not collected inside bench.py (rocprofv3
+    serialises dispatches while it counts)."""
+    for tag in ("r03",):
+        path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+        try:
+            for e in json.load(open(path)).get("entries", []):
+                if e.get("kernel") == kernel and e.get("B") == B and e.get("M") == M:
+                    return e["bytes_per_launch"], f"profiles/{tag}_pmc_traffic.json ({e.get('source', 'tools/pmc_traffic.sh')})"
+        except (OSError, ValueError, KeyError):
+            pass
+    return None, None
 
 
 def usable_cores():
@@ -91,6 +96,64 @@ def cpu_baseline(M, n_obs, budget_s=10.0):
             "checker_oracle": {"value": v_orc, "cores": 1,
                                "sample": f"{p2} passes over {Bs} instances (oracle/emi_oracle.c, one thread: complex-step "
                                          f"derivatives and long-double D.X -- built for checking, not for speed), {e2:.1f} s"}}
+
+
+def check_against_oracle(ev, X, U, recs, outs, M, instances):
+    """Untimed, after the timed region, rank 0 at N = 1 only (part of the cpu_baseline leg: the oracle is the checker, never
+    the thing measured): the outputs the timed passes left in HBM against oracle/emi_oracle.c on sampled instances."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from etol_amd import workloads as W
+    e = O.sampled_errors(1, W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, W.TF, X, U, recs, outs, instances)
+    return {"max_rel_err": e["max_rel_err"], "instances": e["instances"], "defect": e["defect"], "path_rows": e["path"],
+            "jacobian_values": e["vals"], "cost": e["cost"], "against": "oracle/emi_oracle.c (complex-step derivatives, long-double D.X)",
+            "tolerance": {"defect": 5e-13, "node": 1e-13}, "ok": bool(e["defect"] < 5e-13 and e["path"] < 1e-13 and e["vals"] < 1e-13 and e["cost"] < 1e-13)}
+
+
+def roofline_of(m, def_name, key, n_obs, B, M, ns, ms_per_step):
+    """`roofline` object of one measurement.  The one-launch pass kernel does both jobs of the pass:
+    it is reported against the HBM roof (the binding one: PMC traffic puts it at 0.75 of 8 TB/s = 95 % of the ~6.3 TB/s a
+    streaming kernel reaches on this part, profiles/), with its D.X flops beside it as `mfma_roof` -- ALGORITHMIC flops, of
+    which the even/odd split executes half."""
+    c5 = key == "c5"
+    per_node = ALG_BYTES[key] if (c5 or n_obs in (0, 20)) else 560 + 24 * n_obs
+    alg_bytes = per_node * B * M                 # SURVEY.md 8d bytes/node-eval x node-evals per launch (this rank)
+    flops = 2.0 * M * ns * B * M                 # SURVEY.md 8d D.X flops/node-eval (2*M*ns) x node-evals
+    node_name = "emi_nodes_kernel"
+    peak_tf = FP32_MFMA_PEAK_TF if c5 else FP64_MFMA_PEAK_TF
+    dom_s = m["dominant_ms"] * 1e-3
+    one_launch = "emi_pass_f64_kernel" in def_name
+    kname = node_name if m["dominant"] == "node" else def_name.split("<")[0].split(" ")[0]
+    traffic, src = load_pmc_traffic(kname, B, M)
+    if m["dominant"] == "node" or one_launch:
+        ach = alg_bytes / dom_s / 1e9
+        roof = {"kernel": node_name if m["dominant"] == "node" else def_name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "avg_ms": m["dominant_ms"],
+                "algorithmic_bytes_per_launch": alg_bytes}
+        if one_launch:
+            tf = flops / dom_s / 1e12
+            roof["mfma_roof"] = {"bound": "mfma", "achieved_algorithmic": tf, "peak": peak_tf, "unit": "TFLOP/s",
+                                 "frac_algorithmic": tf / peak_tf, "executed_over_algorithmic": 0.5,
+                                 "frac_executed": 0.5 * tf / peak_tf,
+                                 "note": "D.X flops 2*M*ns per node-eval are ALGORITHMIC; the even/odd split of the LGL matrix executes half of them"}
+    else:
+        ach = flops / dom_s / 1e12
+        roof = {"kernel": def_name, "bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s",
+                "frac": ach / peak_tf, "traffic": traffic, "avg_ms": m["dominant_ms"], "algorithmic_flops_per_launch": flops}
+        if not c5:
+            roof["executed_over_algorithmic"] = 0.5 if "symdefect" in def_name else 1.0
+    roof["traffic_source"] = src if traffic is not None else ("none for this (kernel, B, M): PMC passes are separate rocprofv3 runs "
+                                                              "(tools/pmc_traffic.sh), see profiles/")
+    if traffic is not None:
+        roof["traffic_frac_of_peak"] = traffic / dom_s / 1e9 / HBM_PEAK_GBS
+        roof["traffic_over_algorithmic"] = traffic / alg_bytes
+    roof["kernels_ms_warmup"] = {node_name: m["warm_node_ms"], def_name: m["warm_defect_ms"]}
+    roof["concurrent"] = m["overlapped"]
+    roof["pass_hbm_frac"] = alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+    roof["note"] = ("avg_ms: HIP events on the launch stream -- around the dominant kernel in every pass of the timed region, "
+                    "or (one-launch pass: one kernel per pass) around the whole timed region / steps; "
+                    "kernels_ms_warmup: the kernels bracketed during the warm-up passes")
+    return roof
 
 
 PRE_WARM_S = 0.25      # untimed clock warm-up ahead of the W warm-up steps (see measure())
@@ -155,6 +218,7 @@ def main():
     ap.add_argument("--obstacles", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-weak", action="store_true", help="skip the second, weak-scaled measurement of a multi-GPU run")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-5 (fp32) measurement appended to the default run")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     a = ap.parse_args()
 
@@ -193,14 +257,14 @@ def main():
     M = a.nodes or (4096 if c5 else 1024)
     n_obs = 0 if c5 else a.obstacles
     ns = 12 if c5 else 6
-    dt = torch.float32 if c5 else torch.float64
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    def build(B, first):
+    def build(B, first, c5=c5, M=M, n_obs=n_obs):
         """evaluator + resident inputs for scenarios [first, first + B)"""
+        dt = torch.float32 if c5 else torch.float64
         ev = E.Evaluator(local, f32=c5)
         ev.set_mesh(M, 0.0, 20.0 if c5 else W.TF)
         if c5:
@@ -232,7 +296,7 @@ def main():
         dU = torch.from_numpy(U).to(dev, dt)
         outs = ev.alloc_outputs()
         torch.cuda.synchronize()
-        return ev, dX, dU, outs
+        return ev, dX, dU, outs, (X, U, recs)
 
     def reduce_max(x):
         t = torch.tensor([x], dtype=torch.float64, device=ctl)
@@ -249,7 +313,7 @@ def main():
         S, scaling = a.scenarios, "strong"
         lo, hi = shard.shard_range(S, world, rank)
     B = hi - lo
-    ev, dX, dU, outs = build(B, lo)
+    ev, dX, dU, outs, host = build(B, lo)
     m = measure(ev, dX, dU, outs, a.steps, a.warmup, barrier, torch)
     el = reduce_max(m["seconds"])
     ms_per_step = 1e3 * el / a.steps
@@ -267,14 +331,19 @@ def main():
         gather_ms = 1e3 * (time.perf_counter() - tg)
         if rank == 0:
             assert got[0].shape[0] == S and torch.equal(got[0][:B].to(dX.device), dX)
+    checked = None
+    if rank == 0 and world == 1 and not c5 and not a.no_cpu_baseline:
+        # untimed: what the timed passes left in HBM, against the CPU oracle on sampled instances (first / last of the batch,
+        # both sides of a 16-instance tile edge, the middle)
+        checked = check_against_oracle(ev, host[0], host[1], host[2] if n_obs else None, outs, M, [0, 15, 16, B // 2, B - 1])
     ev.close()
-    del dX, dU, outs
+    del dX, dU, outs, host
     torch.cuda.empty_cache()
 
     weak = None
     if world > 1 and scaling == "strong" and not a.no_weak:
         Bw = a.scenarios
-        evw, wX, wU, wouts = build(Bw, rank * Bw)
+        evw, wX, wU, wouts, _ = build(Bw, rank * Bw)
         mw = measure(evw, wX, wU, wouts, a.steps, a.warmup, barrier, torch)
         elw = reduce_max(mw["seconds"])
         weak = {"value": world * Bw * M * a.steps / elw, "unit": "node-evals/s", "instances_per_gpu": Bw,
@@ -283,37 +352,7 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel: algorithmic work per launch / its average launch time in the timed region
-        key = "c5" if c5 else ("c3" if n_obs == 20 else "c2")
-        per_node = ALG_BYTES[key] if (c5 or n_obs in (0, 20)) else 560 + 24 * n_obs
-        alg_bytes = per_node * B * M                 # SURVEY.md 8d bytes/node-eval x node-evals per launch (this rank)
-        flops = 2.0 * M * ns * B * M                 # SURVEY.md 8d D.X flops/node-eval (2*M*ns) x node-evals
-        node_name = "emi_nodes_kernel"
-        traffic = load_pmc_traffic()
-        peak_tf = FP32_MFMA_PEAK_TF if c5 else FP64_MFMA_PEAK_TF
-        if m["dominant"] == "node":
-            ach = alg_bytes / (m["dominant_ms"] * 1e-3) / 1e9
-            roof = {"kernel": node_name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": traffic.get(node_name), "avg_ms": m["dominant_ms"]}
-        else:
-            ach = flops / (m["dominant_ms"] * 1e-3) / 1e12
-            roof = {"kernel": def_name, "bound": "mfma", "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s",
-                    "frac": ach / peak_tf, "traffic": traffic.get(def_name.split("<")[0]), "avg_ms": m["dominant_ms"]}
-            if "emi_pass_f64_kernel" in def_name:
-                # the one-launch pass: the same kernel also moves the pass's bytes -- the roof it is closer to is reported as
-                # the bound, the other one beside it
-                hb = alg_bytes / (m["dominant_ms"] * 1e-3) / 1e9
-                other = {"bound": "hbm", "achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS}
-                if other["frac"] > roof["frac"]:
-                    mf = {k: roof[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
-                    roof.update(other)
-                    other = mf
-                roof["second_roof"] = other
-        roof["kernels_ms_warmup"] = {node_name: m["warm_node_ms"], def_name: m["warm_defect_ms"]}
-        roof["concurrent"] = m["overlapped"]
-        roof["pass_hbm_frac"] = alg_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
-        roof["note"] = ("avg_ms: HIP events on the launch stream -- around the dominant kernel in every pass of the timed region, "
-                        "or (one-launch pass: one kernel per pass) around the whole timed region / steps; "
-                        "kernels_ms_warmup: the kernels bracketed during the warm-up passes")
+        roof = roofline_of(m, def_name, "c5" if c5 else ("c3" if n_obs == 20 else "c2"), n_obs, B, M, ns, ms_per_step)
         if c5:
             workload = (f"config[4]: 12-state fixed-wing VGP, N={M} LGL nodes, fp32 path with MFMA D.X defect, "
                         f"{B} instances per GPU")
@@ -335,6 +374,28 @@ def main():
         }
         if weak:
             line["weak_scaling"] = weak
+        if checked is not None:
+            line["checked"] = checked
+        if world == 1 and not c5 and not a.batch and not a.nodes and not a.no_secondary:
+            # config 5 (BASELINE.json configs[4]) on the same record: 12-state fixed wing, N = 4096, fp32 path with the MFMA
+            # D.X defect, 256 instances, fewer steps (a pass is ~1 ms); its own roofline against the f32 MFMA peak and
+            # 944 algorithmic bytes per node-eval
+            B5, M5, K5, W5 = 256, 4096, max(10, min(a.steps, 50)), max(2, min(a.warmup, 5))
+            ev5, X5, U5, outs5, _ = build(B5, 0, c5=True, M=M5, n_obs=0)
+            m5 = measure(ev5, X5, U5, outs5, K5, W5, barrier, torch)
+            ms5 = 1e3 * m5["seconds"] / K5
+            name5 = ev5.last_defect_kernel
+            r5 = roofline_of(m5, name5, "c5", 0, B5, M5, 12, ms5)
+            r5["pass_mfma_frac"] = 2.0 * M5 * 12 * B5 * M5 / (ms5 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF
+            line["secondary"] = {"c5": {"metric": "collocation-node constraint+Jacobian evals/sec, 12-state VGP N=4096 (fp32, config 5)",
+                                        "value": B5 * M5 * K5 / m5["seconds"], "unit": "node-evals/s", "ms_per_step": ms5, "steps": K5,
+                                        "warmup": W5, "dtype": "f32", "data": "synthetic",
+                                        "config": {"workload": f"config[4]: 12-state fixed-wing VGP, N={M5} LGL nodes, fp32 path with MFMA "
+                                                               f"D.X defect, {B5} instances per GPU"},
+                                        "roofline": r5}}
+            ev5.close()
+            del X5, U5, outs5
+            torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline and not c5:
             line["cpu_baseline"] = cpu_baseline(M, n_obs, a.cpu_budget)
         print(json.dumps(line), flush=True)

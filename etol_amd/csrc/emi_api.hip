@@ -721,12 +721,6 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             // interleaved; 64: 0.0249 / 0.0264; 224: 0.0583 / 0.0686).  From 256 instances the even interleave wins (0.0727 / 0.0748), at 1024 by far
             // (0.226 / 0.292: the node role would start when the MFMA role is half done).
             sa.mfma_first = c->pass_order >= 0 ? c->pass_order : (tiles16 < 128);
-            if (sa.mfma_first >= 100) {     // a density: at most one MFMA block per block (pass_role_of stays a bijection)
-                const long long nm = (long long)tiles16 * (c->ns / plan.sw) * (plan.ks > 1 ? plan.ks : 1);
-                const long long nn = (long long)((c->M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS)) * c->B;
-                const long long dmax = nm > 0 ? 100 * (nm + nn) / nm : 100;
-                if (sa.mfma_first > dmax) sa.mfma_first = (int)dmax;
-            }
             if (c->rtc ? emi::rtc_pass_supported(c->rtc, c->B, c->M, plan.sw, plan.ks, na.store_mode)
                        : emi::pass_supported(c->model, c->ns, c->B, c->M, plan)) {
                 sa.cpart = plan.cpart; sa.cx = plan.cx;
@@ -1169,7 +1163,6 @@ int emi_last_path(emi_ctx_t c, int* fused) {
 /* name of the kernel that produced the defect rows in the last emi_eval_dev of this context (for reports) */
 int emi_debug_pass_roles(int nm, int nn, int order, int* out_role, int out_cap) {
     if (nm < 0 || nn < 0 || nm + nn < 1 || !out_role || out_cap < nm + nn) return EMI_ERR_ARG;
-    if (order >= 100 && nm > 0 && order > 100LL * (nm + nn) / nm) order = (int)(100LL * (nm + nn) / nm);     // as emi_eval_dev clamps it
     for (int j = 0; j < nm + nn; ++j) {
         const emi::PassRole r = emi::pass_role_of(j, nm, nn, order);
         out_role[j] = r.mfma ? r.index : -1 - r.index;

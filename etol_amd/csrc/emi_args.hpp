@@ -16,6 +16,22 @@
 
 #define EMI_NODE_THREADS 256
 
+// Memory order of the arrival tickets (COST finish of the node role, split-K combine of the MFMA role).  The partial sums
+// travel as agent-scope (sc1, write-through / L1-bypassing) stores and loads with a drained vmcnt in between -- one of the
+// hand-off forms MI355X_MICROARCH.md measures as valid -- and the ticket itself is ACQ_REL so that the ordering also holds by
+// the HIP memory model, not only by the ISA's behaviour.  -DEMI_TICKET_RELAXED: the round-2 form (build-time A/B only).
+#ifdef EMI_TICKET_RELAXED
+#define EMI_TICKET_ORDER __ATOMIC_RELAXED
+#else
+#define EMI_TICKET_ORDER __ATOMIC_ACQ_REL
+#endif
+// one wait state between an SALU write of m0 and an LDS-DMA instruction (-DEMI_NO_M0_NOP: the round-2 form, A/B only)
+#ifdef EMI_NO_M0_NOP
+#define EMI_M0_NOP ""
+#else
+#define EMI_M0_NOP "s_nop 0\n\t"
+#endif
+
 // defect GEMM tile (fp64 MFMA path)
 #define DEF_TM 96
 #define DEF_TN 128
@@ -129,8 +145,8 @@ inline RingTile ring_tile_of(int tl, int ntiles, int ngrp, int cpart, int cx) {
 }
 // Role of block j of an XCD's share of the one-launch pass grid (nm MFMA-role and nn node-role blocks): {is_mfma, index within
 // the role}.  order 0: evenly interleaved; 1: all MFMA blocks first; >= 100: interleaved with the MFMA blocks at order / 100 times
-// the even density until they are used up, node blocks at the tail (the launcher clamps the density to one MFMA block per
-// block, which keeps the map a bijection).  One function for the kernel and for the host-side check (emi_debug_pass_roles).
+// the even density until they are used up, node blocks at the tail (the density is clamped HERE to one MFMA block per block,
+// which keeps the map a bijection for every caller: the first form of this map, unclamped, sent node workgroups out of range).  One function for the kernel and for the host-side check (emi_debug_pass_roles).
 struct PassRole { int mfma, index; };
 #if defined(__HIPCC__)
 __host__ __device__
@@ -142,7 +158,8 @@ inline PassRole pass_role_of(int j, int nm, int nn, int order) {
         m0 = j < nm ? j : nm;
         m1 = j < nm ? j + 1 : nm;
     } else {
-        const long long d = order >= 100 ? order : 100;
+        long long d = order >= 100 ? order : 100;
+        if (nm > 0 && d * nm > 100 * t) d = 100 * t / nm;       // at most one MFMA block per block: the map stays a bijection
         m0 = ((long long)j * nm * d) / (100 * t);
         m1 = ((long long)(j + 1) * nm * d) / (100 * t);
         if (m0 > nm) m0 = nm;

@@ -17,29 +17,59 @@
 #include <mutex>
 #include <string>
 
+#include <type_traits>
+
 #include "emi355x.h"
+
+// The prototypes of the eight RCCL entry points this file calls.  Where <rccl/rccl.h> is installed (this image: ROCm 7.2)
+// the real header is included and every function-pointer type of the table below is CHECKED against it at compile time;
+// where it is not, the declarations that follow stand in (opaque handle, 128-byte id, int enums: the ABI-stable part).
+// librccl itself is never linked: decltype(&ncclSend) names a type, not a symbol.
+#if defined(__has_include)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#define EMI_HAVE_RCCL_H 1
+#endif
+#endif
+#ifndef EMI_HAVE_RCCL_H
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+enum { ncclSuccess = 0 };
+enum { ncclInt8 = 0 };
+#endif
 
 namespace {
 
-// the part of rccl.h this file needs (types are ABI-stable: opaque handle, 128-byte id, int enums)
-typedef struct ncclComm* ncclComm_t;
-typedef struct { char internal[128]; } ncclUniqueId;
 static_assert(sizeof(ncclUniqueId) == EMI_COMM_ID_BYTES, "id size");
-enum { ncclSuccess = 0 };
-enum { ncclInt8 = 0 };
+static_assert((int)ncclSuccess == 0 && (int)ncclInt8 == 0 && sizeof(ncclResult_t) == sizeof(int) && sizeof(ncclDataType_t) == sizeof(int),
+              "RCCL enum values / sizes this file relies on");
 
 struct Rccl {
     void* h = nullptr;
-    int (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
+#ifdef EMI_HAVE_RCCL_H
+#define EMI_SAME(member, fn) static_assert(std::is_same<decltype(Rccl::member), decltype(&fn)>::value, #fn ": prototype differs from rccl.h")
+EMI_SAME(GetUniqueId, ncclGetUniqueId);
+EMI_SAME(CommInitRank, ncclCommInitRank);
+EMI_SAME(CommDestroy, ncclCommDestroy);
+EMI_SAME(GroupStart, ncclGroupStart);
+EMI_SAME(GroupEnd, ncclGroupEnd);
+EMI_SAME(Send, ncclSend);
+EMI_SAME(Recv, ncclRecv);
+EMI_SAME(GetErrorString, ncclGetErrorString);
+#undef EMI_SAME
+#endif
 
 Rccl* rccl() {
     static Rccl R;
@@ -93,7 +123,7 @@ int emi_comm_unique_id(void* id) {
     Rccl* R = rccl();
     if (!R) return cfail(nullptr, EMI_ERR_COMM, "librccl unavailable");
     ncclUniqueId u;
-    const int st = R->GetUniqueId(&u);
+    const ncclResult_t st = R->GetUniqueId(&u);
     if (st != ncclSuccess) return cfail(nullptr, EMI_ERR_COMM, "ncclGetUniqueId: %s", R->GetErrorString(st));
     memcpy(id, &u, sizeof u);
     return EMI_OK;
@@ -108,7 +138,7 @@ int emi_comm_create(int device_id, int world, int rank, const void* id, emi_comm
     c->world = world; c->rank = rank; c->device = device_id;
     ncclUniqueId u;
     memcpy(&u, id, sizeof u);
-    const int st = R->CommInitRank(&c->comm, world, u, rank);
+    const ncclResult_t st = R->CommInitRank(&c->comm, world, u, rank);
     if (st != ncclSuccess) {
         cfail(nullptr, EMI_ERR_COMM, "ncclCommInitRank(world %d, rank %d): %s", world, rank, R->GetErrorString(st));
         delete c;
@@ -133,14 +163,14 @@ int emi_comm_gather(emi_comm_t c, const void* dsend, void* drecv, size_t bytes, 
     if (c->rank == root &&
         hipMemcpyAsync((char*)drecv + (size_t)root * bytes, dsend, bytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
         return cfail(c, EMI_ERR_HIP, "emi_comm_gather: local copy");
-    int st = R->GroupStart();
+    ncclResult_t st = R->GroupStart();
     if (st == ncclSuccess && c->rank == root) {
         for (int r = 0; r < c->world && st == ncclSuccess; ++r)
             if (r != root) st = R->Recv((char*)drecv + (size_t)r * bytes, bytes, ncclInt8, r, c->comm, s);
     } else if (st == ncclSuccess) {
         st = R->Send(dsend, bytes, ncclInt8, root, c->comm, s);
     }
-    const int st2 = R->GroupEnd();
+    const ncclResult_t st2 = R->GroupEnd();
     if (st == ncclSuccess) st = st2;
     if (st != ncclSuccess) return cfail(c, EMI_ERR_COMM, "RCCL gather: %s", R->GetErrorString(st));
     if (!hip_stream && hipStreamSynchronize(s) != hipSuccess) return cfail(c, EMI_ERR_HIP, "emi_comm_gather: synchronize");

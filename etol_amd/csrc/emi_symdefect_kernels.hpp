@@ -241,13 +241,15 @@ __global__ __launch_bounds__(256, 2) void emi_symdefect_ring_f64_kernel(SymDefec
     // after the DMA of tile kt+LOOK is issued the wave waited for that very tile -- no tile in flight at all, every K tile
     // paid a full DMA round trip (the ISA of rounds 1-2; profiles/r02_notes.md section 9).  The counted vmcnt waits of
     // the K loop are the only synchronisation with the DMA the ring needs.  m0 = LDS address of the 1 KB the wave writes.
+    // (s_nop 0 between the SALU write of m0 and the DMA: gfx9-family parts need one wait state there, and the hazard
+    // recogniser does not look inside inline assembly -- the builtin form gets the same s_nop from the compiler.)
     const unsigned lds0 = (unsigned)(unsigned long)(emi_lds_ptr_t)smem;          // LDS byte address of the ring
     auto issue = [&](int stage, int kt) {
 #pragma unroll
         for (int t = 0; t < L; ++t) {
             const unsigned dst = lds0 + (unsigned)stage * (unsigned)(STAGE * 8) + (unsigned)(wid + 4 * t) * 1024u;   // wave-uniform
             const double* g = src[t] + (ptrdiff_t)kdir[t] * kt * BK;
-            asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %1\n\t" EMI_M0_NOP "global_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
         }
     };
 
@@ -493,6 +495,8 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     // after the DMA of tile kt+LOOK is issued the wave waited for that very tile -- no tile in flight at all, every K tile
     // paid a full DMA round trip (the ISA of rounds 1-2; profiles/r02_notes.md section 9).  The counted vmcnt waits of
     // the K loop are the only synchronisation with the DMA the ring needs.  m0 = LDS address of the 1 KB the wave writes.
+    // (s_nop 0 between the SALU write of m0 and the DMA: gfx9-family parts need one wait state there, and the hazard
+    // recogniser does not look inside inline assembly -- the builtin form gets the same s_nop from the compiler.)
     const unsigned lds0 = (unsigned)(unsigned long)(emi_lds_ptr_t)smem;          // LDS byte address of the ring
     // running state of the ring, all wave-uniform (SALU): next tile to request, where it goes, where the next fragment
     // reads come from -- an add per DMA instruction instead of a 64-bit multiply by the tile index and a modulo
@@ -504,7 +508,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     int nd = 0;                         // tiles requested so far
     auto issue_one = [&](int t) {       // instruction t of tile nd; the last one moves the ring on
         const unsigned dst = lds0 + st_dma + (unsigned)(wid + 4 * t) * 1024u;   // wave-uniform
-        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[t]), "s"(gnext[t]), "s"(dst) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\t" EMI_M0_NOP "global_load_lds_dwordx4 %0, %1" ::"v"(voff[t]), "s"(gnext[t]), "s"(dst) : "memory", "m0");
         gnext[t] += (long long)gstep[t];
         if (t == L - 1) {
             st_dma = st_dma == (unsigned)((NST - 1) * STAGE * 8) ? 0u : st_dma + (unsigned)(STAGE * 8);
@@ -659,7 +663,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                // every thread's partial sums are out (and the ring is no longer read)
         unsigned* flag = reinterpret_cast<unsigned*>(smem);
-        if (tid == 0) *flag = __hip_atomic_fetch_add(a.tile_ticket + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) *flag = __hip_atomic_fetch_add(a.tile_ticket + tile, 1u, EMI_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);   // release: this slice's sums; acquire: the others'
         __syncthreads();
         if (*flag != (unsigned)KS - 1u) return;
 #pragma unroll

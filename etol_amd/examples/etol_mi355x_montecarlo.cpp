@@ -16,8 +16,11 @@
 // device model or (5th argument "traced") written with mi355x::Var arithmetic and compiled at setup().
 #include <ETOL/eMI355X.hpp>
 #include <emi355x.h>
+#include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -71,29 +74,55 @@ struct Result {
 constexpr int REC_HEAD = 5;
 size_t record_doubles(int M) { return REC_HEAD + (size_t)(6 + 2 + 1) * M; }
 
-// the 128-byte RCCL id goes from rank 0 to the others through a file (one node, shared /tmp)
-bool exchange_id(int rank, char* id) {
-    std::string path = getenv("EMI_COMM_FILE") ? getenv("EMI_COMM_FILE")
-                                               : "/tmp/emi_comm_" + std::to_string((long)getppid()) + "_" +
-                                                     std::string(getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + ".id";
+// The 128-byte RCCL id goes from rank 0 to the others through a file (one node, shared /tmp), AT START-UP, before any
+// solving: the ranks of a launch start within seconds of each other, so a bounded wait means something there (after the
+// solves rank 0 may be minutes behind the others).  The name carries what the launcher gives to tell runs apart (launcher
+// pid, MASTER_PORT, torchrun's run id and restart count); a file older than a minute before this process started is a
+// leftover of a crashed run and is not read; rank 0 removes leftovers before it writes and removes its own file once the
+// communicator exists on every rank (comm_file_done).
+std::string comm_file_path() {
+    if (getenv("EMI_COMM_FILE")) return getenv("EMI_COMM_FILE");
+    auto env = [](const char* n, const char* d) { const char* v = getenv(n); return std::string(v ? v : d); };
+    return "/tmp/emi_comm_" + std::to_string((long)getppid()) + "_" + env("MASTER_PORT", "0") + "_" + env("TORCHELASTIC_RUN_ID", "run") +
+           "_" + env("TORCHELASTIC_RESTART_COUNT", "0") + ".id";
+}
+bool exchange_id(int rank, char* id, double process_start_s, std::string* why) {
+    const std::string path = comm_file_path();
     if (rank == 0) {
-        if (emi_comm_unique_id(id) != EMI_OK) { fprintf(stderr, "emi_comm_unique_id: %s\n", emi_comm_last_error(nullptr)); return false; }
+        unlink(path.c_str());                            // a leftover of an earlier run under the same name
+        if (emi_comm_unique_id(id) != EMI_OK) { *why = std::string("emi_comm_unique_id: ") + emi_comm_last_error(nullptr); return false; }
         const std::string tmp = path + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id, 1, EMI_COMM_ID_BYTES, f) != EMI_COMM_ID_BYTES) return false;
+        if (!f || fwrite(id, 1, EMI_COMM_ID_BYTES, f) != EMI_COMM_ID_BYTES) { *why = "cannot write " + tmp; if (f) fclose(f); return false; }
         fclose(f);
-        return rename(tmp.c_str(), path.c_str()) == 0;
+        if (rename(tmp.c_str(), path.c_str()) != 0) { *why = "cannot rename " + tmp; return false; }
+        return true;
     }
-    for (int tries = 0; tries < 1200; ++tries) {       // up to two minutes
-        FILE* f = fopen(path.c_str(), "rb");
-        if (f) {
-            const size_t n = fread(id, 1, EMI_COMM_ID_BYTES, f);
-            fclose(f);
-            if (n == EMI_COMM_ID_BYTES) return true;
+    const int timeout_s = std::max(1, env_int("EMI_COMM_TIMEOUT_S", 120));
+    bool stale = false;
+    for (int tries = 0; tries < timeout_s * 10; ++tries) {
+        struct stat sb;
+        if (stat(path.c_str(), &sb) == 0) {
+            const double mt = (double)sb.st_mtim.tv_sec + 1e-9 * (double)sb.st_mtim.tv_nsec;
+            if (mt < process_start_s - 60.0) {
+                stale = true;                            // not this launch's file: wait for rank 0 to replace it
+            } else {
+                FILE* f = fopen(path.c_str(), "rb");
+                if (f) {
+                    const size_t n = fread(id, 1, EMI_COMM_ID_BYTES, f);
+                    fclose(f);
+                    if (n == EMI_COMM_ID_BYTES) return true;
+                }
+            }
         }
         usleep(100000);
     }
+    *why = "no RCCL id from rank 0 in " + path + " after " + std::to_string(timeout_s) + " s (EMI_COMM_TIMEOUT_S)" +
+           (stale ? "; only a file of an earlier run is there" : "") + ": is rank 0 running, and is /tmp shared between the ranks?";
     return false;
+}
+void comm_file_done(int rank) {
+    if (rank == 0 && !getenv("EMI_COMM_FILE_KEEP")) unlink(comm_file_path().c_str());
 }
 
 Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
@@ -188,6 +217,17 @@ int main(int argc, char** argv) {
             emi_destroy(sw);
         }
     }
+    char comm_id[EMI_COMM_ID_BYTES] = {0};
+    const bool gather = env_int("EMI_MC_GATHER", 1) != 0;
+    if (gather) {
+        struct timespec ts;
+        clock_gettime(CLOCK_REALTIME, &ts);
+        std::string why;
+        if (!exchange_id(rank, comm_id, (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec, &why)) {
+            fprintf(stderr, "rank %d: RCCL id exchange: %s\n", rank, why.c_str());
+            return EXIT_FAILURE;
+        }
+    }
     std::vector<Result> results(hi - lo);
     std::atomic<int> next(lo);
     const auto t0 = std::chrono::steady_clock::now();
@@ -214,7 +254,7 @@ int main(int argc, char** argv) {
            (hi - lo) / wall, results.empty() ? 0.0 : iters / results.size());
 
     // ---- the one collective: every rank's trajectories to rank 0 over RCCL ------------------------------
-    if (env_int("EMI_MC_GATHER", 1)) {
+    if (gather) {
         const int M = nsteps + 1, per_rank = (nscen + world - 1) / world;    // equal-sized blocks, padded
         const size_t rec = record_doubles(M), bytes = (size_t)per_rank * rec * sizeof(double);
         std::vector<double> block((size_t)per_rank * rec, 0.0);
@@ -230,12 +270,11 @@ int main(int argc, char** argv) {
             }
         }
         auto die = [&](const char* what, const char* why) { fprintf(stderr, "rank %d: %s: %s\n", rank, what, why); return EXIT_FAILURE; };
-        char id[EMI_COMM_ID_BYTES];
-        if (!exchange_id(rank, id)) return die("RCCL id exchange", "no id file");
         emi_ctx_t ctx = nullptr;
         emi_comm_t comm = nullptr;
         if (emi_create(device, &ctx) != EMI_OK) return die("emi_create", "no device");
-        if (emi_comm_create(device, world, rank, id, &comm) != EMI_OK) return die("emi_comm_create", emi_comm_last_error(nullptr));
+        if (emi_comm_create(device, world, rank, comm_id, &comm) != EMI_OK) return die("emi_comm_create", emi_comm_last_error(nullptr));
+        comm_file_done(rank);                           // every rank holds the id by now (ncclCommInitRank is collective)
         void *dsend = nullptr, *drecv = nullptr;
         if (emi_dev_alloc(ctx, bytes, &dsend) != EMI_OK || (rank == 0 && emi_dev_alloc(ctx, bytes * world, &drecv) != EMI_OK))
             return die("emi_dev_alloc", emi_last_error(ctx));

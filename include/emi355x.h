@@ -157,6 +157,10 @@ int emi_synchronize(emi_ctx_t ctx);
  * EMI_EVAL_NODES only.                                                            */
 int emi_set_mesh(emi_ctx_t ctx, int M, const double* tau, const double* w,
                  const double* D, double t0, double tf);
+/* Selects a built-in model.  emi_set_model and emi_set_model_source DROP the path-row
+ * table of the context (np = 0: its px / py name states of the previous model, which
+ * the new one need not have): emi_set_path, and emi_set_tracks where rows of kind
+ * EMI_PATH_TRACK are used, must follow every model change.                        */
 int emi_set_model(emi_ctx_t ctx, int model, const double* params, int nparams,
                   int maximize);
 /* Model given as C++ text: the definition of
@@ -173,7 +177,8 @@ int emi_set_model(emi_ctx_t ctx, int model, const double* params, int nparams,
  * indices, states first) is the union over the rows, and VALS holds n_path_vars
  * partials per traced row (entry ns*(ns+nc) + 2*np_table + j*n_path_vars + q =
  * d c_j / d z_path_vars[q]) between the table rows' pairs and the cost gradient.
- * Replaces a previous emi_set_model / emi_set_model_source.                    */
+ * Replaces a previous emi_set_model / emi_set_model_source (and, like them, drops
+ * the table of emi_set_path).                                                  */
 int emi_set_model_source(emi_ctx_t ctx, const char* struct_name, const char* source,
                          int ns, int nc, int npath, const int* path_vars, int n_path_vars,
                          const double* params, int nparams, int maximize);

@@ -4,15 +4,21 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this file's library; nothing under etol_amd/ or include/ does.
  *
- * PARITY UNPINNED against ePSOPT outputs: the reference ships no tests, golden
- * vectors or expected outputs for this path, and PSOPT 5.0.0 / ADOL-C / IPOPT
- * (where its arithmetic lives) are neither in the reference tree nor
- * installed, so ePSOPT cannot be run here.  What pins
- * this oracle instead is listed in tests/golden/README.md: LGL closed forms
- * and invariants, the analytic optimum of the obstacle-free shipped problem,
- * the reference's own analytic ellipse partials
- * (src/Examples/Dymos/etol_dymos_example1.cpp:239-240), and sympy-derived
- * Jacobians/Hessians of the models at seeded points.
+ * PARITY STATUS, precisely (tests/golden/README.md):
+ *   PINNED BY REFERENCE-EXECUTED VECTORS (oracle/_ref, built from the reference's own sources where they lie):
+ *     the node callbacks of the shipped problem -- objFunction, dxConstraint, dyConstraint, obsConstraint,
+ *     saaConstraint of src/Examples/Dymos/etol_dymos_example1.cpp, values and partials -- and the waypoint
+ *     interpolation of include/ETOL/TrajectoryOptimizer.hpp:239-258 (orc_track_centres is bit-exact with it):
+ *     tests/golden/ref_dymos_ex1.json, ref_interp.json, ref_traj.json, tests/test_ref_vectors.py.
+ *   PINNED BY A RESTATEMENT ONLY: the per-edge constants (xc, yc, radsq, tt) that orc_edge_ellipse computes follow
+ *     setExz (etol_dymos_example1.cpp:316-326), which needs CGAL-linked objects and cannot run here; the generator
+ *     restates its four formulas in Python (tests/golden/gen_ref_vectors.py:63-71), so orc_edge_ellipse is checked
+ *     against that restatement and against the reference callbacks FED with it, not against setExz output.
+ *   PINNED BY CLOSED FORMS ONLY: LGL nodes / weights / D, defect D.X - h F, quadrature (PSOPT 5.0.0 is not in the
+ *     reference tree): 50-digit mpmath values and invariants; the build's quadrotor / fixed-wing models: sympy.
+ *   UNPINNED: ePSOPT's solved trajectories (PSOPT / ADOL-C / IPOPT absent, ordinary missing dependencies: SURVEY.md
+ *     section 8c); the analytic optimum of the obstacle-free shipped problem and an independent CPU optimiser
+ *     (tests/indep_nlp.py) stand in.
  *
  * What is restated, and from where (paths in the reference tree):
  *   node loop, evaluation order     src/ePSOPT/ePSOPT.cpp:218-276 (dae),

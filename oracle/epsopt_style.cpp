@@ -1,9 +1,9 @@
 // epsopt_style.cpp -- "ePSOPT-style" CPU evaluator.  TEST INFRASTRUCTURE ONLY
 // (used by tests/ as a third opinion and by bench.py's cpu_baseline leg).
 //
-// PARITY UNPINNED: see the header of emi_oracle.c.  This file is a PORT, not
-// the reference binary: real ePSOPT needs PSOPT 5.0.0 + ADOL-C + IPOPT, none
-// of which exist here.
+// Parity status: as the header of emi_oracle.c states it (node callbacks pinned by reference-executed
+// vectors, LGL / defect by closed forms, ePSOPT's solved trajectories unpinned).  This file is a PORT,
+// not the reference binary: real ePSOPT needs PSOPT 5.0.0 + ADOL-C + IPOPT, none of which exist here.
 //
 // It reproduces the *shape* of the reference's per-node work so that the CPU
 // number printed beside the GPU number carries the same overheads:

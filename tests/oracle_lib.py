@@ -126,3 +126,30 @@ def hessian(model, params, M, mesh, t0, tf, X, U, lamF, lamC, sigma=1.0, recs=No
                           px, py, tx.shape[1], tx.shape[0], _dp(tx), _dp(ty), _dp(X), _dp(U), _dp(lamF), _dp(lamC),
                           float(sigma), _dp(H)) == 0
     return H
+
+
+def sampled_errors(model, params, M, mesh, t0, tf, X, U, recs, got, instances, maximize=False):
+    """Compare device results of a LARGE batch with the oracle on a few sampled instances (the oracle takes ~10 ms per
+    1024-node instance).  X, U, recs: host arrays of the whole batch (recs per instance or one shared set); got = (RES,
+    VALS, COST) as arrays or torch tensors of the whole batch.  Returns the worst errors in the units of the parity
+    tolerances of tests/test_gpu_parity.py: defect rows relative to sum_j |D_kj||x_j| + |row| + 1, node rows / VALS
+    entries relative to the entry's largest magnitude + 1, COST relative."""
+    ns = MODEL_DIMS[model][0]
+    idx = sorted({int(i) for i in instances if 0 <= int(i) < X.shape[0]})
+    Xs, Us = np.ascontiguousarray(X[idx]), np.ascontiguousarray(U[idx])
+    rs = None
+    if recs is not None and np.size(recs):
+        recs = np.asarray(recs)
+        rs = recs[idx] if recs.ndim == 3 and recs.shape[0] == X.shape[0] and recs.shape[0] > 1 else recs
+    ref = evaluate(model, params, M, mesh, t0, tf, Xs, Us, rs, maximize=maximize)
+    pick = lambda a: (a[idx].cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)[idx])
+    RES, VALS, COST = (pick(a) for a in got)
+    absD = np.abs(np.asarray(mesh[2]))
+    scale = np.einsum("kj,bij->bik", absD, np.abs(Xs)) + np.abs(ref[0][:, :ns]) + 1.0
+    out = {"instances": idx,
+           "defect": float((np.abs(RES[:, :ns] - ref[0][:, :ns]) / scale).max()),
+           "path": float(np.abs(RES[:, ns:] - ref[0][:, ns:]).max() / (np.abs(ref[0][:, ns:]).max() + 1.0)) if RES.shape[1] > ns else 0.0,
+           "vals": float(max(np.abs(VALS[:, e] - ref[1][:, e]).max() / (np.abs(ref[1][:, e]).max() + 1.0) for e in range(VALS.shape[1]))),
+           "cost": float(np.abs(COST - ref[2]).max() / (np.abs(ref[2]).max() + 1.0))}
+    out["max_rel_err"] = max(out["defect"], out["path"], out["vals"], out["cost"])
+    return out

@@ -686,3 +686,86 @@ def test_mfma_defect_kernel_variants_for_the_two_state_model(built, sym_ct):
         assert ev.uses_fused_kernel
         check(dict(X=X), ev, got, ref)
     ev.close()
+
+
+def _expected_default_form(B, M=1024):
+    """What emi_eval_dev's policy picks for the 6-state model by itself (csrc/emi_api.hip: one launch below 192 and from
+    384 sixteen-instance x 128-node tiles, two streams in between; batches above 2048 instances in slices of 1024)."""
+    last = B if B <= 2048 else (B % 1024 or 1024)
+    tiles16 = ((last + 15) // 16) * (M // 128)
+    if tiles16 < 192:
+        return "emi_pass_f64_kernel<SW=1>"
+    if tiles16 >= 384:
+        return "emi_pass_f64_kernel<SW=2>"
+    return "emi_symdefect_ring"
+
+
+@pytest.mark.parametrize("B", [128, 512, 1024, 2064])
+def test_default_dispatch_at_the_benchmarked_shapes_matches_the_oracle(built, B):
+    """The shapes bench.py and config 4 actually run -- M = 1024, 20 PER-INSTANCE keep-outs, B = 128 (the shard of config 4:
+    one launch, SW = 1, MFMA workgroups first), 512 (two streams), 1024 (the headline: one launch, SW = 2, 2 column
+    partitions, non-temporal stores), 2064 (slices of 1024 + a 16-instance tail) -- through the DEFAULT dispatch (no option
+    set), device-pointer form as bench.py calls it, against the CPU oracle on sampled instances that sit on every tile
+    edge: 0, 15, 16, B/2, B-1, first / last of every slice.  Outputs are poisoned first: a tile or a role left out shows."""
+    import torch
+    import etol_amd as E
+    M = 1024
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, cases.W.TF)
+    ev.set_model(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS)
+    ev.set_batch(B)
+    X, U, recs = cases.W.quadrotor_batch(3, B, M, 20)
+    ev.set_path(recs, 0, 1)
+    dX, dU = torch.from_numpy(X).cuda(), torch.from_numpy(U).cuda()
+    outs = ev.alloc_outputs()
+    for t in outs:
+        t.fill_(float("nan"))
+    for _ in range(2):                       # twice: self-resetting tickets, same bits
+        ev.eval_dev(dX, dU, *outs)
+    ev.synchronize()
+    torch.cuda.synchronize()
+    assert _expected_default_form(B) in ev.last_defect_kernel, ev.last_defect_kernel
+    for t in outs:
+        assert not torch.isnan(t).any().item()          # every row of every instance was written
+    sample = [0, 15, 16, 17, B // 2 - 1, B // 2, B - 16, B - 1, 1023, 1024, 2047, 2048, 2063]
+    e = O.sampled_errors(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, cases.W.TF, X, U, recs, outs, sample)
+    print(f"B={B}: {ev.last_defect_kernel}: {e}")
+    assert e["defect"] < TOL_DEFECT and e["path"] < TOL_NODE and e["vals"] < TOL_NODE and e["cost"] < 1e-13, e
+    ev.close()
+
+
+@pytest.mark.parametrize("B", [256, 1024])
+def test_front_loaded_pass_orders_match_the_oracle(built, B):
+    """"pass_order" >= 100 (MFMA workgroups at 1.25 x / 4 x / far beyond the even density, node workgroups at the tail: the
+    block -> role map whose first version sent node workgroups out of range).  pass_role_of clamps the density itself; every
+    order must give the bits of the default order and the oracle's values."""
+    import torch
+    import etol_amd as E
+    M = 1024
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, cases.W.TF)
+    ev.set_model(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS)
+    ev.set_batch(B)
+    X, U, recs = cases.W.quadrotor_batch(3, B, M, 20)
+    ev.set_path(recs, 0, 1)
+    ev.set_option("overlap_mode", 3)
+    dX, dU = torch.from_numpy(X).cuda(), torch.from_numpy(U).cuda()
+    base = None
+    for order in (-1, 0, 1, 125, 400, 100000):
+        ev.set_option("pass_order", order)
+        outs = ev.alloc_outputs()
+        for t in outs:
+            t.fill_(float("nan"))
+        ev.eval_dev(dX, dU, *outs)
+        ev.synchronize()
+        torch.cuda.synchronize()
+        assert "one launch" in ev.last_defect_kernel
+        if base is None:
+            base = outs
+            e = O.sampled_errors(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, cases.W.TF, X, U, recs, outs,
+                                 [0, 15, 16, B // 2, B - 1])
+            assert e["defect"] < TOL_DEFECT and e["path"] < TOL_NODE and e["vals"] < TOL_NODE and e["cost"] < 1e-13, e
+        else:
+            for p, q in zip(outs, base):
+                assert torch.equal(p, q), order
+    ev.close()

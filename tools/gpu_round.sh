@@ -9,11 +9,11 @@ timeout -k 10 300 python bench.py --config c5 --steps 50 --warmup 5 > gpurun_out
 for b in 128 256 512; do timeout -k 10 200 python bench.py --batch $b --no-cpu-baseline > gpurun_out/bench_b$b.log 2>&1; tail -1 gpurun_out/bench_b$b.log | cut -c1-200; done
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof $R/gpurun_out/prof_c5
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-secondary > $R/gpurun_out/prof.log 2>&1
 echo "rocprof c3 rc=$?"; cat $R/gpurun_out/prof/*/*kernel_stats.csv
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c5 -- python $R/bench.py --config c5 --steps 30 --warmup 5 > $R/gpurun_out/prof_c5.log 2>&1
 echo "rocprof c5 rc=$?"; cat $R/gpurun_out/prof_c5/*/*kernel_stats.csv
-cd $R && bash tools/pmc_traffic.sh > gpurun_out/pmc_traffic.log 2>&1; tail -2 gpurun_out/pmc_traffic.log
+cd $R && bash tools/pmc_traffic.sh "1024 128" > gpurun_out/pmc_traffic.log 2>&1; tail -2 gpurun_out/pmc_traffic.log
 bash tools/pmc_busy.sh > gpurun_out/pmc_busy.log 2>&1; tail -3 gpurun_out/pmc_busy.log | cut -c1-200
 rm -f gpurun_out/pass_variants.jsonl gpurun_out/pass_variants_noprof.jsonl
 for b in 1024 512 256 128; do
