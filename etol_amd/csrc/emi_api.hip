@@ -83,9 +83,11 @@ struct emi_ctx_s {
     DevBuf d_ticket;            // [B] arrival counters of the in-kernel COST finish (zeroed once, self-resetting)
     bool cost_in_kernel = true; // "cost_in_kernel": the node kernel of the overlapped pass finishes COST itself (ticket), no emi_cost_finish_kernel
     int sym_nst = 3;            // "sym_nst": ring stages of the one-launch pass (3 or 4)
+    int slice = 0;              // "slice" option: > 0: batches above 2 * slice instances are evaluated in pieces of this many; 0: one launch (see emi_eval_dev)
     int slice_first = 0;        // first instance of the slice emi_eval_dev is working on (per-instance tables are offset by it)
     int sym_ksplit = 0;         // "sym_ksplit" option: K slices per tile of the state-split ring kernel (0: by batch size)
     int sym_cpart = 0;          // "sym_cpart" option: column partitions of the tile order (0: by mesh size, -1: plain order, 1/2/4/8)
+    int sym_gblk = 0, sym_cx = 0;   // "sym_gblk" / "sym_cx" options: grouped tile order, instance groups per super-block (0: off) and column tiles per block (0: 2)
     int pass_order = -1;        // "pass_order" option: one-launch pass, MFMA workgroups of an XCD first (1), interleaved with the node
                                 // workgroups (0), or by batch size (-1: first for small batches)
     int sym_combine = 1;        // "sym_combine" option: 1 slices combined in-kernel by ticket, 0 by emi_symdefect_combine_kernel
@@ -210,11 +212,12 @@ void fill_node_args(emi_ctx_t c, emi::NodeArgs<T>& a, const void* dX, const void
     a.ntracks = c->ntracks;
     a.px = c->px;
     a.py = c->py;
-    // Non-temporal result stores once a pass writes more than the Infinity Cache holds (256 MB): measured on the
-    // overlapped pass, B = 1024: 0.31 -> 0.27 ms (the ~1 GB stream no longer evicts the MFMA kernel's operands);
-    // B = 128 (127 MB, stays in the cache): plain stores are 5 % faster.  profiles/r02_pass_variants.json
+    // Non-temporal result stores once a pass writes about what the Infinity Cache holds (256 MB; RES + VALS above 230 MiB):
+    // measured on the one-launch pass, M = 1024 (profiles/r03_mid_sweep.json): 256 instances (244 MiB) 0.0581 ms against
+    // 0.0720 with plain stores, 320: 0.0749 / 0.0973, 384: 0.0879 / 0.1050; 224 instances (214 MiB): plain 0.0557 / nt 0.0606,
+    // 128: 0.0338 / 0.0354.  (Round 2 switched at 300 MB of VALS, i.e. above 384 instances: the 256 .. 384 band ran 20 % slow.)
     a.store_mode = c->node_store >= 0 ? c->node_store
-                                      : ((size_t)c->B * nvals_of(c) * c->M * (c->f32 ? 4 : 8) > ((size_t)300 << 20) ? 2 : 0);
+                                      : ((size_t)c->B * (nvals_of(c) + nres_of(c)) * c->M * (c->f32 ? 4 : 8) > ((size_t)230 << 20) ? 2 : 0);
     a.h = (T)((c->tf - c->t0) / 2.0);
     a.sgn = c->maximize ? T(-1) : T(1);
     for (int i = 0; i < EMI_MAX_PARAMS; ++i) a.P.p[i] = (T)c->params[i];
@@ -619,12 +622,24 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
                  unsigned flags) {
     int st = ready(c);
     if (st) return st;
-    // Very large batches go through the overlapped pass in slices of 1024 instances: the two kernels of a slice finish
-    // together, whereas one pair of launches over 16384 instances drifts apart (measured 3.4e9 node-evals/s against
-    // 4.1e9 at 1024, profiles/r02_batch_sweep.json).  Not while per-kernel profiling is on (one bracket per call).
-    const int SL = 1024;
-    if (c->B > 2 * SL && !c->profile && !c->f32 && (flags & EMI_EVAL_ALL) == EMI_EVAL_ALL && overlapped_path(c) && dX && dU && dRES && dCOST &&
+    // Large batches.  Round 2 cut everything above 2048 instances into 1024-instance launches (the two-stream form drifted apart
+    // on long launches); with the pass as ONE launch that buys nothing, and inputs of more than ~256 MB no longer stay in the
+    // Infinity Cache from one pass to the next, which is what really slows a large batch (B = 16384: 3.47e9 node-evals/s sliced or
+    // not, profiles/r03_notes.md).  Now: one launch over the whole batch, in the GROUPED tile order (plan_symdefect: an XCD's
+    // MFMA tiles and node workgroups walk the same instances together): 4.10e9 /s at 16384 instances, 4.13e9 at 4096.  Pieces
+    // remain only where something forces them: the "slice" option (> 0: pieces of that many instances once B > 2 slice), the
+    // 32-bit operand offsets of the MFMA role (X of a launch below 4 GB), and a remainder that is not a multiple of 256
+    // instances (the grouped order wants whole super-blocks on every XCD) as a second launch.  Not while per-kernel profiling is on.
+    int piece = 0;
+    if (!c->profile && !c->f32 && (flags & EMI_EVAL_ALL) == EMI_EVAL_ALL && overlapped_path(c) && dX && dU && dRES && dCOST &&
         (dVALS || (flags & EMI_EVAL_NOJAC))) {
+        const long long cap = ((0xFFFFFFFFLL / ((long long)c->ns * c->M * 8)) / 256) * 256;     // instances whose X stays below 4 GB
+        if (c->slice > 0) { if (c->B > 2 * c->slice) piece = c->slice; }
+        else if (c->B > 2048) piece = (int)std::min<long long>(cap > 0 ? cap : 256, c->B - c->B % 256);
+        if (piece >= c->B) piece = 0;
+    }
+    if (piece > 0) {
+        const int SL = piece;
         const int Btot = c->B;
         const size_t rb = 8, M = c->M;
         const size_t nres = nres_of(c), nvals = nvals_of(c);
@@ -686,25 +701,29 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
         const int tiles16 = ((c->B + 15) / 16) * (c->M / 128);
         const bool auto_mode = c->overlap_mode == 0;
-        if ((c->overlap_mode == 3 || (auto_mode && (tiles16 < 192 || tiles16 >= 384))) && jac) {
-            // The pass as ONE launch: MFMA-role and node-role workgroups in one grid, COST finished in-kernel.
-            // Chosen by itself for small batches, where the fork / join of the two-stream form costs as much as a kernel
-            // (B = 128: 0.044 ms against 0.055; B = 256: 0.074 against 0.077), and -- since the MFMA role is software-
-            // pipelined and needs 90 registers -- for large ones, where the two-stream form leaves the chip idle between
-            // passes and deals the two kernels' workgroups less evenly (one process, interleaved rounds, ms per pass:
-            // B = 896 0.218 against 0.251, B = 1024 0.246 against 0.277, B = 2048 0.470 against 0.514); in between
-            // (B = 512 .. 768) the two streams are level or ahead (0.119 against 0.128 at 512): profiles/r02_pass_variants.json.
-            emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, 1, c->sym_cpart);
+        if ((c->overlap_mode == 3 || auto_mode) && jac) {
+            // The pass as ONE launch: MFMA-role and node-role workgroups in one grid, COST finished in-kernel -- since round 3
+            // at EVERY batch size (round 2: two streams between 384 and 767 instances, which ran 20 - 25 % under the rest).
+            // One box, interleaved rounds, M = 1024, ms per pass, best one-launch form against the round-2 choice
+            // (profiles/r03_mid_sweep.json): 256: 0.0581 / 0.0731, 320: 0.0749 / 0.0927, 384: 0.0879 / 0.1177 (two streams),
+            // 448: 0.1035 / 0.1038, 512: 0.1188 / 0.1162, 576: 0.1332 / 0.1777, 640: 0.146 / 0.155, 704: 0.160 / 0.181.
+            //   * SW (states per MFMA workgroup): 1 below 128 sixteen-instance x 128-node tiles (more workgroups than CUs), else 2;
+            //   * block order (pass_role_of): MFMA workgroups first below 240 tiles (their 64-tile dependency chains start at
+            //     once, the streaming workgroups fill in behind), at 1.5 x the even density up to 384 tiles, evenly
+            //     interleaved from there (B >= 768, where "first" would hold the node role back: 0.288 against 0.222 at 1024);
+            //   * stores: fill_node_args (non-temporal from about 256 instances).
+            emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, 1, c->sym_cpart, c->sym_gblk, c->sym_cx);
+            const int gblk_auto = (c->sym_gblk == 0 && c->sym_cpart == 0 && c->B > 2048 && c->B % 256 == 0) ? 2 : c->sym_gblk;   // grouped order for large batches (emi_eval_dev)
             if (auto_mode && (c->sym_ct == 0 || c->sym_ct == 4))
-                plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 < 192 ? 7 : 6, 1, c->sym_cpart);        // SW = 1 (small batches: more workgroups than CUs) / 2
-            else if (plan.ring1) plan = emi::plan_symdefect(c->ns, c->B, c->M, 5, 1, c->sym_cpart);
+                plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 < 128 ? 7 : 6, 1, c->sym_cpart, gblk_auto, c->sym_cx);        // SW = 1 / 2
+            else if (plan.ring1) plan = emi::plan_symdefect(c->ns, c->B, c->M, 5, 1, c->sym_cpart, c->sym_gblk, c->sym_cx);
             plan.nst = c->sym_nst;
             if (c->sym_ksplit > 1) {
                 // "sym_ksplit": the K range of a tile cut into slices, their partial sums combined in-kernel by ticket.
                 // Not chosen by itself: at 128 instances SW = 2 x 2 slices 0.0437 ms against SW = 1 unsplit 0.0446 -- the
                 // fixed parts of the MFMA role (launch, prologue, epilogue: ~15 us) are what a small pass waits for
                 const int ct_now = plan.sw == c->ns ? 5 : (plan.sw == 2 ? 6 : (plan.sw == 3 ? 8 : 7));
-                plan = emi::plan_symdefect(c->ns, c->B, c->M, ct_now, c->sym_ksplit, c->sym_cpart);
+                plan = emi::plan_symdefect(c->ns, c->B, c->M, ct_now, c->sym_ksplit, c->sym_cpart, c->sym_gblk, c->sym_cx);
                 plan.nst = c->sym_nst;
             } else {
                 plan.ks = 1;
@@ -713,14 +732,12 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
                 // a run-time compiled model holds two instantiations of the pass kernel: SW = 1 with plain stores (small
                 // batches) and SW = 2 (1 for an odd number of states) with non-temporal stores (large ones)
                 const int swl = emi::rtc_pass_sw_large(c->rtc);
-                plan = emi::plan_symdefect(c->ns, c->B, c->M, (na.store_mode == 2 && swl == 2) ? 6 : 7, 1, c->sym_cpart);
+                plan = emi::plan_symdefect(c->ns, c->B, c->M, (na.store_mode == 2 && swl == 2) ? 6 : 7, 1, c->sym_cpart, gblk_auto, c->sym_cx);
                 plan.nst = 3;
             }
-            // Small batches: the MFMA workgroups of an XCD come first in its share of the grid, so that the 64-tile dependency
-            // chains start at once and the streaming workgroups fill in behind them (128 instances: 0.0340 ms against 0.0386
-            // interleaved; 64: 0.0249 / 0.0264; 224: 0.0583 / 0.0686).  From 256 instances the even interleave wins (0.0727 / 0.0748), at 1024 by far
-            // (0.226 / 0.292: the node role would start when the MFMA role is half done).
-            sa.mfma_first = c->pass_order >= 0 ? c->pass_order : (tiles16 < 128);
+            // (round 2 measured "first" against "interleaved" WITH PLAIN STORES at 256 instances and found interleaved ahead,
+            // 0.0727 / 0.0748; with non-temporal stores "first" wins up to 448 instances: 256: 0.0581 against 0.0756 interleaved)
+            sa.mfma_first = c->pass_order >= 0 ? c->pass_order : (tiles16 < 240 ? 1 : (tiles16 < 384 ? 150 : 0));
             if (c->rtc ? emi::rtc_pass_supported(c->rtc, c->B, c->M, plan.sw, plan.ks, na.store_mode)
                        : emi::pass_supported(c->model, c->ns, c->B, c->M, plan)) {
                 sa.cpart = plan.cpart; sa.cx = plan.cx;
@@ -767,7 +784,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             HIP_TRY(c, emi::rtc_launch_symdefect(c->rtc, sa, s1));
             c->last_defect_kernel = "emi_symdefect_ring_f64_kernel";
         } else {
-            const emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, c->sym_ksplit, c->sym_cpart);
+            const emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, c->sym_ksplit, c->sym_cpart, c->sym_gblk, c->sym_cx);
             if (plan.slab_bytes) {
                 int est = ensure(c, c->d_slab, plan.slab_bytes);
                 if (est) return est;
@@ -1121,6 +1138,11 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         return EMI_OK;
     }
     if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }
+    if (strcmp(name, "slice") == 0) {
+        if (value < 0 || (value > 0 && value % 16 != 0)) return fail(c, EMI_ERR_ARG, "slice must be 0 (never) or a multiple of 16 instances");
+        c->slice = value;
+        return EMI_OK;
+    }
     if (strcmp(name, "pass_order") == 0) { c->pass_order = value < 0 ? -1 : (value >= 100 ? value : (value != 0)); return EMI_OK; }
     if (strcmp(name, "sym_ablate") == 0) { c->sym_ablate = value; return EMI_OK; }   // diagnostics only
     if (strcmp(name, "cost_in_kernel") == 0) { c->cost_in_kernel = value != 0; return EMI_OK; }
@@ -1132,6 +1154,16 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
     if (strcmp(name, "sym_cpart") == 0) {
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, EMI_ERR_ARG, "sym_cpart must be -1 (plain order), 0 (by mesh size), 1, 2, 4 or 8");
         c->sym_cpart = value;
+        return EMI_OK;
+    }
+    if (strcmp(name, "sym_gblk") == 0) {
+        if (value < 0 || value > 64) return fail(c, EMI_ERR_ARG, "sym_gblk must be 0 (off) .. 64 instance groups per super-block");
+        c->sym_gblk = value;
+        return EMI_OK;
+    }
+    if (strcmp(name, "sym_cx") == 0) {
+        if (value < 0 || value > 64) return fail(c, EMI_ERR_ARG, "sym_cx must be 0 (default) .. 64 column tiles per block");
+        c->sym_cx = value;
         return EMI_OK;
     }
     if (strcmp(name, "sym_combine") == 0) { c->sym_combine = value != 0; return EMI_OK; }
@@ -1172,15 +1204,20 @@ int emi_debug_pass_roles(int nm, int nn, int order, int* out_role, int out_cap) 
 
 int emi_debug_tile_order(int ns, int B, int M, int sym_ct, int sym_cpart, int* out_tile, int out_cap, int* ntiles_total, int* cpart,
                          int* cx) {
+    return emi_debug_tile_order2(ns, B, M, sym_ct, sym_cpart, 0, 0, out_tile, out_cap, ntiles_total, cpart, cx);
+}
+
+int emi_debug_tile_order2(int ns, int B, int M, int sym_ct, int sym_cpart, int sym_gblk, int sym_cx, int* out_tile, int out_cap,
+                          int* ntiles_total, int* cpart, int* cx) {
     if (ns < 1 || B < 1 || M < 128 || M % 128 != 0 || !ntiles_total) return EMI_ERR_ARG;
-    const emi::SymPlan p = emi::plan_symdefect(ns, B, M, sym_ct, 1, sym_cpart);
+    const emi::SymPlan p = emi::plan_symdefect(ns, B, M, sym_ct, 1, sym_cpart, sym_gblk, sym_cx);
     if (p.ring1 || p.sw < 1) return EMI_ERR_UNSUPPORTED;
     const int ntiles = (M / 2) / 64, ngrp = ((B + 15) / 16) * (ns / p.sw), total = ntiles * ngrp;
     *ntiles_total = total;
     if (cpart) *cpart = p.cpart;
     if (cx) *cx = p.cx;
     for (int t = 0; t < total && t < out_cap && out_tile; ++t) {
-        const emi::RingTile rt = emi::ring_tile_of(t, ntiles, ngrp, p.cpart, p.cx);
+        const emi::RingTile rt = emi::ring_tile_of(t, ntiles, ngrp, p.cpart, p.cx, ns / p.sw);
         out_tile[t] = rt.ntile + ntiles * rt.grp;
     }
     return EMI_OK;

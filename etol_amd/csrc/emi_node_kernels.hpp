@@ -267,7 +267,7 @@ EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, con
             // HIP guide Guideline 16 R1: store, drain, then the ticket); the ticket word resets itself.
             __hip_atomic_store(part + bx, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned t = __hip_atomic_fetch_add(a.cost_ticket + b, 1u, EMI_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);   // release: this block's partial; acquire: the others'
+            const unsigned t = __hip_atomic_fetch_add(a.cost_ticket + b, 1u, EMI_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
             if (t == (unsigned)nbx - 1u) {
                 T tot = T(0);
                 for (int c = 0; c < nbx; ++c) tot += __hip_atomic_load(part + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

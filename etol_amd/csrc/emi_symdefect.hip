@@ -99,7 +99,7 @@ static hipError_t launch_ring2_model(const SymDefectArgs& a, hipStream_t s) {
 //   fewer (the shard of config 4: 128 instances = 64 tiles for 256 CUs): SW = 1 (<= 96 tiles) or 2, i.e. more workgroups
 //      than CUs (0.055 ms at 128 instances; SW = NS with 4 K slices, the choice before the K loop was software-pipelined: 0.089).
 // ct 5 / 6 / 7 / 8 force SW = NS / 2 / 1 / 3; ksplit_opt > 0 forces the slice count.
-SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_opt) {
+SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_opt, int gblk_opt, int cx_opt) {
     SymPlan p;
     const int tiles = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64);
     const int nkt = (M / 2) / 8;
@@ -127,7 +127,14 @@ SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_o
         else if (cpart_opt == 0 && tiles >= 192)    // (small batches: an XCD's few tiles do not walk the panels often enough to matter)
             for (int c = 1; c <= 8 && !cp; c *= 2)
                 if (valid(c) && (ntiles / c <= target_cols || c == 8 || !valid(2 * c))) cp = c;
-        if (cp > 0) {
+        const int mtiles = (B + FUSED_TI - 1) / FUSED_TI;
+        if (gblk_opt > 0 && mtiles % (8 * gblk_opt) == 0 && (ngrp * ntiles) % 8 == 0) {
+            // grouped order ("sym_gblk"): super-blocks of gblk instance groups per XCD, column blocks of cx tiles
+            int cxg = cx_opt > 0 ? cx_opt : 2;
+            while (cxg > 1 && ntiles % cxg != 0) --cxg;
+            p.cpart = -gblk_opt;
+            p.cx = cxg;
+        } else if (cp > 0) {
             p.cpart = cp;
             p.cx = 1;                                            // largest divisor of the partition's column count within the target
             for (int d = 1; d <= std::min(ntiles / cp, target_cols); ++d)
@@ -168,9 +175,9 @@ static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<doub
     a.nm8 = nm / 8;
     a.nn8 = nn / 8;
     const size_t lds = (size_t)NST * ((2 * SW * FUSED_TI + 2 * 64 + 63) / 64 * 64) * 8 * sizeof(double);
-    static bool attr_done[2] = {false, false};
-    const int st = na.store_mode == 2 ? 1 : 0;
-    auto kern = st ? emi_pass_f64_kernel<Model, SW, 2, 2, NST> : emi_pass_f64_kernel<Model, SW, 2, 0, NST>;
+    static bool attr_done[3] = {false, false, false};
+    const int st = na.store_mode == 2 ? 2 : (na.store_mode == 1 ? 1 : 0);   // result stores: plain / write-through (sc1) / non-temporal
+    auto kern = st == 2 ? emi_pass_f64_kernel<Model, SW, 2, 2, NST> : (st == 1 ? emi_pass_f64_kernel<Model, SW, 2, 1, NST> : emi_pass_f64_kernel<Model, SW, 2, 0, NST>);
     if (!attr_done[st]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

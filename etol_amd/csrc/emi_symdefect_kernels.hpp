@@ -445,7 +445,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     // 0.2408 ms against 0.2107 with all tiles reading the same 64 rows).  Partitioned order (a.cpart > 0): XCD x works on
     // column partition x % cpart only (its share of De / Do stays in L2) and on group partition x / cpart; X tiles are then
     // read by cpart XCDs instead of one, which costs little (they come from the Infinity Cache).
-    const RingTile rt = ring_tile_of(bid / KS, ntiles, (B + TI - 1) / TI * NSG, a.cpart, a.cx);
+    const RingTile rt = ring_tile_of(bid / KS, ntiles, (B + TI - 1) / TI * NSG, a.cpart, a.cx, NSG);
     const int ntile = rt.ntile, grp = rt.grp;
     const int tile = grp * ntiles + ntile;              // slab / ticket index
     const int sg = grp % NSG, mtile = grp / NSG;
@@ -663,7 +663,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                // every thread's partial sums are out (and the ring is no longer read)
         unsigned* flag = reinterpret_cast<unsigned*>(smem);
-        if (tid == 0) *flag = __hip_atomic_fetch_add(a.tile_ticket + tile, 1u, EMI_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);   // release: this slice's sums; acquire: the others'
+        if (tid == 0) *flag = __hip_atomic_fetch_add(a.tile_ticket + tile, 1u, EMI_TICKET_ORDER, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*flag != (unsigned)KS - 1u) return;
 #pragma unroll
@@ -737,6 +737,8 @@ __global__ __launch_bounds__(256) void emi_symdefect_combine_kernel(SymDefectArg
 // share X and De/Do panels in that XCD's L2).  Requires nm % 8 == 0 and nn % 8 == 0 (the launcher checks).
 // ---------------------------------------------------------------------------------------------
 
+#define EMI_STR2(x) #x
+#define EMI_STR(x) EMI_STR2(x)
 #ifndef EMI_PASS_WAVES_PER_EU
 #define EMI_PASS_WAVES_PER_EU 0         // build-time experiment switch (tools/ab_build.sh): register cap of the pass kernel as waves per SIMD
 #endif
@@ -747,6 +749,9 @@ __global__ __launch_bounds__(256) void emi_symdefect_combine_kernel(SymDefectArg
 #endif
 template <class Model, int SW, int VEC, int ST, int NST = 3>
 __global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs a) {
+#ifdef EMI_ENTRY_PAD_NOPS      // build-time experiment (tools/ab_build.sh): shift the whole instruction stream by 4-byte steps
+    asm volatile(".rept " EMI_STR(EMI_ENTRY_PAD_NOPS) "\n\ts_nop 0\n\t.endr" ::: "memory");
+#endif
     const int g = blockIdx.x, xcd = g & 7, j = g >> 3;
     const PassRole role = pass_role_of(j, a.nm8, a.nn8, a.s.mfma_first);
     if (a.s.ablate & (role.mfma ? 16 : 32)) return;    // diagnostics: one of the two roles does nothing

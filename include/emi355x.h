@@ -293,6 +293,10 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * size; -1 = plain (the column tiles of an X tile are neighbours, X tiles dealt over
  * the XCDs); 1 / 2 / 4 / 8 = the column tiles cut into that many partitions, each
  * worked on by 8 / cpart XCDs, so that an XCD's share of De / Do stays in its L2.
+ * "sym_gblk" / "sym_cx": the GROUPED tile order (csrc/emi_args.hpp ring_tile_of): an XCD keeps a contiguous range of instance
+ * groups -- the range whose node-role workgroups it also runs -- and walks it in super-blocks of sym_gblk 16-instance groups,
+ * the column tiles in blocks of sym_cx (0: 2); X and U of a super-block then reach that XCD's L2 once for every consumer.
+ * sym_gblk 0: off (unless the policy chooses it: inputs that do not stay in the Infinity Cache between passes).
  * "sym_nst": ring stages of the one-launch pass (3 default, 4).  "pass_order": the MFMA workgroups of an
  * XCD first in its share of the one-launch grid (1), interleaved with the node workgroups (0), interleaved
  * at value / 100 times the even MFMA density with the node workgroups at the tail (>= 100), or -1 (default)
@@ -301,6 +305,8 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * the Schur path starts at the dual regularisation level that worked last on this
  * mesh; "kkt_debug", "kkt_cholesky", "kkt_chol_panel", "kkt_batched_max_nodes",
  * "kkt_potrf_lock": diagnostics, see csrc/emi_kkt.hip).
+ * "slice": batches above 2 * slice instances are evaluated in pieces of `slice` instances (default 1024; 0 = never,
+ * one launch over the whole batch).
  * "sym_ablate": diagnostics only, results invalid.                             */
 int emi_set_option(emi_ctx_t ctx, const char* name, int value);
 /* 1 if emi_eval(EMI_EVAL_ALL) currently takes the overlapped path             */
@@ -311,6 +317,9 @@ int emi_last_path(emi_ctx_t ctx, int* fused);
  * Every value 0 .. ntiles_total-1 must occur exactly once (tests/test_abi.py).                                               */
 int emi_debug_tile_order(int ns, int B, int M, int sym_ct, int sym_cpart, int* out_tile, int out_cap, int* ntiles_total,
                          int* cpart, int* cx);
+/* ... the same with the grouped order's options "sym_gblk" / "sym_cx" (*cpart comes back negative, -gblk, when the plan takes it) */
+int emi_debug_tile_order2(int ns, int B, int M, int sym_ct, int sym_cpart, int sym_gblk, int sym_cx, int* out_tile, int out_cap,
+                          int* ntiles_total, int* cpart, int* cx);
 /* Diagnostics, no device needed: how the one-launch pass deals an XCD's nm MFMA-role and nn node-role blocks ("pass_order":
  * 0 evenly interleaved, 1 MFMA blocks first, >= 100 interleaved at order / 100 times the even MFMA density).  out_role[j] =
  * MFMA block index (>= 0) or -1 - node block index; every index of either role must occur exactly once.                      */

@@ -157,6 +157,31 @@ def test_every_tile_order_of_the_mfma_defect_kernel_is_a_permutation():
                             partitioned += 1
                         checked += 1
     assert checked > 5000 and partitioned > 500, (checked, partitioned)
+    # the grouped order ("sym_gblk" instance groups per super-block, "sym_cx" column tiles per block)
+    grouped = 0
+    for M in (128, 256, 512, 768, 1024, 1280, 2048):
+        for B in (128, 256, 384, 512, 640, 1024, 1536, 2048, 4096):
+            for ns in (2, 6, 12):
+                for ct in (5, 6, 7, 8):
+                    for gblk in (1, 2, 3, 4, 8):
+                        for cxo in (0, 1, 2, 3, 4, 8):
+                            tot, cp, cx = C.c_int(), C.c_int(), C.c_int()
+                            cap = ((M // 128) * ((B + 15) // 16) * ns)
+                            out = (C.c_int * cap)()
+                            st = lib.emi_debug_tile_order2(ns, B, M, ct, 0, gblk, cxo, out, cap, C.byref(tot), C.byref(cp), C.byref(cx))
+                            if st != 0:
+                                continue
+                            assert sorted(out[:tot.value]) == list(range(tot.value)), (M, B, ns, ct, gblk, cxo, cp.value, cx.value)
+                            if cp.value < 0:
+                                assert cp.value == -gblk and (M // 128) % cx.value == 0
+                                # an XCD's tiles stay inside its own contiguous range of instance groups
+                                nt, per = M // 128, tot.value // 8
+                                nsg = tot.value // nt // ((B + 15) // 16)
+                                for x in range(8):
+                                    mts = {out[t] // nt // nsg for t in range(x * per, (x + 1) * per)}
+                                    assert mts == set(range(x * len(mts), (x + 1) * len(mts))), (M, B, ns, ct, gblk, x)
+                                grouped += 1
+    assert grouped > 500, grouped
 
 
 def test_every_role_map_of_the_one_launch_pass_is_a_bijection():

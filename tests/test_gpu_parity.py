@@ -584,7 +584,7 @@ def test_every_mfma_defect_kernel_variant_matches_the_oracle(built, sym_ct, shap
     ev.close()
 
 
-@pytest.mark.parametrize("shape", [(1024, 40), (2048, 24), (512, 72), (256, 128), (1280, 32), (768, 48)])
+@pytest.mark.parametrize("shape", [(1024, 40), (2048, 24), (512, 72), (256, 128), (1280, 32), (768, 48), (1024, 256), (512, 384)])
 def test_partitioned_tile_orders_of_the_mfma_role(built, shape):
     """"sym_cpart": the column tiles of the state-split ring cut into 1 / 2 / 4 / 8 partitions over the XCDs (the default
     for large batches), against the plain order and the oracle -- for meshes with 2 .. 16 column tiles (10 and 6 among them: partitions of 5 and 3 columns), batch sizes whose
@@ -605,16 +605,20 @@ def test_partitioned_tile_orders_of_the_mfma_role(built, shape):
         base = None
         for mode in (2, 3):
             ev.set_option("overlap_mode", mode)
-            for cpart in (-1, 1, 2, 4, 8, 0):
+            for cpart, gblk, cxo in ((-1, 0, 0), (1, 0, 0), (2, 0, 0), (4, 0, 0), (8, 0, 0), (0, 0, 0), (0, 1, 1), (0, 1, 2), (0, 2, 2), (0, 2, 4), (0, 4, 1)):
                 ev.set_option("sym_cpart", cpart)
+                ev.set_option("sym_gblk", gblk)                # grouped order: super-blocks of gblk instance groups, column blocks of cxo
+                ev.set_option("sym_cx", cxo)
                 poison = ev.eval_host(X + 1.0, U)              # another input first: a tile left out would keep these rows
                 got = ev.eval_host(X, U)
                 assert ev.uses_fused_kernel
                 check(c, ev, got, ref)
                 if base is None:
                     base = got
-                assert np.array_equal(got[0], base[0]), (sym_ct, mode, cpart)      # the order of the tiles changes no bit
+                assert np.array_equal(got[0], base[0]), (sym_ct, mode, cpart, gblk, cxo)      # the order of the tiles changes no bit
                 assert not np.array_equal(poison[0], got[0])
+            ev.set_option("sym_gblk", 0)
+            ev.set_option("sym_cx", 0)
     ev.close()
 
 
@@ -632,8 +636,9 @@ def test_default_dispatch_on_random_shapes_matches_the_general_path(built):
 
 
 def test_very_large_batches_are_evaluated_in_slices_with_the_same_results(built):
-    """emi_eval_dev cuts batches above 2048 instances into slices of 1024 (per-instance keep-out tables, cost partials
-    and outputs offset per slice); with per-kernel profiling on it evaluates the batch in one piece: same results."""
+    """emi_eval_dev evaluates a batch above 2048 instances as one launch over its multiple of 256 instances plus a second
+    launch for the remainder (per-instance keep-out tables, cost partials and outputs offset per piece), or in pieces of
+    "slice" instances when that option is set; with per-kernel profiling on it evaluates the batch in one piece: same results."""
     import torch
     import etol_amd as E
     M, B = 128, 2100
@@ -648,7 +653,14 @@ def test_very_large_batches_are_evaluated_in_slices_with_the_same_results(built)
     ev.set_path(recs, 0, 1)
     dX, dU = torch.from_numpy(X).cuda(), torch.from_numpy(U).cuda()
     a, b = ev.alloc_outputs(), ev.alloc_outputs()
-    ev.eval_dev(dX, dU, *a)                                   # sliced
+    ev.eval_dev(dX, dU, *a)                                   # 2048 + 52 instances
+    c3 = ev.alloc_outputs()
+    ev.set_option("slice", 512)
+    ev.eval_dev(dX, dU, *c3)                                  # 512 + 512 + 512 + 512 + 52
+    ev.set_option("slice", 0)
+    torch.cuda.synchronize()
+    for p, q in zip(a, c3):
+        assert (p - q).abs().max().item() <= 1e-12 * q.abs().max().item()
     ev.profile(1)
     ev.eval_dev(dX, dU, *b)                                   # one piece
     ev.profile_read()
@@ -689,22 +701,20 @@ def test_mfma_defect_kernel_variants_for_the_two_state_model(built, sym_ct):
 
 
 def _expected_default_form(B, M=1024):
-    """What emi_eval_dev's policy picks for the 6-state model by itself (csrc/emi_api.hip: one launch below 192 and from
-    384 sixteen-instance x 128-node tiles, two streams in between; batches above 2048 instances in slices of 1024)."""
-    last = B if B <= 2048 else (B % 1024 or 1024)
+    """What emi_eval_dev's policy picks for the 6-state model by itself (csrc/emi_api.hip): the pass as one launch at every
+    size, SW = 1 below 128 sixteen-instance x 128-node tiles and 2 from there; batches above 2048 instances as one launch over
+    the multiple of 256 instances (grouped tile order) plus a second launch for the remainder."""
+    last = B if (B <= 2048 or B % 256 == 0) else B % 256
     tiles16 = ((last + 15) // 16) * (M // 128)
-    if tiles16 < 192:
-        return "emi_pass_f64_kernel<SW=1>"
-    if tiles16 >= 384:
-        return "emi_pass_f64_kernel<SW=2>"
-    return "emi_symdefect_ring"
+    return "emi_pass_f64_kernel<SW=1>" if tiles16 < 128 else "emi_pass_f64_kernel<SW=2>"
 
 
-@pytest.mark.parametrize("B", [128, 512, 1024, 2064])
+@pytest.mark.parametrize("B", [128, 256, 512, 1024, 2064, 2560])
 def test_default_dispatch_at_the_benchmarked_shapes_matches_the_oracle(built, B):
     """The shapes bench.py and config 4 actually run -- M = 1024, 20 PER-INSTANCE keep-outs, B = 128 (the shard of config 4:
-    one launch, SW = 1, MFMA workgroups first), 512 (two streams), 1024 (the headline: one launch, SW = 2, 2 column
-    partitions, non-temporal stores), 2064 (slices of 1024 + a 16-instance tail) -- through the DEFAULT dispatch (no option
+    one launch, SW = 1, MFMA workgroups first, plain stores), 256 (SW = 2, MFMA workgroups first, non-temporal stores), 512 (SW = 2, MFMA
+    workgroups at 1.5 x the even density), 1024 (the headline: SW = 2, evenly interleaved, 2 column partitions), 2064 (one launch of
+    2048 instances + a 16-instance tail), 2560 (one launch in the grouped tile order) -- through the DEFAULT dispatch (no option
     set), device-pointer form as bench.py calls it, against the CPU oracle on sampled instances that sit on every tile
     edge: 0, 15, 16, B/2, B-1, first / last of every slice.  Outputs are poisoned first: a tile or a role left out shows."""
     import torch
@@ -720,6 +730,7 @@ def test_default_dispatch_at_the_benchmarked_shapes_matches_the_oracle(built, B)
     outs = ev.alloc_outputs()
     for t in outs:
         t.fill_(float("nan"))
+    torch.cuda.synchronize()                 # (the fills run on torch's stream, the evaluator launches on its own)
     for _ in range(2):                       # twice: self-resetting tickets, same bits
         ev.eval_dev(dX, dU, *outs)
     ev.synchronize()
@@ -727,7 +738,7 @@ def test_default_dispatch_at_the_benchmarked_shapes_matches_the_oracle(built, B)
     assert _expected_default_form(B) in ev.last_defect_kernel, ev.last_defect_kernel
     for t in outs:
         assert not torch.isnan(t).any().item()          # every row of every instance was written
-    sample = [0, 15, 16, 17, B // 2 - 1, B // 2, B - 16, B - 1, 1023, 1024, 2047, 2048, 2063]
+    sample = [0, 15, 16, 17, B // 2 - 1, B // 2, B - 16, B - 1, 1023, 1024, 2047, 2048, 2063, 2303, 2304]
     e = O.sampled_errors(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, cases.W.TF, X, U, recs, outs, sample)
     print(f"B={B}: {ev.last_defect_kernel}: {e}")
     assert e["defect"] < TOL_DEFECT and e["path"] < TOL_NODE and e["vals"] < TOL_NODE and e["cost"] < 1e-13, e
@@ -756,10 +767,13 @@ def test_front_loaded_pass_orders_match_the_oracle(built, B):
         outs = ev.alloc_outputs()
         for t in outs:
             t.fill_(float("nan"))
+        torch.cuda.synchronize()             # (the fills run on torch's stream, the evaluator launches on its own)
         ev.eval_dev(dX, dU, *outs)
         ev.synchronize()
         torch.cuda.synchronize()
         assert "one launch" in ev.last_defect_kernel
+        for t in outs:
+            assert not torch.isnan(t).any().item(), order
         if base is None:
             base = outs
             e = O.sampled_errors(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, cases.W.TF, X, U, recs, outs,
