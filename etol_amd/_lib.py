@@ -84,6 +84,9 @@ SYMBOLS = {
     "emi_last_defect_kernel": (C.c_char_p, [_P]),
     "emi_debug_pass_roles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "emi_debug_tile_order": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "emi_set_delays": (C.c_int, [_P, C.c_int, C.c_int, C.c_double]),
+    "emi_get_delays": (C.c_int, [_P, _I, _I, _I]),
+    "emi_delay_matrix": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, C.POINTER(C.c_double)]),
     "emi_debug_tile_order2": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "emi_comm_unique_id": (C.c_int, [_P]),
     "emi_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, _P, C.POINTER(_P)]),

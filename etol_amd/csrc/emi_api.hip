@@ -83,6 +83,13 @@ struct emi_ctx_s {
     DevBuf d_ticket;            // [B] arrival counters of the in-kernel COST finish (zeroed once, self-resetting)
     bool cost_in_kernel = true; // "cost_in_kernel": the node kernel of the overlapped pass finishes COST itself (ticket), no emi_cost_finish_kernel
     int sym_nst = 3;            // "sym_nst": ring stages of the one-launch pass (3 or 4)
+    // delayed values (emi_set_delays): x_horizon - 1 delayed copies of every state and u_horizon of every control, appended to the
+    // controls the node functions see: nc = nc_free + nch; W[d] = interpolation matrix of delay (d + 1) dt on this mesh
+    int xh = 0, uh = 0, nch = 0;
+    double delay_dt = 0.0;
+    bool delay_dirty = true;    // W must be rebuilt (mesh or delays changed)
+    DevBuf d_W;                 // [max(xh - 1, uh)][M][M]
+    DevBuf d_uext;              // [B][nc][M]: the caller's controls, then the delayed values
     int slice = 0;              // "slice" option: > 0: batches above 2 * slice instances are evaluated in pieces of this many; 0: one launch (see emi_eval_dev)
     int slice_first = 0;        // first instance of the slice emi_eval_dev is working on (per-instance tables are offset by it)
     int sym_ksplit = 0;         // "sym_ksplit" option: K slices per tile of the state-split ring kernel (0: by batch size)
@@ -223,6 +230,78 @@ void fill_node_args(emi_ctx_t c, emi::NodeArgs<T>& a, const void* dX, const void
     for (int i = 0; i < EMI_MAX_PARAMS; ++i) a.P.p[i] = (T)c->params[i];
 }
 
+// Delayed values.  Row k of W(delay) holds the Lagrange basis of the LGL nodes at the node coordinate of max(t_k - delay, t0):
+// what PSOPT's get_delayed_state / get_delayed_control hand ePSOPT::dae (reference src/ePSOPT/ePSOPT.cpp:231-248) -- the value
+// at t - delay of the polynomial that interpolates the variable's node values ("Legendre" collocation: Lagrange interpolation).
+// PSOPT 5.0.0 is not in the reference tree; times before t0 are CLAMPED to t0 here (the history of a delayed variable is its
+// initial value), which is an assumption of this build, stated in include/emi355x.h and DESIGN.md section 5.
+// Barycentric form with the LGL weights lambda_j ~ (-1)^j sqrt(w_j) (w_j = 2 / (N (N+1) P_N(tau_j)^2)).
+void delay_matrix(const std::vector<double>& tau, const std::vector<double>& w, double t0, double tf, double delay, double* W) {
+    const int M = (int)tau.size();
+    std::vector<double> lam(M);
+    for (int j = 0; j < M; ++j) lam[j] = ((j & 1) ? -1.0 : 1.0) * std::sqrt(w[j]);
+    const double hh = (tf - t0) / 2.0;
+    for (int k = 0; k < M; ++k) {
+        double ts = t0 + hh * (tau[k] + 1.0) - delay;
+        if (ts < t0) ts = t0;
+        const double x = (ts - t0) / hh - 1.0;
+        double* row = W + (size_t)k * M;
+        int hit = -1;
+        for (int j = 0; j < M; ++j)
+            if (x == tau[j]) hit = j;
+        if (ts <= t0) hit = 0;
+        if (hit >= 0) {
+            for (int j = 0; j < M; ++j) row[j] = j == hit ? 1.0 : 0.0;
+            continue;
+        }
+        double den = 0.0;
+        for (int j = 0; j < M; ++j) {
+            row[j] = lam[j] / (x - tau[j]);
+            den += row[j];
+        }
+        for (int j = 0; j < M; ++j) row[j] /= den;
+    }
+}
+
+// dU_free [B][nc - nch][M] -> *dU_ext [B][nc][M] = [U | x(t - dt) .. x(t - (xh-1) dt) | u(t - dt) .. u(t - uh dt)], the delayed
+// rows as products with W on the general MFMA defect kernel (rows += Z . W^T onto zeroed rows)
+int extend_controls(emi_ctx_t c, const void* dX, const void* dU_free, const void** dU_ext) {
+    if (c->f32) return fail(c, EMI_ERR_UNSUPPORTED, "delayed values: f64 contexts only");
+    if (c->points_only) return fail(c, EMI_ERR_STATE, "delayed values need a collocation mesh (this context holds a points-only mesh)");
+    const int M = c->M, ncf = c->nc - c->nch, nd = std::max(c->xh - 1, c->uh);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->attr_set) {
+        HIP_TRY(c, emi::defect_f64_set_attr());
+        c->attr_set = true;
+    }
+    int st;
+    if (c->delay_dirty) {
+        std::vector<double> W((size_t)nd * M * M);
+        for (int d = 0; d < nd; ++d) delay_matrix(c->h_tau, c->h_w, c->t0, c->tf, (d + 1) * c->delay_dt, W.data() + (size_t)d * M * M);
+        if ((st = upload_real(c, c->d_W, W.data(), W.size()))) return st;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));        // W is a local: the copy must be done before it goes
+        c->delay_dirty = false;
+    }
+    const size_t row = (size_t)M * 8;
+    if ((st = ensure(c, c->d_uext, (size_t)c->B * c->nc * row))) return st;
+    HIP_TRY(c, hipMemsetAsync(c->d_uext.p, 0, (size_t)c->B * c->nc * row, c->stream));
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_uext.p, (size_t)c->nc * row, dU_free, (size_t)ncf * row, (size_t)ncf * row, c->B, hipMemcpyDeviceToDevice, c->stream));
+    double* base = (double*)c->d_uext.p + (size_t)ncf * M;
+    for (int i = 1; i < c->xh; ++i) {       // x(t - i dt): all states against W[i-1]
+        emi::DefectArgs a{(const double*)dX, (const double*)c->d_W.p + (size_t)(i - 1) * M * M, base + (size_t)(i - 1) * c->ns * M,
+                          c->B * c->ns, M, c->ns, c->nc};
+        HIP_TRY(c, emi::launch_defect_f64(a, c->stream));
+    }
+    base += (size_t)std::max(c->xh - 1, 0) * c->ns * M;
+    for (int i = 1; i <= c->uh; ++i) {      // u(t - i dt): the caller's controls against W[i-1]
+        emi::DefectArgs a{(const double*)dU_free, (const double*)c->d_W.p + (size_t)(i - 1) * M * M, base + (size_t)(i - 1) * ncf * M,
+                          c->B * ncf, M, ncf, c->nc};
+        HIP_TRY(c, emi::launch_defect_f64(a, c->stream));
+    }
+    *dU_ext = c->d_uext.p;
+    return EMI_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -346,7 +425,9 @@ int emi_set_mesh(emi_ctx_t c, int M, const double* tau, const double* w, const d
         if ((st = upload_real(c, c->d_Ddiag, zero.data(), M))) return st;
         c->symmetric = false;
         c->points_only = true;
-        c->h_tau.assign(tau, tau + M);
+        c->delay_dirty = true;
+    c->h_tau.assign(tau, tau + M);
+        c->delay_dirty = true;
         c->h_w.assign(w, w + M);
         c->M = M; c->t0 = t0; c->tf = tf;
         c->ntracks = 0; c->track_sets = 0;
@@ -440,6 +521,7 @@ int emi_set_model(emi_ctx_t c, int model, const double* params, int nparams, int
     c->model = model;
     c->ns = ns;
     c->nc = nc;
+    c->xh = c->uh = c->nch = 0;
     c->np_model = 0;
     c->pvars.clear();
     c->maximize = maximize ? 1 : 0;
@@ -476,6 +558,7 @@ int emi_set_model_source(emi_ctx_t c, const char* struct_name, const char* sourc
     c->model = EMI_MODEL_SOURCE;
     c->ns = ns;
     c->nc = nc;
+    c->xh = c->uh = c->nch = 0;     // delayed values belong to the model they were declared for: emi_set_delays again
     c->np_model = npath;
     c->pvars.assign(path_vars, path_vars + (npath > 0 ? n_path_vars : 0));
     c->maximize = maximize ? 1 : 0;
@@ -506,6 +589,40 @@ int emi_set_batch(emi_ctx_t c, int B) {
     int st = ensure(c, c->d_cost_part, (size_t)B * emi::node_chunks(c->M) * rb);
     if (st) return st;
     c->B = B;
+    return EMI_OK;
+}
+
+int emi_set_delays(emi_ctx_t c, int x_horizon, int u_horizon, double dt) {
+    if (!c || x_horizon < 0 || u_horizon < 0) return fail(c, EMI_ERR_ARG, "emi_set_delays: horizons must be >= 0");
+    if (c->model < 0) return fail(c, EMI_ERR_STATE, "emi_set_model / emi_set_model_source must precede emi_set_delays");
+    const int nxd = std::max(x_horizon - 1, 0) * c->ns;
+    // nc_free + nxd + uh * nc_free = nc  (the model's control count includes the delayed values)
+    const int rest = c->nc - nxd;
+    if (nxd + u_horizon == 0) { c->xh = x_horizon; c->uh = 0; c->nch = 0; return EMI_OK; }
+    if (!(dt > 0)) return fail(c, EMI_ERR_ARG, "emi_set_delays: dt must be positive");
+    if (rest < 1 || rest % (1 + u_horizon) != 0)
+        return fail(c, EMI_ERR_ARG, "emi_set_delays: the model has %d controls, which is not nc + %d delayed states + %d x nc delayed controls for any nc >= 1",
+                    c->nc, nxd, u_horizon);
+    if (c->f32) return fail(c, EMI_ERR_UNSUPPORTED, "emi_set_delays: f64 contexts only");
+    c->xh = x_horizon;
+    c->uh = u_horizon;
+    c->nch = c->nc - rest / (1 + u_horizon);
+    c->delay_dt = dt;
+    c->delay_dirty = true;
+    return EMI_OK;
+}
+
+int emi_get_delays(emi_ctx_t c, int* x_horizon, int* u_horizon, int* n_delayed) {
+    if (!c) return EMI_ERR_ARG;
+    if (x_horizon) *x_horizon = c->xh;
+    if (u_horizon) *u_horizon = c->uh;
+    if (n_delayed) *n_delayed = c->nch;
+    return EMI_OK;
+}
+
+int emi_delay_matrix(int M, const double* tau, const double* w, double t0, double tf, double delay, double* W) {
+    if (M < 2 || !tau || !w || !W || !(tf > t0) || delay < 0) return EMI_ERR_ARG;
+    delay_matrix(std::vector<double>(tau, tau + M), std::vector<double>(w, w + M), t0, tf, delay, W);
     return EMI_OK;
 }
 
@@ -622,6 +739,7 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
                  unsigned flags) {
     int st = ready(c);
     if (st) return st;
+    if (c->nch > 0 && dX && dU && (st = extend_controls(c, dX, dU, &dU))) return st;     // delayed values appended to the controls
     // Large batches.  Round 2 cut everything above 2048 instances into 1024-instance launches (the two-stream form drifted apart
     // on long launches); with the pass as ONE launch that buys nothing, and inputs of more than ~256 MB no longer stay in the
     // Infinity Cache from one pass to the next, which is what really slows a large batch (B = 16384: 3.47e9 node-evals/s sliced or
@@ -914,7 +1032,7 @@ int emi_eval_host(emi_ctx_t c, const double* X, const double* U, double* RES, do
     if (st) return st;
     if (!X || !U) return fail(c, EMI_ERR_ARG, "emi_eval_host: null input");
     const size_t rb = c->f32 ? 4 : 8;
-    const size_t nX = (size_t)c->B * c->ns * c->M, nU = (size_t)c->B * c->nc * c->M;
+    const size_t nX = (size_t)c->B * c->ns * c->M, nU = (size_t)c->B * (c->nc - c->nch) * c->M;
     const size_t nR = (size_t)c->B * nres_of(c) * c->M, nV = (size_t)c->B * nvals_of(c) * c->M;
     if ((st = upload_real(c, c->s_X, X, nX))) return st;
     if ((st = upload_real(c, c->s_U, U, nU))) return st;
@@ -943,6 +1061,7 @@ int emi_hess_dev(emi_ctx_t c, const void* dX, const void* dU, const void* dLamF,
     if (!dX || !dU || !dLamF || !dH || (np_total(c) > 0 && !dLamC))
         return fail(c, EMI_ERR_ARG, "emi_hess: null device pointer");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->nch > 0 && (st = extend_controls(c, dX, dU, &dU))) return st;
     auto fill = [&](auto& a) {
         using T = typename std::remove_reference<decltype(a.h)>::type;
         a.X = (const T*)dX; a.U = (const T*)dU; a.lamF = (const T*)dLamF; a.lamC = (const T*)dLamC;
@@ -972,7 +1091,7 @@ int emi_hess_host(emi_ctx_t c, const double* X, const double* U, const double* L
     if (st) return st;
     if (!X || !U || !LamF || !H || (np_total(c) > 0 && !LamC)) return fail(c, EMI_ERR_ARG, "emi_hess_host: null pointer");
     const size_t rb = c->f32 ? 4 : 8;
-    const size_t nX = (size_t)c->B * c->ns * c->M, nU = (size_t)c->B * c->nc * c->M;
+    const size_t nX = (size_t)c->B * c->ns * c->M, nU = (size_t)c->B * (c->nc - c->nch) * c->M;
     const size_t nC = (size_t)c->B * np_total(c) * c->M, nH = (size_t)c->B * nhess_of(c) * c->M;
     if ((st = upload_real(c, c->s_X, X, nX))) return st;
     if ((st = upload_real(c, c->s_U, U, nU))) return st;

@@ -101,6 +101,17 @@ class Evaluator:
     def set_batch(self, B):
         self._ck(self.lib.emi_set_batch(self.ctx, B), "emi_set_batch")
 
+    def set_delays(self, x_horizon, u_horizon, dt):
+        """Delayed states / controls as extra inputs of the node functions (include/emi355x.h, emi_set_delays): the model is
+        written on nc + (x_horizon - 1) ns + u_horizon nc controls, evaluations keep taking U[B][nc][M]."""
+        self._ck(self.lib.emi_set_delays(self.ctx, int(x_horizon), int(u_horizon), float(dt)), "emi_set_delays")
+
+    @property
+    def n_delayed(self):
+        n = C.c_int()
+        self._ck(self.lib.emi_get_delays(self.ctx, None, None, C.byref(n)), "emi_get_delays")
+        return n.value
+
     def set_path(self, recs, px=0, py=1):
         recs = np.ascontiguousarray(recs, dtype=np.float64)
         if recs.ndim == 2:
@@ -144,7 +155,7 @@ class Evaluator:
     def eval_dev(self, X, U, RES, VALS, COST, flags=L.EVAL_ALL):
         """X,U,RES,VALS,COST: contiguous torch tensors on this evaluator's device."""
         lay = self.layout
-        for t, shape in ((X, (lay.B, lay.ns, lay.M)), (U, (lay.B, lay.nc, lay.M)),
+        for t, shape in ((X, (lay.B, lay.ns, lay.M)), (U, (lay.B, lay.nc - self.n_delayed, lay.M)),
                          (RES, (lay.B, lay.nres, lay.M)), (VALS, (lay.B, lay.nvals, lay.M)), (COST, (lay.B,))):
             if t is None:
                 continue
@@ -165,7 +176,7 @@ class Evaluator:
         lay = self.layout
         X = np.ascontiguousarray(X, dtype=np.float64)
         U = np.ascontiguousarray(U, dtype=np.float64)
-        assert X.shape == (lay.B, lay.ns, lay.M) and U.shape == (lay.B, lay.nc, lay.M)
+        assert X.shape == (lay.B, lay.ns, lay.M) and U.shape == (lay.B, lay.nc - self.n_delayed, lay.M)
         RES = np.zeros((lay.B, lay.nres, lay.M)) if res_in is None else np.ascontiguousarray(res_in, dtype=np.float64).copy()
         VALS = np.zeros((lay.B, lay.nvals, lay.M))
         COST = np.zeros(lay.B)

@@ -145,6 +145,15 @@ void eMI355X::traceCallbacks() {
     vector_t x, u;
     for (size_t i = 0; i < getNStates(); ++i) x.push_back(mi355x::Symbol{mi355x::Symbol::STATE, i});
     for (size_t j = 0; j < getNControls(); ++j) u.push_back(mi355x::Symbol{mi355x::Symbol::CONTROL, j});
+    // Delayed values, appended in ePSOPT::dae's order (ePSOPT.cpp:231-248): x(t - i dt) of every state for i = 1 ..
+    // Xrhorizon - 1 behind the states, u(t - i dt) of every control for i = 1 .. Urhorizon behind the controls.  For the
+    // device they are extra inputs of the node functions: handles on control slots nc .. nc + ndelayed - 1, states' delayed
+    // copies first (the layout emi_set_delays documents).
+    const size_t nsx = getNStates(), ncx = getNControls();
+    const size_t nxd = getXrhorizon() > 1 ? (getXrhorizon() - 1) * nsx : 0, nud = getUrhorizon() * ncx;
+    for (size_t q = 0; q < nxd; ++q) x.push_back(mi355x::Symbol{mi355x::Symbol::CONTROL, ncx + q});
+    for (size_t q = 0; q < nud; ++q) u.push_back(mi355x::Symbol{mi355x::Symbol::CONTROL, ncx + nxd + q});
+    const int nc_model = (int)(ncx + nxd + nud);        // controls of the device model: free controls + delayed values
     const std::any tsym = mi355x::Symbol{mi355x::Symbol::TIME, 0};
     if (_objective == NULL) die("no objective function set");
     if (_gradient.size() != getNStates()) die("setGradient needs one function per state");
@@ -165,6 +174,7 @@ void eMI355X::traceCallbacks() {
             } else {
                 const mi355x::ModelTerm t = std::any_cast<mi355x::ModelTerm>(out);
                 if (t.row != -1) die("the objective callback must return mi355x::objective(...) or a traced Var");
+                if (nxd + nud > 0) die("delayed states / controls (rhorizon) need callbacks computed with the mi355x::Var handles; the hand-written device models take none");
                 P.model = t.model;
                 P.model_params = t.params;
             }
@@ -236,7 +246,7 @@ void eMI355X::traceCallbacks() {
             mi355x::Trace& tr = mi355x::Trace::active();
             std::vector<int> used;
             for (int n : path_nodes)
-                for (int v : tr.dependencies(n, (int)getNStates(), (int)getNControls()))
+                for (int v : tr.dependencies(n, (int)getNStates(), nc_model))
                     if (std::find(used.begin(), used.end(), v) == used.end()) used.push_back(v);
             std::sort(used.begin(), used.end());
             if (!have_xy) {
@@ -247,7 +257,7 @@ void eMI355X::traceCallbacks() {
             }
             // row normalisation (the iteration works on sigma_j c_j): largest value along the straight line between
             // the boundary states, which for a keep-out row is reached where the line passes closest to its centre
-            std::vector<double> xs(getNStates()), us(getNControls(), 0.0);
+            std::vector<double> xs(getNStates()), us(nc_model, 0.0);
             for (int n : path_nodes) {
                 double ref = 0;
                 for (int q = 0; q <= 32; ++q) {
@@ -262,7 +272,7 @@ void eMI355X::traceCallbacks() {
             P.model = EMI_MODEL_SOURCE;
             P.model_params.clear();
             std::string gerr;
-            P.model_source = mi355x::Trace::active().generate_model("TracedModel", (int)getNStates(), (int)getNControls(), f_nodes,
+            P.model_source = mi355x::Trace::active().generate_model("TracedModel", (int)getNStates(), nc_model, f_nodes,
                                                                      cost_node, path_nodes, &P.path_vars, &gerr);
             if (P.model_source.empty()) die(gerr);
         }
@@ -318,10 +328,12 @@ void eMI355X::setup() {
     mi355x::Prob& P = _problem;
     // ePSOPT::dae appends delayed states for i = 1 .. Xrhorizon-1 and delayed controls for i = 1 .. Urhorizon
     // (ePSOPT.cpp:231-248): a state horizon of 0 or 1 adds nothing (the shipped mip_2d_ex1.xml has rhorizon="1")
-    if (getXrhorizon() > 1 || getUrhorizon() > 0)
-        die("delayed states (rhorizon > 1) / delayed controls (rhorizon > 0) are not supported by the device models yet");
     P.nstates = getNStates();
     P.ncontrols = getNControls();
+    P.xhorizon = getXrhorizon();
+    P.uhorizon = getUrhorizon();
+    P.ndelayed = (P.xhorizon > 1 ? (P.xhorizon - 1) * P.nstates : 0) + P.uhorizon * P.ncontrols;
+    P.delay_dt = getDt();                            // delay = getDt() * i, ePSOPT.cpp:232, 241
     P.nodes = getNSteps() + 1;                       // ePSOPT.cpp:44-45
     P.t0 = 0.;
     P.tf = getNSteps() * getDt();                    // fixed horizon, ePSOPT.cpp:151-154
@@ -397,7 +409,7 @@ void eMI355X::configureDevice(Device* dev) {
     if (P.model == EMI_MODEL_SOURCE) {
         // compiled for gfx950 once per context; meshes come and go.  The call also fixes the objective sign.
         if (dev->installed_source != P.model_source || dev->installed_maximize != isMaximized())
-            must(emi_set_model_source(c, "TracedModel", P.model_source.c_str(), (int)P.nstates, (int)P.ncontrols,
+            must(emi_set_model_source(c, "TracedModel", P.model_source.c_str(), (int)P.nstates, (int)(P.ncontrols + P.ndelayed),
                                       (int)P.npath_traced, P.path_vars.data(), (int)P.path_vars.size(), nullptr, 0,
                                       isMaximized() ? 1 : 0), c, "emi_set_model_source");
         dev->installed_source = P.model_source;
@@ -407,6 +419,7 @@ void eMI355X::configureDevice(Device* dev) {
              "emi_set_model");
         dev->installed_source.clear();
     }
+    must(emi_set_delays(c, (int)P.xhorizon, (int)P.uhorizon, P.delay_dt > 0 ? P.delay_dt : 1.0), c, "emi_set_delays");
     must(emi_set_batch(c, 1), c, "emi_set_batch");
     if (P.ntracks)
         must(emi_set_tracks(c, (int)P.ntracks, 1, P.track_x.data(), P.track_y.data()), c, "emi_set_tracks");
@@ -637,9 +650,29 @@ std::vector<double> initial_guess(const Prob& P) {
 
 }  // namespace mi355x
 
+void eMI355X::evaluate(const std::vector<double>& z, std::vector<double>* res, std::vector<double>* vals, double* cost) {
+    if (!_dev || !_dev->ctx) die("evaluate() called before setup()");
+    const mi355x::Prob& P = _problem;
+    const size_t ns = P.nstates, nc = P.ncontrols, M = P.nodes;
+    if (z.size() != (ns + nc) * M) die("evaluate(): z must hold nstates + ncontrols rows of `nodes` values");
+    emi_layout_t lay;
+    must(emi_get_layout(_dev->ctx, &lay), _dev->ctx, "emi_get_layout");
+    std::vector<double> r((size_t)lay.nres * M), v((size_t)lay.nvals * M);
+    double c = 0;
+    must(emi_eval_host(_dev->ctx, z.data(), z.data() + ns * M, r.data(), v.data(), &c, vals ? EMI_EVAL_ALL : (EMI_EVAL_ALL | EMI_EVAL_NOJAC)),
+         _dev->ctx, "emi_eval_host");
+    if (res) *res = r;
+    if (vals) *vals = v;
+    if (cost) *cost = c;
+}
+
 void eMI355X::solve() {
     if (!_dev || !_dev->ctx) die("solve() called before setup()");
     mi355x::Prob& P = _problem;
+    if (P.ndelayed > 0)
+        die("solve(): delayed states / controls are evaluated on the device (setup(), evaluate()), but the Newton step of this "
+            "backend is built on a node-diagonal Jacobian plus D (x) I; the interpolation operator of a delayed value couples a "
+            "node to the whole trajectory and has no place in it yet (INTEGRATION.md, limitations)");
     const size_t ns = P.nstates, nc = P.ncontrols;
 
     mi355x::NlpOptions opt;

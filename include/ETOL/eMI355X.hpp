@@ -76,6 +76,10 @@ struct Sol {
 struct Prob {
     std::string name = "ETOL Problem";
     size_t nstates = 0, ncontrols = 0, nodes = 0, npath = 0;
+    // delayed values (ePSOPT::dae, ePSOPT.cpp:231-248): xhorizon - 1 delayed copies of every state, uhorizon of every control,
+    // delay i * delay_dt; the device model sees them as ndelayed extra inputs behind the ncontrols controls
+    size_t xhorizon = 0, uhorizon = 0, ndelayed = 0;
+    double delay_dt = 0;
     std::vector<size_t> row_order;                 // evaluation-order row q is row row_order[q] of the callbacks
     std::vector<double> traced_scale;              // normalisation of the traced rows inside the NLP iteration
     size_t npath_traced = 0;                       // of npath: rows traced from constraint callbacks (they follow the table rows)
@@ -117,6 +121,12 @@ class eMI355X : public TrajectoryOptimizer {
     // PSOPT-style relative local ODE error of a trajectory z = [X (nstates x nodes), U (ncontrols x nodes)] on the
     // current mesh (what the automatic mesh refinement compares with ode_tolerance); needs setup()
     double odeError(const std::vector<double>& z, std::vector<double>* z_fine = nullptr, size_t* nodes_fine = nullptr);
+    // One evaluation pass of the transcribed problem at z = [X (nstates x nodes), U (ncontrols x nodes)] on the device -- what
+    // the NLP solver asks ePSOPT for through PSOPT (dae + integrand_cost at every node, defects, quadrature, Jacobian
+    // values): res [nstates + npath][nodes] (defect rows, then path rows), vals [nvals][nodes] (may be NULL), cost.  Layouts:
+    // include/emi355x.h.  Needs setup().  With delayed states / controls the node variables of vals are
+    // [x | u | delayed values] (emi_set_delays).
+    void evaluate(const std::vector<double>& z, std::vector<double>* res, std::vector<double>* vals, double* cost);
 
  protected:
     mi355x::Alg _algorithm;

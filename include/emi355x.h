@@ -187,6 +187,23 @@ int emi_set_model_source(emi_ctx_t ctx, const char* struct_name, const char* sou
 int emi_check_model_source(const char* struct_name, const char* source, int ns,
                            int nc, int npath, int n_path_vars, int f32, char* log, size_t log_len);
 int emi_set_batch(emi_ctx_t ctx, int B);
+/* Delayed states and controls -- what ePSOPT::dae appends to the callbacks' x and u through PSOPT's get_delayed_state /
+ * get_delayed_control (reference src/ePSOPT/ePSOPT.cpp:231-248): x(t - i dt) of every state for i = 1 .. x_horizon - 1 and
+ * u(t - i dt) of every control for i = 1 .. u_horizon.  On the device they are extra INPUTS of the node functions: the model
+ * (emi_set_model_source) is written with nc_model = nc + (x_horizon - 1) ns + u_horizon nc controls, ordered
+ *     [ u (nc) | x(t - dt) (ns) | .. | x(t - (x_horizon-1) dt) | u(t - dt) (nc) | .. | u(t - u_horizon dt) ],
+ * the caller keeps passing U[B][nc][M], and every evaluation first forms the delayed rows as W(i dt) . (node values) on the
+ * MFMA defect kernel: W(delay)[k][j] = Lagrange basis polynomial j of the LGL nodes at t_k - delay (the value of the
+ * collocation polynomial -- PSOPT's "Legendre" interpolation), with t_k - delay CLAMPED to t0: PSOPT 5.0.0 is not part of the
+ * reference tree, and this build takes the history of a delayed variable before t0 to be its value at t0.
+ * VALS / H then hold partials with respect to the delayed inputs as they hold those of the controls (entries of the extended
+ * node-variable vector); the total derivative with respect to the trajectory is (d . / d delayed) . W -- W stays an operator,
+ * like the off-diagonal part of I (x) D.  emi_get_layout reports nc = nc_model; emi_get_delays the split.  Must follow
+ * emi_set_model_source (a model change drops the delays).  Horizons 0 / 1 and 0: no delayed values, as the reference.    */
+int emi_set_delays(emi_ctx_t ctx, int x_horizon, int u_horizon, double dt);
+int emi_get_delays(emi_ctx_t ctx, int* x_horizon, int* u_horizon, int* n_delayed);
+/* W(delay)[M][M] as above, on the host (no device needed)                                                                   */
+int emi_delay_matrix(int M, const double* tau, const double* w, double t0, double tf, double delay, double* W);
 /* recs: [nsets][np][EMI_PATH_REC]; nsets is 1 (shared) or B (per instance) */
 int emi_set_path(emi_ctx_t ctx, int np, int nsets, const double* recs,
                  int px_state, int py_state);

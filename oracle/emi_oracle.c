@@ -45,7 +45,7 @@
 
 typedef double complex cplx;
 
-enum { M_POINTMASS = 0, M_QUADROTOR = 1, M_FIXEDWING = 2 };
+enum { M_POINTMASS = 0, M_QUADROTOR = 1, M_FIXEDWING = 2, M_DELAYDEMO = 3 };
 enum { P_ELLIPSE = 0, P_DISC = 1, P_TRACK = 2 };
 #define REC 8
 
@@ -54,6 +54,9 @@ static int model_dims(int model, int* ns, int* nc) {
         case M_POINTMASS: *ns = 2; *nc = 2; return 0;
         case M_QUADROTOR: *ns = 6; *nc = 2; return 0;
         case M_FIXEDWING: *ns = 12; *nc = 4; return 0;
+        /* 2 states, 2 controls, state horizon 3, control horizon 1 (ePSOPT.cpp:231-248): the node functions see
+         * z = [x0 x1 | u0 u1 | x(t-dt) | x(t-2dt) | u(t-dt)], i.e. 8 "controls" of which the last 6 are delayed values */
+        case M_DELAYDEMO: *ns = 2; *nc = 8; return 0;
     }
     return 1;
 }
@@ -114,6 +117,30 @@ int orc_lgl(int M, double* tau, double* w, double* D) {
     return 0;
 }
 
+/* ---- delayed values ---------------------------------------------------------- */
+/* ePSOPT::dae appends get_delayed_state / get_delayed_control values (ePSOPT.cpp:231-248).  PSOPT 5.0.0 is not in the
+ * reference tree; per its published description the delayed value is the collocation polynomial (Lagrange interpolation
+ * through the node values for "Legendre" collocation) evaluated at t - delay.  Times before t0 are clamped to t0 (an
+ * assumption of this build, the same one as the product: include/emi355x.h).  Route deliberately different from the
+ * product's barycentric form: the plain product formula of the Lagrange basis, in long double.
+ * W[k][j] = l_j(x_k*),  x_k* = node coordinate of max(t_k - delay, t0).                                                  */
+int orc_delay_matrix(int M, const double* tau, double t0, double tf, double delay, double* W) {
+    if (M < 2 || !(tf > t0) || delay < 0) return 1;
+    const long double hh = ((long double)tf - t0) / 2;
+    for (int k = 0; k < M; ++k) {
+        long double ts = t0 + hh * ((long double)tau[k] + 1) - delay;
+        if (ts < t0) ts = t0;
+        const long double x = (ts - t0) / hh - 1;
+        for (int j = 0; j < M; ++j) {
+            long double l = 1;
+            for (int m = 0; m < M; ++m)
+                if (m != j) l *= (x - tau[m]) / ((long double)tau[j] - tau[m]);
+            W[(size_t)k * M + j] = (double)l;
+        }
+    }
+    return 0;
+}
+
 /* ---- keep-out constants ----------------------------------------------------- */
 /* etol_psopt_example1.cpp:163-176, operation for operation */
 void orc_edge_ellipse(double xa, double ya, double xb, double yb, double* rec) {
@@ -152,6 +179,10 @@ static void dyn(int model, const double* p, const cplx* z, cplx* f) {
         /* dxdt returns u0, dydt returns u1 */
         f[0] = z[2];
         f[1] = z[3];
+    } else if (model == M_DELAYDEMO) {
+        /* build-defined test dynamics on delayed inputs (the reference ships no model with a horizon above 1) */
+        f[0] = -p[0] * z[4] + z[2] + 0.1 * z[9] * z[1];
+        f[1] = z[0] * z[7] - csin(z[5]) + z[3] * z[8];
     } else if (model == M_QUADROTOR) {
         const double m = p[0], Jy = p[1], g = p[2];
         f[0] = z[3];
@@ -189,6 +220,7 @@ static void dyn(int model, const double* p, const cplx* z, cplx* f) {
 static cplx lag(int model, const double* p, const cplx* z) {
     if (model == M_POINTMASS) return z[2] * z[2] + z[3] * z[3]; /* objFunction :108 */
     if (model == M_QUADROTOR) return p[3] * z[6] * z[6] + p[4] * z[7] * z[7];
+    if (model == M_DELAYDEMO) return z[2] * z[2] + z[3] * z[3] + p[1] * z[4] * z[6] + 0.05 * z[8] * z[8];
     return p[15] * (z[12] * z[12] + z[13] * z[13] + z[14] * z[14] + z[15] * z[15]);
 }
 

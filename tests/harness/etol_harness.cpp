@@ -264,6 +264,50 @@ mx::Var traced_quad_rhs(const std::vector<mx::Var>& x, const std::vector<mx::Var
 mx::Var traced_quad_cost(const std::vector<mx::Var>& u) { return 1.0 * u[0] * u[0] + 1.0 * u[1] * u[1]; }
 }  // namespace
 
+// ---- delayed states / controls (ePSOPT::dae, ePSOPT.cpp:231-248): a 2-state problem with a state horizon of 3 and a control
+// horizon of 1, set up through the public ETOL API; the callbacks compute with the handles as an ePSOPT user's compute with
+// adoubles, reading the delayed values from the tails of x and u exactly where ePSOPT::dae appends them.  Same functions as
+// model 3 of oracle/emi_oracle.c.  Returns the device's evaluation at z = [X (2 x M) | U (2 x M)].
+extern "C" int harness_delay_demo(int nsteps, double dt, int xh, int uh, int with_disc, const double* z, double* res, int res_cap,
+                                  double* vals, int vals_cap, double* cost, int* nres, int* nvals) {
+    ETOL::eMI355X solver;
+    ETOL::TrajectoryOptimizer* t = &solver;
+    t->setNSteps(nsteps); t->setDt(dt); t->setNStates(2); t->setNControls(2);
+    t->setXrhorizon(xh); t->setUrhorizon(uh);
+    t->setX0({1, 2}); t->setXf({3, 1}); t->setXtol({0.01, 0.01});
+    t->setXlower({-10, -10}); t->setXupper({10, 10}); t->setUlower({-5, -5}); t->setUupper({5, 5});
+    t->setMaximize(false);
+    const double p0 = 0.7, p1 = 0.3;
+    auto V = [](const std::any& a) { return std::any_cast<mx::Var>(a); };
+    // x = [x0 x1 | x(t-dt) | x(t-2dt)], u = [u0 u1 | u(t-dt)]  (ePSOPT.cpp:225-248)
+    ETOL::f_t obj = [=](F_ARGS) -> ETOL::scalar_t {
+        return V(u.at(0)) * V(u.at(0)) + V(u.at(1)) * V(u.at(1)) + p1 * V(x.at(2)) * V(x.at(4)) + 0.05 * V(u.at(2)) * V(u.at(2));
+    };
+    ETOL::f_t f0 = [=](F_ARGS) -> ETOL::scalar_t { return -p0 * V(x.at(2)) + V(u.at(0)) + 0.1 * V(u.at(3)) * V(x.at(1)); };
+    ETOL::f_t f1 = [=](F_ARGS) -> ETOL::scalar_t { return V(x.at(0)) * V(x.at(5)) - mx::sin(V(x.at(3))) + V(u.at(1)) * V(u.at(2)); };
+    t->setObjective(&obj);
+    t->setGradient({&f0, &f1});
+    ETOL::f_t obs = [](F_ARGS) -> ETOL::scalar_t {
+        return mx::disc_rows({{2.0, 1.5, 0.5}}, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+    };
+    if (with_disc) {
+        t->addParams({std::pair<PARAM_PAIR>("disc_0", {ETOL::var_t::CONTINUOUS, -1000., 0., 0., nsteps * dt})});
+        t->setConstraints({&obs});
+    }
+    t->setup();
+    const size_t M = nsteps + 1;
+    std::vector<double> zz(z, z + 4 * M), r, v;
+    solver.evaluate(zz, &r, &v, cost);
+    *nres = (int)(r.size() / M);
+    *nvals = (int)(v.size() / M);
+    if ((int)r.size() > res_cap || (int)v.size() > vals_cap) return 2;
+    std::copy(r.begin(), r.end(), res);
+    std::copy(v.begin(), v.end(), vals);
+    g_out = solver.getProblem()->model_source;
+    t->close();
+    return 0;
+}
+
 // ---- quadrotor VGP (the headline model) as an ETOL problem set up through the public API --------
 namespace {
 int g_traced = 0;               // 1: callbacks compute with mx::Var handles (traced model) instead of naming a built-in

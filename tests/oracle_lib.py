@@ -57,6 +57,15 @@ def lgl(M):
     return tau, w, D
 
 
+def delay_matrix(M, tau, t0, tf, delay):
+    """W[k][j]: value at t_k - delay (clamped to t0) of the Lagrange basis polynomial j of the nodes (emi_oracle.c)"""
+    tau = np.ascontiguousarray(tau, dtype=np.float64)
+    W = np.empty((M, M))
+    orc().orc_delay_matrix.argtypes = [C.c_int, _D, C.c_double, C.c_double, C.c_double, _D]
+    assert orc().orc_delay_matrix(M, _dp(tau), t0, tf, delay, _dp(W)) == 0
+    return W
+
+
 def edge_ellipse(xa, ya, xb, yb):
     rec = np.zeros(8)
     orc().orc_edge_ellipse(xa, ya, xb, yb, _dp(rec))
@@ -70,7 +79,7 @@ def track_centres(t, x, y, node_t):
     return xc, yc
 
 
-MODEL_DIMS = {0: (2, 2), 1: (6, 2), 2: (12, 4)}
+MODEL_DIMS = {0: (2, 2), 1: (6, 2), 2: (12, 4), 3: (2, 8)}      # 3: delay demo (2 controls + 6 delayed values)
 
 
 def _prep(model, params, M, recs, tracks, X, U):
