@@ -49,6 +49,7 @@ struct KktTuning {
     std::atomic<int> debug{0};              // "kkt_debug": 1 retries and fallbacks on stderr, 2 also the blocks around a failing pivot
     std::atomic<int> potrf_lock{0};         // "kkt_potrf_lock": serialise rocsolver_dpotrf calls of different host threads
     std::atomic<int> sticky_reg{1};         // "kkt_sticky_reg": start the Schur path at the regularisation level that worked last on this mesh
+    std::atomic<int> primal_levels{1};      // "kkt_primal_levels": 1 primal regularisation levels behind the dual ones before the LU fallback, 0 the round-2 ladder
 };
 static KktTuning g_tune;
 bool kkt_set_option(const char* name, int value) {
@@ -58,6 +59,7 @@ bool kkt_set_option(const char* name, int value) {
     if (!strcmp(name, "kkt_debug")) { g_tune.debug = value; return true; }
     if (!strcmp(name, "kkt_potrf_lock")) { g_tune.potrf_lock = value != 0; return true; }
     if (!strcmp(name, "kkt_sticky_reg")) { g_tune.sticky_reg = value != 0; return true; }
+    if (!strcmp(name, "kkt_primal_levels")) { g_tune.primal_levels = value != 0; return true; }
     return false;
 }
 
@@ -159,7 +161,7 @@ __global__ void emi_kkt_mask_rhs_kernel(double* __restrict__ rhs, const unsigned
 __global__ __launch_bounds__(64) void emi_kkt_node_inverse_kernel(const double* __restrict__ Q, const double* __restrict__ J,
                                                                  const unsigned char* __restrict__ fixed, int M, int ns,
                                                                  int nv, double* __restrict__ Pinv, double* __restrict__ G,
-                                                                 double* __restrict__ Rk, int* __restrict__ flag) {
+                                                                 double* __restrict__ Rk, int* __restrict__ flag, double dw) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= M) return;
     double A[KKT_NV_MAX][KKT_NV_MAX], X[KKT_NV_MAX][KKT_NV_MAX];
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64) void emi_kkt_node_inverse_kernel(const double* 
     for (int v = 0; v < nv; ++v) fx[v] = fixed[v * M + k] != 0;
     for (int v = 0; v < nv; ++v)
         for (int q = 0; q <= v; ++q)
-            A[v][q] = (fx[v] || fx[q]) ? (v == q ? 1.0 : 0.0) : Q[(size_t)(v * (v + 1) / 2 + q) * M + k];
+            A[v][q] = (fx[v] || fx[q]) ? (v == q ? 1.0 : 0.0) : Q[(size_t)(v * (v + 1) / 2 + q) * M + k] + ((v == q && v < ns) ? dw : 0.0);
     bool ok = true;
     for (int i = 0; i < nv; ++i)
         for (int j = 0; j <= i; ++j) {
@@ -589,9 +591,6 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         KKT_HIP(hipMemsetAsync(w->flag, 0, sizeof(int), stream));
         const unsigned nb2 = (unsigned)(((size_t)M * M + 255) / 256);
         hipLaunchKernelGGL(emi_kkt_doff_kernel, dim3(nb2), dim3(256), 0, stream, dD, w->Doff, M);
-        hipLaunchKernelGGL(emi_kkt_node_inverse_kernel, dim3((M + 63) / 64), dim3(64), 0, stream, w->Q, w->J, w->fixed, M, ns, nv,
-                           w->Pinv, w->G, w->Rk, w->flag);
-        KKT_HIP(hipGetLastError());
         // Doff is stored [k][j] row-major, i.e. as the column-major matrix Dc = Doff^T:  Doff diag(p) Doff^T = Dc^T (diag(p) Dc)
         const double one = 1.0, zero = 0.0;
         rocblas_int hinfo = 0;
@@ -600,16 +599,30 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         // a 1000-node mesh the entries of S reach 1e16 and an absolute 1e-3 no longer rescues the Cholesky -- the relative
         // shift does, but the factor of such an S is too inaccurate for the refinement to repair: the 1024-node solve went
         // from 12 to 174 iterations.  Those few matrices belong to the LU below.)
-        double dc_schur = dc > 1e-9 ? dc : 1e-9;
+        // Regularisation ladder of the Schur path.  Level l factorises S with the dual regularisation dc_l and the node blocks
+        // with a primal regularisation dw_l on their free diagonal (IPOPT's delta_c / delta_w, here applied ONLY to make the
+        // factorisation exist: the caller's iterative refinement works against the nominal matrix and takes the difference
+        // out again).  Round 2 had the dual levels only and sent what failed all three to an LU of the whole assembled KKT
+        // matrix (rocSOLVER getrf, one launch per column: 43 000 launches and ~210 ms at 1024 nodes of the 6-state model, two
+        // or three times per solve).  Those matrices come from late iterations (mu <= 1e-7): state variables away from their
+        // bounds carry ~1e-9 of curvature, P = Q^-1 ~ 1e9, and S = J P J^T ~ 1e19 at the clustered end nodes loses its positive
+        // definiteness to rounding whatever the dual shift.  A primal shift bounds P instead (profiles/r03_notes.md) -- on the
+        // STATE variables only: they are pinned by the defect equations, so the shift barely moves the step, whereas the
+        // controls' own curvature (h w_k L_uu ~ 1e-5 .. 1e-2) would drown in it (shifting every variable: 24 factorisations on
+        // the last mesh of scenario 0 instead of 13).
+        static const double LV_DC[5] = {1.0, 1e3, 1e3, 1e3, 1e6}, LV_DW[5] = {0.0, 0.0, 1e-7, 1e-5, 1e-3};
+        constexpr int NLV = 5;
+        const double dc_base = dc > 1e-9 ? dc : 1e-9;
+        double dc_schur = dc_base;
         if (w->reg_M != M || w->reg_ns != ns || w->reg_nv != nv || !g_tune.sticky_reg.load()) {
             w->reg_level = w->reg_hits = 0;
             w->reg_M = M; w->reg_ns = ns; w->reg_nv = nv;
-        } else if (w->reg_level > 0 && w->reg_hits >= 2) {
+        } else if (w->reg_level > 0 && w->reg_hits >= 4) {
             --w->reg_level;
             w->reg_hits = 0;
         }
-        const int first_attempt = w->reg_level;
-        for (int a = 0; a < first_attempt && a < 3; ++a) dc_schur *= 1e3;
+        const int max_lv = g_tune.primal_levels.load() ? NLV : 2;      // "kkt_primal_levels" 0: the round-2 ladder (dual levels, then the LU)
+        const int first_attempt = std::min(w->reg_level, max_lv - 1);
         if (batched && (w->ptrs_key[0] != w->Doff || w->ptrs_key[1] != w->W || w->ptrs_key[2] != w->S || w->ptrs_M != M ||
                         w->ptrs_ns != ns)) {
             std::vector<double*> hp(3 * (size_t)npairs);
@@ -626,8 +639,16 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
             w->ptrs_M = M; w->ptrs_ns = ns;
         }
         int attempt = first_attempt;
-        if (first_attempt >= 3) hinfo = 1;          // the last factorisations on this mesh all ended in the LU
-        for (; attempt < 3; ++attempt, dc_schur *= 1e3) {
+        double dw_done = -1.0;
+        for (; attempt < max_lv; ++attempt) {
+            dc_schur = dc_base * LV_DC[attempt];
+            if (LV_DW[attempt] != dw_done) {        // node blocks (re)inverted with this level's primal shift
+                dw_done = LV_DW[attempt];
+                KKT_HIP(hipMemsetAsync(w->flag, 0, sizeof(int), stream));
+                hipLaunchKernelGGL(emi_kkt_node_inverse_kernel, dim3((M + 63) / 64), dim3(64), 0, stream, w->Q, w->J, w->fixed, M, ns, nv,
+                                   w->Pinv, w->G, w->Rk, w->flag, dw_done);
+                KKT_HIP(hipGetLastError());
+            }
             if (batched) {
                 // three launches for all ns (ns + 1) / 2 state pairs: small meshes are launch-bound here
                 hipLaunchKernelGGL(emi_kkt_scale_all_kernel, dim3(nb2, npairs), dim3(256), 0, stream, w->Doff, w->Pinv, w->W, M, nv);
@@ -653,8 +674,8 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
             KKT_HIP(hipStreamSynchronize(stream));
             if (hinfo == 0 || hflag != 0) break;      // factorised, or hopeless (a Q block is not positive definite)
             if (g_tune.debug.load())
-                fprintf(stderr, "emi_kkt_factor: S not positive definite at %d with dual regularisation %.1e (M %d), retrying\n",
-                        (int)hinfo, dc_schur, M);
+                fprintf(stderr, "emi_kkt_factor: S not positive definite at %d with dual regularisation %.1e, primal %.1e (M %d), retrying\n",
+                        (int)hinfo, dc_schur, dw_done, M);
         }
         if (hinfo == 0 && hflag == 0) {
             if (attempt == first_attempt) ++w->reg_hits; else { w->reg_level = attempt; w->reg_hits = 0; }
@@ -664,11 +685,11 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
             return EMI_OK;
         }
         if (hflag == 0) {                           // S not positive definite at any level
-            w->reg_level = 2;                           // (the next factorisation starts at the last level, not at the LU)
+            w->reg_level = max_lv - 1;                  // (the next factorisation starts at the last level, not at the LU)
             w->reg_hits = 0;
         }
         // a block was not positive definite or S is not: not the quasi-definite case -- general path below
-        if (g_tune.debug.load() >= 2 && hinfo > 0 && first_attempt < 3) {
+        if (g_tune.debug.load() >= 2 && hinfo > 0) {
             // diagnosis: the node blocks around the failing pivot (diagonals of Q as uploaded and of P = Q^-1)
             const int kf = ((int)hinfo - 1) % M, i_f = ((int)hinfo - 1) / M;
             std::vector<double> hq((size_t)nh * M), hp((size_t)nv * nv * M);

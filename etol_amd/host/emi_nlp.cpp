@@ -964,13 +964,13 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 double bmax = 0;
                 for (size_t r = 0; r < NN; ++r) bmax = std::max(bmax, std::fabs(rhs_keep[r]));
                 double prev = 1e300;
-                for (int ir = 0; ir < 3; ++ir) {
+                for (int ir = 0; ir < 8; ++ir) {      // (8 since the backend may have regularised the factorised matrix: linear convergence)
                     { const auto tm = now(); kkt_matvec(Qm.data(), rhs_full.data(), resid.data(), dc); R.t_matvec += secs(tm, now()); }
                     double rmax = 0;
                     for (size_t r = 0; r < NN; ++r) { resid[r] = rhs_keep[r] - resid[r]; rmax = std::max(rmax, std::fabs(resid[r])); }
                     if (!(rmax > 1e-14 * std::max(1.0, bmax)) || !(rmax < 0.5 * prev)) break;
                     prev = rmax;
-                    if (kkt->solve(resid.data(), 1) != 0) break;
+                    { const auto ts = now(); const int rs = kkt->solve(resid.data(), 1); R.t_solve += secs(ts, now()); ++R.n_solve; if (rs != 0) break; }
                     bool fin = true;
                     for (size_t r = 0; r < NN && fin; ++r) fin = std::isfinite(resid[r]);
                     if (!fin) break;
