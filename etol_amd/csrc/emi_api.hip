@@ -1292,7 +1292,7 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         return EMI_OK;
     }
     if (strcmp(name, "node_store") == 0) {
-        if (value < -1 || value > 2) return fail(c, EMI_ERR_ARG, "node_store must be -1 (by size), 0 (plain), 1 (write-through) or 2 (non-temporal)");
+        if (value < -1 || value > 3) return fail(c, EMI_ERR_ARG, "node_store must be -1 (by size), 0 (plain), 1 (write-through sc1), 2 (non-temporal) or 3 (nt sc1; the one-launch pass only)");
         c->node_store = value;
         return EMI_OK;
     }

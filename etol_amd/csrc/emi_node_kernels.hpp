@@ -49,6 +49,38 @@ EMI_DEV void store_vec(T* __restrict__ p, const T (&r)[VEC]) {
     }
 }
 
+// Result rows of one instance (RES or VALS block: wave-uniform base, per-lane element offset).  ST 0 plain, 2 non-temporal: global
+// stores through store_vec.  ST 1 (sc1: write-through, the line is DROPPED from the XCD's L2) and 3 (nt sc1): buffer stores issued by
+// the compiler (`buffer_store_dwordx4 ... sc1` from __builtin_amdgcn_raw_buffer_store_b128, cache-policy bits sc1 = 16, nt = 2) -- the
+// inline-assembly sc1 form above pins every store in program order behind a wait state and was 50 % slower in the one-launch pass.
+template <typename T, int VEC, int ST> struct RowStore {
+    T* base;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __amdgpu_buffer_rsrc_t rs;
+#endif
+    EMI_DEV explicit RowStore(T* b) : base(b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (ST == 1 || ST == 3) rs = __builtin_amdgcn_make_buffer_rsrc(b, 0, 0x7fffffff, 0x00027000);
+#endif
+    }
+    EMI_DEV void operator()(size_t off, const T (&r)[VEC]) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr ((ST == 1 || ST == 3) && sizeof(T) * VEC == 16) {
+            using P = typename Pack<T, VEC>::type;
+            P v;
+            T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) e[i] = r[i];
+            emi_v4i q;
+            __builtin_memcpy(&q, &v, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(q, rs, (int)(off * sizeof(T)), 0, ST == 1 ? 16 : 18);
+            return;
+        }
+#endif
+        store_vec<T, VEC, (ST == 3 ? 2 : ST)>(base + off, r);
+    }
+};
+
 // VALS entries of the rows traced from constraint callbacks: NPATH * PW (0 for the hand-written models)
 template <class Model> EMI_DEV constexpr int emi_traced_partials() {
     if constexpr (Model::NPATH > 0) return Model::NPATH * Model::PW;
@@ -92,6 +124,7 @@ EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, con
         const T* __restrict__ Ub = a.U + (size_t)b * NC * M;
         T* __restrict__ Rb = a.RES + (size_t)b * a.nres * M;
         T* __restrict__ Vb = JAC ? a.VALS + (size_t)b * a.nvals * M : nullptr;
+        const RowStore<T, VEC, ST> stR(Rb), stV(Vb);      // every result row of this instance goes through these
 
         T z[NV][VEC];
 #pragma unroll
@@ -121,7 +154,7 @@ EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, con
             }
             if (DEFROWS) {
 #pragma unroll
-                for (int i = 0; i < NS; ++i) store_vec<T, VEC, ST>(Rb + (size_t)i * M + k0, fo[i]);
+                for (int i = 0; i < NS; ++i) stR((size_t)i * M + k0, fo[i]);
             }
         }
         if (JAC) {
@@ -148,11 +181,11 @@ EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, con
             for (int i = 0; i < NS; ++i)
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
-                    store_vec<T, VEC, ST>(Vb + (size_t)(i * NV + v) * M + k0, Jv[i][v]);
+                    stV((size_t)(i * NV + v) * M + k0, Jv[i][v]);
             // cost gradient: behind the dynamics block, two partials per table row and PW per traced row
-            T* __restrict__ Gb = Vb + (size_t)(NS * NV + 2 * (a.np - Model::NPATH) + emi_traced_partials<Model>()) * M;
+            const size_t goff = (size_t)(NS * NV + 2 * (a.np - Model::NPATH) + emi_traced_partials<Model>()) * M;
 #pragma unroll
-            for (int v = 0; v < NV; ++v) store_vec<T, VEC, ST>(Gb + (size_t)v * M + k0, gv[v]);
+            for (int v = 0; v < NV; ++v) stV(goff + (size_t)v * M + k0, gv[v]);
         }
         // ---- K2 path constraints (records are wave-uniform: scalar loads) --
         const int np = a.np - Model::NPATH;      // rows of the record table; the model's own rows follow them
@@ -160,8 +193,7 @@ EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, con
             const int set = a.path_sets > 1 ? b : 0;
             typedef const __attribute__((address_space(4))) T* cptr_t;   // read-only table: scalar loads
             cptr_t rec = (cptr_t)(a.path + (size_t)set * np * EMI_PATH_REC);
-            T* __restrict__ Cb = Rb + (size_t)NS * M;
-            T* __restrict__ JCb = JAC ? Vb + (size_t)(NS * NV) * M : nullptr;
+            const size_t coff = (size_t)NS * M, jcoff = (size_t)(NS * NV) * M;      // path rows in RES, their partials in VALS
             // the keep-outs act on two runtime-chosen states: select with
             // compares, a runtime register index would go to scratch
             T px[VEC], py[VEC];
@@ -217,10 +249,10 @@ EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, con
                         cy[e] = T(-2) * dy;
                     }
                 }
-                store_vec<T, VEC, ST>(Cb + (size_t)j * M + k0, c);
+                stR(coff + (size_t)j * M + k0, c);
                 if (JAC) {
-                    store_vec<T, VEC, ST>(JCb + (size_t)(2 * j) * M + k0, cx);
-                    store_vec<T, VEC, ST>(JCb + (size_t)(2 * j + 1) * M + k0, cy);
+                    stV(jcoff + (size_t)(2 * j) * M + k0, cx);
+                    stV(jcoff + (size_t)(2 * j + 1) * M + k0, cy);
                 }
             }
             if constexpr (Model::NPATH > 0) {
@@ -240,10 +272,10 @@ EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, con
                     for (int j = 0; j < NPM * PW; ++j) cdm[j][e] = cde[j];
                 }
 #pragma unroll
-                for (int j = 0; j < NPM; ++j) store_vec<T, VEC, ST>(Cb + (size_t)(np + j) * M + k0, cm[j]);
+                for (int j = 0; j < NPM; ++j) stR(coff + (size_t)(np + j) * M + k0, cm[j]);
                 if (JAC) {
 #pragma unroll
-                    for (int j = 0; j < NPM * PW; ++j) store_vec<T, VEC, ST>(JCb + (size_t)(2 * np + j) * M + k0, cdm[j]);
+                    for (int j = 0; j < NPM * PW; ++j) stV(jcoff + (size_t)(2 * np + j) * M + k0, cdm[j]);
                 }
             }
         }

@@ -175,9 +175,10 @@ static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<doub
     a.nm8 = nm / 8;
     a.nn8 = nn / 8;
     const size_t lds = (size_t)NST * ((2 * SW * FUSED_TI + 2 * 64 + 63) / 64 * 64) * 8 * sizeof(double);
-    static bool attr_done[3] = {false, false, false};
-    const int st = na.store_mode == 2 ? 2 : (na.store_mode == 1 ? 1 : 0);   // result stores: plain / write-through (sc1) / non-temporal
-    auto kern = st == 2 ? emi_pass_f64_kernel<Model, SW, 2, 2, NST> : (st == 1 ? emi_pass_f64_kernel<Model, SW, 2, 1, NST> : emi_pass_f64_kernel<Model, SW, 2, 0, NST>);
+    static bool attr_done[4] = {false, false, false, false};
+    const int st = (na.store_mode >= 0 && na.store_mode <= 3) ? na.store_mode : 0;   // result stores: plain / sc1 (write-through) / non-temporal / nt sc1
+    auto kern = st == 2 ? emi_pass_f64_kernel<Model, SW, 2, 2, NST>
+              : (st == 1 ? emi_pass_f64_kernel<Model, SW, 2, 1, NST> : (st == 3 ? emi_pass_f64_kernel<Model, SW, 2, 3, NST> : emi_pass_f64_kernel<Model, SW, 2, 0, NST>));
     if (!attr_done[st]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

@@ -547,8 +547,11 @@ def test_every_mfma_defect_kernel_variant_matches_the_oracle(built, sym_ct, shap
         got = ev.eval_host(X, U)
         assert ev.uses_fused_kernel
         check(c, ev, got, ref)
-    ev.set_option("node_store", -1)
     ev.set_option("overlap_mode", 3)      # the pass as one launch (MFMA-role and node-role workgroups, COST by ticket)
+    for store in (1, 3):                  # ... with write-through (sc1) and nt sc1 result stores (compiler-issued buffer stores)
+        ev.set_option("node_store", store)
+        check(c, ev, ev.eval_host(X, U), ref)
+    ev.set_option("node_store", -1)
     one = ev.eval_host(X, U)
     if sym_ct != 3 and M == 1024:      # (the other shapes do not fill whole XCD shares and fall back to two streams)
         assert "one launch" in ev.last_defect_kernel, ev.last_defect_kernel

@@ -63,6 +63,19 @@ FORMS = {
     "g1c2": dict(sym_gblk=1, sym_cx=2),
     "g2c4": dict(sym_gblk=2, sym_cx=4),
     "slice512": dict(slice=512),
+    "one_sw2_ntsc1": dict(overlap_mode=3, sym_ct=6, node_store=3),
+    "one_sw2_sc1_cp1": dict(overlap_mode=3, sym_ct=6, node_store=1, sym_cpart=1),
+    "one_sw2_ntsc1_cp1": dict(overlap_mode=3, sym_ct=6, node_store=3, sym_cpart=1),
+    "one_sw1_sc1": dict(overlap_mode=3, sym_ct=7, node_store=1),
+    "one_sw1_first_sc1": dict(overlap_mode=3, sym_ct=7, node_store=1, pass_order=1),
+    "one_sw2_first_sc1": dict(overlap_mode=3, sym_ct=6, node_store=1, pass_order=1),
+    "abl_x": dict(overlap_mode=3, sym_ct=6, sym_ablate=8),
+    "abl_panels": dict(overlap_mode=3, sym_ct=6, sym_ablate=64),
+    "abl_epi": dict(overlap_mode=3, sym_ct=6, sym_ablate=4),
+    "abl_x_panels": dict(overlap_mode=3, sym_ct=6, sym_ablate=72),
+    "abl_x_panels_epi": dict(overlap_mode=3, sym_ct=6, sym_ablate=76),
+    "abl_mfma_off": dict(overlap_mode=3, sym_ct=6, sym_ablate=16),
+    "abl_node_off": dict(overlap_mode=3, sym_ct=6, sym_ablate=32),
     "one_sw2_nst4": dict(overlap_mode=3, sym_ct=6, sym_nst=4),
     "one_sw2_g2c2_nst4": dict(overlap_mode=3, sym_ct=6, sym_nst=4, sym_gblk=2, sym_cx=2),
     "one_sw2_sc1": dict(overlap_mode=3, sym_ct=6, node_store=1),
@@ -94,7 +107,7 @@ FORMS = {
     "one_sw1_g4c4": dict(overlap_mode=3, sym_ct=7, sym_gblk=4, sym_cx=4),
     "one_sw3_cp4": dict(overlap_mode=3, sym_ct=8, sym_cpart=4),
 }
-RESET = dict(overlap_mode=0, sym_ct=0, pass_order=-1, slice=0, node_store=-1, sym_cpart=0, sym_gblk=0, sym_cx=0, sym_nst=3, sym_ksplit=0)
+RESET = dict(overlap_mode=0, sym_ct=0, pass_order=-1, slice=0, node_store=-1, sym_cpart=0, sym_gblk=0, sym_cx=0, sym_nst=3, sym_ksplit=0, sym_ablate=0)
 
 
 def main():
