@@ -49,6 +49,7 @@ struct KktTuning {
     std::atomic<int> debug{0};              // "kkt_debug": 1 retries and fallbacks on stderr, 2 also the blocks around a failing pivot
     std::atomic<int> potrf_lock{0};         // "kkt_potrf_lock": serialise rocsolver_dpotrf calls of different host threads
     std::atomic<int> sticky_reg{1};         // "kkt_sticky_reg": start the Schur path at the regularisation level that worked last on this mesh
+    std::atomic<int> block_trsv{1};         // "kkt_block_trsv": 1 single right-hand sides through the block-inverse triangular solves below, 0 rocsolver_dpotrs (trsv)
     std::atomic<int> primal_levels{1};      // "kkt_primal_levels": 1 primal regularisation levels behind the dual ones before the LU fallback, 0 the round-2 ladder
 };
 static KktTuning g_tune;
@@ -59,6 +60,7 @@ bool kkt_set_option(const char* name, int value) {
     if (!strcmp(name, "kkt_debug")) { g_tune.debug = value; return true; }
     if (!strcmp(name, "kkt_potrf_lock")) { g_tune.potrf_lock = value != 0; return true; }
     if (!strcmp(name, "kkt_sticky_reg")) { g_tune.sticky_reg = value != 0; return true; }
+    if (!strcmp(name, "kkt_block_trsv")) { g_tune.block_trsv = value != 0; return true; }
     if (!strcmp(name, "kkt_primal_levels")) { g_tune.primal_levels = value != 0; return true; }
     return false;
 }
@@ -101,6 +103,12 @@ struct KktWorkspace {
     // a wandering solve (inertia search: many trial matrices per iteration) stuck there with 209 of 585 factorisations
     // at 85 ms each where the Cholesky path, tried, takes 10 ms (513 nodes, profiles/r02_notes.md section 12).
     int reg_level = 0, reg_hits = 0, reg_M = 0, reg_ns = 0, reg_nv = 0;
+    // single-right-hand-side solves with the Cholesky factor of S (blk_potrs): inverses of its 512 x 512 diagonal blocks
+    double* Linv = nullptr;        // [nblk][512][512] column-major, zeros above the diagonal
+    size_t cap_Linv = 0;
+    int linv_n = 0;                // order of the factor the inverses belong to (0: none -- rocsolver_dpotrs is used)
+    double* trsv_tmp = nullptr;    // [512] x_j while its block is being multiplied
+    size_t cap_trsv_tmp = 0;
     double* chol_blk = nullptr;    // [64][64] + [64]: factorised diagonal block and reciprocal diagonal of the current block column
     double* chol_copy = nullptr;   // the matrix handed to dpotrf, kept until the factorisation is confirmed (potrf_checked)
     size_t cap_chol_copy = 0;
@@ -418,6 +426,41 @@ __global__ __launch_bounds__(64) void emi_chol_panel_kernel(double* __restrict__
     for (int c = 0; c < CHOL_NB; ++c) x[(size_t)c * lda] = y[c];
 }
 
+// ---- single-right-hand-side triangular solves with a Cholesky factor (lower, column-major) -----------------------------------
+// rocBLAS trsv takes 0.73 ms per triangular solve at 6144 rows (a 96-step dependency chain inside one launch); a 1024-node
+// interior-point solve makes ~580 of them: 36 % of its kernel time (profiles/r03_notes.md).  Here: the diagonal 512 x 512 blocks of L
+// are inverted once per factorisation (rocblas_dtrtri_strided_batched), and a solve walks the 12 block columns with two launches
+// each: x_j = Linv_j b_j (the kernels below, 64 rows per workgroup), then the right-looking update of everything not yet solved as ONE
+// gemv (rocBLAS).  Fixed summation order (atomics are off on the handle): bitwise reproducible.
+#define TRSV_NB 512
+// y = Linv b (forward, trans = 0: row r of the lower-triangular inverse block against b) or x = Linv^T y (backward, trans = 1: column c
+// of the block -- contiguous -- against y); in place on x[0 .. bs).  64 rows per workgroup; the right-hand side goes through LDS.
+__global__ __launch_bounds__(64) void emi_trsv_diag_kernel(const double* __restrict__ Linv, int bs, int trans, double* __restrict__ x,
+                                                          double* __restrict__ out) {
+    __shared__ double bsh[TRSV_NB];
+    for (int i = threadIdx.x; i < TRSV_NB; i += 64) bsh[i] = i < bs ? x[i] : 0.0;
+    __syncthreads();
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= bs) return;
+    double acc = 0.0;
+    if (!trans) {
+        const double* Li = Linv + r;                       // element (r, c) at Linv[c * NB + r]: coalesced over r
+#pragma unroll 8
+        for (int c = 0; c <= r; ++c) acc += Li[(size_t)c * TRSV_NB] * bsh[c];
+    } else {
+        // x[r] = sum_{q >= r} Linv[q][r] y[q]: walk the rows q in steps, lanes on consecutive COLUMNS r -> stride NB between lanes;
+        // the block is 2 MB and read once: L2 absorbs the stride
+        const double* Lc = Linv + (size_t)r * TRSV_NB;
+#pragma unroll 8
+        for (int q = r; q < bs; ++q) acc += Lc[q] * bsh[q];
+    }
+    out[r] = acc;
+}
+__global__ void emi_trsv_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 // error plumbing of the host functions below: they have `std::string* err` in scope and return an EMI_* status
 #define KKT_HIP(call)                                                                      \
     do {                                                                                   \
@@ -527,13 +570,56 @@ int cholesky(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, rocb
     return own ? chol_blocked(w, stream, n, A, hinfo, err) : potrf_checked(w, stream, n, A, hinfo, err);
 }
 
+
+// inverses of the diagonal TRSV_NB blocks of the factor L (n x n, lda == n) -> w->Linv; call after a successful Cholesky
+int blk_invert(KktWorkspace* w, hipStream_t stream, rocblas_int n, const double* L, std::string* err) {
+    w->linv_n = 0;
+    if (!g_tune.block_trsv.load() || n < 2 * TRSV_NB) return EMI_OK;
+    const int nblk = (n + TRSV_NB - 1) / TRSV_NB, full = n / TRSV_NB, tail = n - full * TRSV_NB;
+    KKT_ENSURE(w->Linv, w->cap_Linv, (size_t)nblk * TRSV_NB * TRSV_NB * sizeof(double));
+    KKT_HIP(hipMemsetAsync(w->Linv, 0, (size_t)nblk * TRSV_NB * TRSV_NB * sizeof(double), stream));
+    KKT_RB(rocblas_dtrtri_strided_batched(w->handle, rocblas_fill_lower, rocblas_diagonal_non_unit, TRSV_NB, L, n,
+                                          (rocblas_stride)TRSV_NB * (n + 1), w->Linv, TRSV_NB, (rocblas_stride)TRSV_NB * TRSV_NB, full));
+    if (tail > 0)
+        KKT_RB(rocblas_dtrtri(w->handle, rocblas_fill_lower, rocblas_diagonal_non_unit, tail, L + (size_t)full * TRSV_NB * (n + 1), n,
+                              w->Linv + (size_t)full * TRSV_NB * TRSV_NB, TRSV_NB));
+    w->linv_n = n;
+    return EMI_OK;
+}
+
+// x <- (L L^T)^-1 x for ONE right-hand side through the block inverses (w->linv_n == n)
+int blk_potrs(KktWorkspace* w, hipStream_t stream, rocblas_int n, const double* L, double* x, std::string* err) {
+    const int nblk = (n + TRSV_NB - 1) / TRSV_NB;
+    const double one = 1.0, mone = -1.0;
+    KKT_ENSURE(w->trsv_tmp, w->cap_trsv_tmp, (size_t)TRSV_NB * sizeof(double));
+    for (int j = 0; j < nblk; ++j) {            // forward: L y = b
+        const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, (int)n - j0), rest = (int)n - j0 - bs;
+        hipLaunchKernelGGL(emi_trsv_diag_kernel, dim3((bs + 63) / 64), dim3(64), 0, stream, (const double*)w->Linv + (size_t)j * TRSV_NB * TRSV_NB,
+                           bs, 0, x + j0, w->trsv_tmp);
+        hipLaunchKernelGGL(emi_trsv_copy_kernel, dim3((bs + 255) / 256), dim3(256), 0, stream, (const double*)w->trsv_tmp, x + j0, bs);
+        if (rest > 0)           // b_rest -= L[rest rows, block j] y_j
+            KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_none, rest, bs, &mone, L + (size_t)j0 * n + j0 + bs, n, x + j0, 1, &one,
+                                 x + j0 + bs, 1));
+    }
+    for (int j = nblk - 1; j >= 0; --j) {       // backward: L^T x = y
+        const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, (int)n - j0);
+        hipLaunchKernelGGL(emi_trsv_diag_kernel, dim3((bs + 63) / 64), dim3(64), 0, stream, (const double*)w->Linv + (size_t)j * TRSV_NB * TRSV_NB,
+                           bs, 1, x + j0, w->trsv_tmp);
+        hipLaunchKernelGGL(emi_trsv_copy_kernel, dim3((bs + 255) / 256), dim3(256), 0, stream, (const double*)w->trsv_tmp, x + j0, bs);
+        if (j0 > 0)             // y_(0 .. j0) -= L[block row j, 0 .. j0)^T x_j
+            KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_transpose, bs, j0, &mone, L + j0, n, x + j0, 1, &one, x, 1));
+    }
+    KKT_HIP(hipGetLastError());
+    return EMI_OK;
+}
+
 }  // namespace
 
 void kkt_destroy(KktWorkspace* w) {
     if (!w) return;
     if (w->handle) (void)rocblas_destroy_handle(w->handle);
     void* bufs[] = {w->K, w->ipiv, w->info, w->Q, w->J, w->rhs, w->fixed, w->S, w->Pinv, w->G, w->Rk, w->Doff, w->W, w->gemm_ptrs, w->T,
-                    w->Cb, w->flag, w->chol_blk, w->chol_copy, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
+                    w->Cb, w->flag, w->chol_blk, w->chol_copy, w->Linv, w->trsv_tmp, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete w;
@@ -547,6 +633,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
     KktWorkspace* w = *pw;
     w->factored = false;
     w->lr_active = false;
+    w->linv_n = 0;
     if (!w->handle) {
         KKT_RB(rocblas_create_handle(&w->handle));
         // split-K kernels that accumulate with atomics make the factorisation, and with it the iteration path of
@@ -678,6 +765,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
                         (int)hinfo, dc_schur, dw_done, M);
         }
         if (hinfo == 0 && hflag == 0) {
+            if (int st = blk_invert(w, stream, (rocblas_int)md, w->S, err)) return st;
             if (attempt == first_attempt) ++w->reg_hits; else { w->reg_level = attempt; w->reg_hits = 0; }
             *info = 0;
             w->factored = true;
@@ -763,7 +851,8 @@ static int solve_dev(KktWorkspace* w, hipStream_t stream, int nz, double* X, int
                            (size_t)md, M, ns, nv);
         KKT_HIP(hipGetLastError());
         // lambda = S^-1 Cb
-        KKT_RB(rocsolver_dpotrs(w->handle, rocblas_fill_lower, md, nrhs, w->S, md, w->Cb, md));
+        if (nrhs == 1 && w->linv_n == md) { if (int st = blk_potrs(w, stream, md, w->S, w->Cb, err)) return st; }
+        else KKT_RB(rocsolver_dpotrs(w->handle, rocblas_fill_lower, md, nrhs, w->S, md, w->Cb, md));
         // y = a - J^T lambda  (in place in the primal part of X), then x = P y
         KKT_RB(rocblas_dgemm_strided_batched(w->handle, rocblas_operation_none, rocblas_operation_none, M, ns, M, &mone, w->Doff,
                                              M, 0, w->Cb, M, (rocblas_stride)md, &one, X, M, (rocblas_stride)N, nrhs));

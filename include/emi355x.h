@@ -318,7 +318,8 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * XCD first in its share of the one-launch grid (1), interleaved with the node workgroups (0), interleaved
  * at value / 100 times the even MFMA density with the node workgroups at the tail (>= 100), or -1 (default)
  * by batch size: first for small batches (fewer than 128 tiles).
- * "kkt_*": process-wide switches of emi_kkt_factor ("kkt_primal_levels" 1 (default): primal regularisation levels behind the
+ * "kkt_*": process-wide switches of emi_kkt_factor ("kkt_block_trsv" 1 (default): single right-hand sides through the
+ * library's block-inverse triangular solves instead of rocBLAS trsv; "kkt_primal_levels" 1 (default): primal regularisation levels behind the
  * dual ones before the LU fallback; "kkt_sticky_reg" 1 (default):
  * the Schur path starts at the dual regularisation level that worked last on this
  * mesh; "kkt_debug", "kkt_cholesky", "kkt_chol_panel", "kkt_batched_max_nodes",

@@ -32,7 +32,7 @@ def dense_kkt(D, Qblk, Jblk, fixed, dc, M, ns, nv):
 
 
 @pytest.mark.parametrize("method", [1, 0])       # 1: Schur complement + Cholesky, 0: LU of the full matrix
-@pytest.mark.parametrize("M,model", [(9, 0), (33, 1), (64, 1), (200, 1)])
+@pytest.mark.parametrize("M,model", [(9, 0), (33, 1), (64, 1), (200, 1), (256, 1)])
 def test_kkt_factor_solve_matches_numpy(built, M, model, method):
     import etol_amd as E
     from etol_amd import workloads as W
@@ -78,6 +78,49 @@ def test_kkt_factor_solve_matches_numpy(built, M, model, method):
         res = K @ sol - ref_rhs
         assert np.abs(res).max() < 1e-10 * (np.abs(K).max() * np.abs(sol).max() + 1)
         assert np.abs(sol - ref).max() < 1e-7 * (np.abs(ref).max() + 1)
+
+
+@pytest.mark.parametrize("M", [171, 200, 256, 300])
+def test_block_inverse_triangular_solves_match_rocblas_trsv(built, M):
+    """Single right-hand sides go through the library's own block-inverse triangular solves once the Schur complement has
+    1024 rows or more (emi_trsv_fwd / bwd kernels: 256-row blocks, diagonal blocks inverted once per factorisation, a partial
+    last block at 171 / 200 / 300 nodes); "kkt_block_trsv" 0 takes rocsolver_dpotrs (rocBLAS trsv).  Same solutions to
+    rounding, both with a small backward error in the numpy matrix."""
+    import etol_amd as E
+    from etol_amd import workloads as W
+    ns, nv, nh = 6, 8, 36
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 4.0)
+    ev.set_model(1, W.QUAD_PARAMS)
+    ev.set_batch(1)
+    rng = np.random.default_rng(1000 + M)
+    Qblk = np.zeros((nh, M))
+    for k in range(M):
+        A = rng.standard_normal((nv, nv))
+        Qk = A @ A.T + nv * np.eye(nv)
+        for v in range(nv):
+            for q in range(v + 1):
+                Qblk[v * (v + 1) // 2 + q, k] = Qk[v, q]
+    Jblk = rng.standard_normal((ns * nv, M))
+    for i in range(ns):
+        Jblk[i * nv + i] += np.diag(ev.D)
+    fixed = np.zeros(nv * M, dtype=np.uint8)
+    fixed[np.arange(ns) * M] = 1
+    K = dense_kkt(ev.D, Qblk, Jblk, fixed, 1e-9, M, ns, nv)
+    rhs = rng.standard_normal((3, (nv + ns) * M))
+    sols = {}
+    for mode in (1, 0):
+        ev.set_option("kkt_block_trsv", mode)
+        assert ev.kkt_factor(Qblk, Jblk, fixed, 1e-9) == 0
+        sols[mode] = np.array([ev.kkt_solve(b) for b in rhs])           # one right-hand side per call
+        for b, x in zip(rhs, sols[mode]):
+            b = b.copy()
+            b[np.nonzero(fixed)[0]] = 0
+            assert np.abs(K @ x - b).max() < 1e-10 * (np.abs(K).max() * np.abs(x).max() + 1), mode
+        again = np.array([ev.kkt_solve(b) for b in rhs])
+        assert np.array_equal(again, sols[mode])                        # fixed summation order: bitwise reproducible
+    ev.set_option("kkt_block_trsv", 1)
+    assert np.abs(sols[1] - sols[0]).max() < 1e-9 * (np.abs(sols[0]).max() + 1)
 
 
 def test_schur_method_falls_back_to_lu_for_indefinite_blocks(built):
