@@ -122,7 +122,7 @@ def roofline_of(m, def_name, key, n_obs, B, M, ns, ms_per_step):
     node_name = "emi_nodes_kernel"
     peak_tf = FP32_MFMA_PEAK_TF if c5 else FP64_MFMA_PEAK_TF
     dom_s = m["dominant_ms"] * 1e-3
-    one_launch = "emi_pass_f64_kernel" in def_name
+    one_launch = "emi_pass_f64_kernel" in def_name              # (the fp32 one-launch pass is reported against the MFMA roof, below)
     kname = node_name if m["dominant"] == "node" else def_name.split("<")[0].split(" ")[0]
     traffic, src = load_pmc_traffic(kname, B, M)
     if m["dominant"] == "node" or one_launch:
@@ -183,7 +183,7 @@ def measure(ev, dX, dU, outs, steps, warmup, barrier, torch):
     # around the whole timed region (emi_timer_start / emi_timer_stop), not from a bracket per pass -- two event records
     # per pass cost ~8 us of a 44 us pass at 128 instances.  (The span includes the gaps between consecutive launches,
     # 2-3 us each: it overstates the kernel's duration a little, never understates it.)
-    one_launch = "emi_pass_f64_kernel" in ev.last_defect_kernel
+    one_launch = "emi_pass_f" in ev.last_defect_kernel          # emi_pass_f64_kernel / emi_pass_f32_kernel
     ev.profile(0 if one_launch else level)
     barrier()
     torch.cuda.synchronize()

@@ -90,6 +90,9 @@ struct emi_ctx_s {
     bool delay_dirty = true;    // W must be rebuilt (mesh or delays changed)
     DevBuf d_W;                 // [max(xh - 1, uh)][M][M]
     DevBuf d_uext;              // [B][nc][M]: the caller's controls, then the delayed values
+    int f32_one_launch = 0;     // "f32_one_launch": fp32 contexts take the one-launch pass (emi_pass_f32_kernel) by themselves where it applies.
+                                // Off: measured at config 5 (256 instances, 4096 nodes) 1.12 - 1.26 ms per pass in every block order against
+                                // 1.04 ms for the node kernel followed by the MFMA kernel (profiles/r03_notes.md section 6)
     int slice = 0;              // "slice" option: > 0: batches above 2 * slice instances are evaluated in pieces of this many; 0: one launch (see emi_eval_dev)
     int slice_first = 0;        // first instance of the slice emi_eval_dev is working on (per-instance tables are offset by it)
     int sym_ksplit = 0;         // "sym_ksplit" option: K slices per tile of the state-split ring kernel (0: by batch size)
@@ -957,6 +960,28 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         }
         return EMI_OK;
     }
+    if (c->f32 && nodes && defect && jac && !c->rtc && c->allow_fused && (c->overlap_mode == 3 || (c->overlap_mode == 0 && c->f32_one_launch)) &&
+        emi::pass_f32_supported(c->model, c->B * c->ns, c->M, c->B)) {
+        // fp32 contexts (config 5): the pass as ONE launch -- MFMA-role and node-role workgroups in one grid, the defect rows zeroed
+        // here and completed by float atomics from both roles (emi_defect_f32.hip), COST finished in-kernel by ticket
+        emi::NodeArgs<float> na;
+        fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
+        const size_t rowb = (size_t)c->M * 4;
+        HIP_TRY(c, hipMemset2DAsync(dRES, (size_t)nres_of(c) * rowb, 0, (size_t)c->ns * rowb, c->B, c->stream));
+        if (c->d_ticket.bytes < (size_t)c->B * 4) {
+            int est = ensure(c, c->d_ticket, (size_t)c->B * 4);
+            if (est) return est;
+            HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, (size_t)c->B * 4, c->stream));
+        }
+        na.cost_ticket = (unsigned*)c->d_ticket.p;
+        emi::DefectArgsF32 da{(const float*)dX, (const float*)c->d_D.p, (float*)dRES, c->B * c->ns, c->M, c->ns, nres_of(c)};
+        if (plv) HIP_TRY(c, hipEventRecord(pe->k[0], c->stream));
+        HIP_TRY(c, emi::launch_pass_f32(c->model, da, na, c->pass_order >= 0 ? c->pass_order : 0, c->stream));
+        if (plv) HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
+        if (pe) { pe->level = -1; pe->fused = true; }
+        c->last_defect_kernel = "emi_pass_f32_kernel (MFMA + node roles, one launch)";
+        return EMI_OK;
+    }
     if (c->f32 && nodes && defect && jac && !c->rtc && c->allow_fused && c->overlap_mode == 2 && emi::defect_f32_mfma_supported(c->M)) {
         // fp32 contexts (config 5), only when asked for ("overlap_mode" 2): the f32 MFMA defect kernel ACCUMULATES onto
         // -h f, so a values-only node kernel writes -h f first and the MFMA kernel follows it on the context's stream, while
@@ -1257,6 +1282,7 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         return EMI_OK;
     }
     if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }
+    if (strcmp(name, "f32_one_launch") == 0) { c->f32_one_launch = value != 0; return EMI_OK; }
     if (strcmp(name, "slice") == 0) {
         if (value < 0 || (value > 0 && value % 16 != 0)) return fail(c, EMI_ERR_ARG, "slice must be 0 (never) or a multiple of 16 instances");
         c->slice = value;

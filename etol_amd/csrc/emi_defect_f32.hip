@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 
 #include "emi_kernels.hpp"
+#include "emi_models.hpp"
+#include "emi_node_kernels.hpp"
 
 namespace emi {
 
@@ -27,19 +29,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef EMI_F32_WGS_PER_CU
 #define EMI_F32_WGS_PER_CU 2
 #endif
-__global__ __launch_bounds__(256, EMI_F32_WGS_PER_CU) void emi_defect_f32_mfma_kernel(DefectArgsF32 a) {
+// bid: tile id in XCD-local runs (an XCD gets a contiguous range, i.e. whole D column panels); nwg: tiles of the launch.
+// ATOMIC: the epilogue adds its sums with no-return float atomics (the one-launch pass below) instead of a plain read-modify-write.
+template <bool ATOMIC>
+__device__ __forceinline__ void emi_defect_f32_body(const DefectArgsF32& a, const int bid, const int nwg) {
     constexpr int TM = 64, TN = 128, BK = 32, LDK = BK + 1;
     __shared__ float As[2][TM][LDK];
     __shared__ float Bs[2][TN][LDK];
 
     const int R = a.R, M = a.M;
     const int ntiles = M / TN;
-    int bid = blockIdx.x;
-    {   // XCD-aware bijective remap: workgroups that share a D column panel share blockIdx % 8
-        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    }
-    const int mtiles = gridDim.x / ntiles;
+    const int mtiles = nwg / ntiles;
     const int ntile = bid / mtiles, mtile = bid - ntile * mtiles;
     const int m0 = mtile * TM, n0 = ntile * TN;
 
@@ -142,10 +142,67 @@ __global__ __launch_bounds__(256, EMI_F32_WGS_PER_CU) void emi_defect_f32_mfma_k
             if (r < R) {
                 const int inst = r / a.ns, st = r - inst * a.ns;
                 float* o = a.RES + ((size_t)inst * a.nres + st) * M + n;
-                *o += acc[c][i];
+                if constexpr (ATOMIC) unsafeAtomicAdd(o, acc[c][i]);
+                else *o += acc[c][i];
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256, EMI_F32_WGS_PER_CU) void emi_defect_f32_mfma_kernel(DefectArgsF32 a) {
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: workgroups that share a D column panel share blockIdx % 8
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    emi_defect_f32_body<false>(a, bid, (int)gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fp32 evaluation pass (config 5) as ONE launch, like emi_pass_f64_kernel: MFMA-role workgroups (the body above) and
+// node-role workgroups (emi_nodes_body) dealt per XCD by pass_role_of, COST finished in-kernel by ticket.  The two roles meet in the
+// defect rows: the caller zeroes them, the node role ADDS -h f and the MFMA role ADDS D.X, both with no-return float atomics
+// (global_atomic_add_f32: executed at the memory side, 50 MB of them per role at 256 instances against a ~1.3 TB/s rate).  Two
+// contributions per element: 0 + a + b = 0 + b + a exactly, so the rows are bitwise what the sequential pair of launches leaves
+// (-h f stored, then D.X added to it), whichever role gets to an element first.
+struct PassArgsF32 {
+    DefectArgsF32 d;
+    NodeArgs<float> n;
+    int nm8, nn8, nbx, order;
+};
+template <class Model>
+__global__ __launch_bounds__(256, 3) void emi_pass_f32_kernel(PassArgsF32 a) {      // 3 workgroups per CU (50.7 KB of LDS each): <= 168 registers
+    const int g = blockIdx.x, xcd = g & 7, j = g >> 3;
+    const PassRole role = pass_role_of(j, a.nm8, a.nn8, a.order);
+    if (role.mfma) {
+        __builtin_amdgcn_s_setprio(3);
+        emi_defect_f32_body<true>(a.d, xcd * a.nm8 + role.index, 8 * a.nm8);
+    } else {
+        const int nid = xcd * a.nn8 + role.index;
+        emi_nodes_body<float, Model, 2, true, true, 0, true>(a.n, nid % a.nbx, nid / a.nbx, a.nbx);
+    }
+}
+
+bool pass_f32_supported(int model, int R, int M, int B) {
+    if (model != EMI_MODEL_FIXEDWING12 || M < 128 || M % 128 != 0) return false;
+    const int nm = ((R + 63) / 64) * (M / 128), nn = ((M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS)) * B;
+    return nm % 8 == 0 && nn % 8 == 0 && R % 64 == 0;
+}
+
+hipError_t launch_pass_f32(int model, const DefectArgsF32& d, const NodeArgs<float>& n, int order, hipStream_t s) {
+    if (model != EMI_MODEL_FIXEDWING12) return hipErrorInvalidValue;
+    PassArgsF32 a;
+    a.d = d;
+    a.n = n;
+    const int nm = ((d.R + 63) / 64) * (d.M / 128);
+    a.nbx = (n.M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS);
+    const int nn = a.nbx * n.B;
+    if (nm % 8 || nn % 8) return hipErrorInvalidConfiguration;
+    a.nm8 = nm / 8;
+    a.nn8 = nn / 8;
+    a.order = order;
+    hipLaunchKernelGGL((emi_pass_f32_kernel<FixedWing12<float>>), dim3(nm + nn), dim3(256), 0, s, a);
+    return hipGetLastError();
 }
 
 bool defect_f32_mfma_supported(int M) { return M >= 128 && M % 128 == 0; }

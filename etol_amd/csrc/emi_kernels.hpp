@@ -25,6 +25,9 @@ hipError_t launch_defect_small_f64(const DefectArgs& a, hipStream_t s);
 hipError_t launch_defect_f32(const DefectArgsF32& a, hipStream_t s);
 bool defect_f32_mfma_supported(int M);
 hipError_t launch_defect_f32_mfma(const DefectArgsF32& a, hipStream_t s);
+// the fp32 pass as one launch (MFMA role + node role, defect rows by float atomics onto zeroed rows): emi_defect_f32.hip
+bool pass_f32_supported(int model, int R, int M, int B);
+hipError_t launch_pass_f32(int model, const DefectArgsF32& d, const NodeArgs<float>& n, int order, hipStream_t s);
 hipError_t defect_f64_set_attr();
 template <typename T>
 hipError_t launch_cost_finish(const T* part, T* cost, int B, int nchunks, T scale, hipStream_t s);

@@ -111,7 +111,10 @@ template <typename T> EMI_DEV T wave_sum(T v) {
 // ---------------------------------------------------------------------------
 // bx / nbx: node chunk of this workgroup and chunks per instance; b: instance.  (A device function so that the
 // one-launch pass kernel of emi_symdefect_kernels.hpp can give some of its workgroups this role.)
-template <typename T, class Model, int VEC, bool JAC, bool DEFROWS, int ST>
+// DEFATOMIC (with DEFROWS): -h f is ADDED to the defect rows with no-return float atomics instead of stored -- the one-launch fp32 pass
+// (emi_defect_f32.hip), where the MFMA role adds D.X to the same, zeroed, rows in no particular order: two contributions per element,
+// and 0 + a + b = 0 + b + a exactly, so the result does not depend on which role comes first.
+template <typename T, class Model, int VEC, bool JAC, bool DEFROWS, int ST, bool DEFATOMIC = false>
 EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, const int nbx) {
     constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
     const int M = a.M;
@@ -152,7 +155,12 @@ EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, con
                 }
                 lsum += wk[e] * Model::cost(a.P, ze, tk[e]);
             }
-            if (DEFROWS) {
+            if constexpr (DEFROWS && DEFATOMIC) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) unsafeAtomicAdd(Rb + (size_t)i * M + k0 + e, fo[i][e]);
+            } else if (DEFROWS) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) stR((size_t)i * M + k0, fo[i]);
             }

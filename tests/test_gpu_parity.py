@@ -284,6 +284,53 @@ def test_f32_context_fixedwing(built):
     assert np.array_equal(dRES.cpu().numpy().astype(np.float64), RES)
 
 
+@pytest.mark.parametrize("M,B", [(512, 64), (256, 128), (4096, 16)])
+def test_f32_pass_as_one_launch_matches_the_sequential_pair_and_the_oracle(built, M, B):
+    """Config-5 arithmetic, the pass as ONE launch (emi_pass_f32_kernel: MFMA-role and node-role workgroups in one grid; the
+    defect rows are zeroed and both roles ADD their share with float atomics).  Two contributions per element, 0 + a + b =
+    0 + b + a exactly: the rows must equal those of the node kernel followed by the MFMA kernel bit for bit (signed zeros
+    aside), VALS and COST too; and all of it the oracle's values to f32 accuracy."""
+    import torch
+    import etol_amd as E
+    from etol_amd import workloads as W
+    gen = min(B, 16)
+    X, U = W.fixedwing_batch(4, gen, M)
+    X, U = np.tile(X, (B // gen, 1, 1)), np.tile(U, (B // gen, 1, 1))
+    X = X.astype(np.float32).astype(np.float64) + 0.0
+    U = U.astype(np.float32).astype(np.float64)
+    ev = E.Evaluator(0, f32=True)
+    ev.set_mesh(M, 0.0, 20.0)
+    ev.set_model(E.MODEL_FIXEDWING12, W.FW_PARAMS)
+    ev.set_batch(B)
+    dX, dU = torch.from_numpy(X.astype(np.float32)).cuda(), torch.from_numpy(U.astype(np.float32)).cuda()
+    res = {}
+    for mode, name in ((0, "default, one launch allowed"), (1, "sequential"), (3, "one launch")):
+        ev.set_option("f32_one_launch", 1 if mode == 0 else 0)          # (by itself the library keeps the sequential pair: it is faster)
+        ev.set_option("overlap_mode", mode)
+        outs = ev.alloc_outputs()
+        for t in outs:
+            t.fill_(float("nan"))
+        torch.cuda.synchronize()
+        for _ in range(2):                       # twice on the same buffers: the rows are zeroed per pass, the ticket resets itself
+            ev.eval_dev(dX, dU, *outs)
+        ev.synchronize()
+        torch.cuda.synchronize()
+        assert ("emi_pass_f32_kernel" in ev.last_defect_kernel) == (mode != 1), (name, ev.last_defect_kernel)
+        res[mode] = [o.cpu().numpy().astype(np.float64) for o in outs]
+        assert not any(np.isnan(a).any() for a in res[mode])
+    for q in range(3):
+        assert np.array_equal(res[3][q], res[1][q]), q
+        assert np.array_equal(res[0][q], res[3][q]), q
+    sub = slice(0, 4)
+    rRES, rVALS, rCOST = O.evaluate(E.MODEL_FIXEDWING12, W.FW_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, 20.0, X[sub], U[sub])
+    scale = np.einsum("kj,bij->bik", np.abs(ev.D), np.abs(X[sub])) + np.abs(rRES) + 1.0
+    assert (np.abs(res[3][0][sub] - rRES) / scale).max() < (2e-6 if M <= 512 else 5e-6)
+    for e in range(rVALS.shape[1]):
+        assert np.abs(res[3][1][sub][:, e] - rVALS[:, e]).max() / (np.abs(rVALS[:, e]).max() + 1.0) < 2e-6
+    assert np.abs(res[3][2][sub] - rCOST).max() / np.abs(rCOST).max() < 2e-6
+    ev.close()
+
+
 def test_device_pointer_form_matches_host_form(built):
     import etol_amd as E
     import torch
