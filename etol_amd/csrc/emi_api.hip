@@ -90,6 +90,7 @@ struct emi_ctx_s {
     bool delay_dirty = true;    // W must be rebuilt (mesh or delays changed)
     DevBuf d_W;                 // [max(xh - 1, uh)][M][M]
     DevBuf d_uext;              // [B][nc][M]: the caller's controls, then the delayed values
+    int f32_ring = 1;           // "f32_ring": the fp32 MFMA defect kernel in its LDS-DMA ring form (0: register-staged operands, the round-2 form)
     int f32_one_launch = 0;     // "f32_one_launch": fp32 contexts take the one-launch pass (emi_pass_f32_kernel) by themselves where it applies.
                                 // Off: measured at config 5 (256 instances, 4096 nodes) 1.12 - 1.26 ms per pass in every block order against
                                 // 1.04 ms for the node kernel followed by the MFMA kernel (profiles/r03_notes.md section 6)
@@ -1038,7 +1039,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         if (c->f32) {
             emi::DefectArgsF32 a{(const float*)dX, (const float*)c->d_D.p, (float*)dRES, c->B * c->ns,
                                  c->M, c->ns, nres_of(c)};
-            if (emi::defect_f32_mfma_supported(c->M) && c->allow_fused) { HIP_TRY(c, emi::launch_defect_f32_mfma(a, c->stream)); c->last_defect_kernel = "emi_defect_f32_mfma_kernel"; }
+            if (emi::defect_f32_mfma_supported(c->M) && c->allow_fused) { HIP_TRY(c, emi::launch_defect_f32_mfma(a, c->stream, c->f32_ring)); c->last_defect_kernel = c->f32_ring ? "emi_defect_f32_ring_kernel" : "emi_defect_f32_mfma_kernel"; }
             else { HIP_TRY(c, emi::launch_defect_f32(a, c->stream)); c->last_defect_kernel = "emi_defect_f32_kernel"; }
         } else {
             emi::DefectArgs a{(const double*)dX, (const double*)c->d_D.p, (double*)dRES, c->B * c->ns,
@@ -1282,6 +1283,7 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         return EMI_OK;
     }
     if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }
+    if (strcmp(name, "f32_ring") == 0) { c->f32_ring = value != 0; return EMI_OK; }
     if (strcmp(name, "f32_one_launch") == 0) { c->f32_one_launch = value != 0; return EMI_OK; }
     if (strcmp(name, "slice") == 0) {
         if (value < 0 || (value > 0 && value % 16 != 0)) return fail(c, EMI_ERR_ARG, "slice must be 0 (never) or a multiple of 16 instances");

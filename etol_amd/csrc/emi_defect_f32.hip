@@ -105,25 +105,39 @@ __device__ __forceinline__ void emi_defect_f32_body(const DefectArgsF32& a, cons
         // Fragments one group (two k-steps, four MFMAs) ahead of the matrix pipe, in registers: read just in time, every
         // group waited for its LDS reads with the pipe idle (the ISA had s_waitcnt lgkmcnt(0) in front of two of every four
         // MFMAs).  sched_barrier pins the reads ahead of the MFMAs (the scheduler sinks them otherwise).
+        // The shifted A operands (x - s for the wave's two column tiles) are formed one group AHEAD as well, behind the MFMAs of the
+        // group before: a v_sub directly in front of each MFMA holds the matrix pipe for its result (no-shift ablation of the ring
+        // form: 0.910 -> 0.8245 ms, profiles/r03_notes.md section 6).
         struct Frag { float a[2], b0[2], b1[2]; };
+        struct Shifted { float s0[2], s1[2]; };
         auto read_frag = [&](Frag& f, int g) {
             f.a[0] = Ar[4 * g];  f.a[1] = Ar[4 * g + 2];
             f.b0[0] = B0[4 * g]; f.b0[1] = B0[4 * g + 2];
             f.b1[0] = B1[4 * g]; f.b1[1] = B1[4 * g + 2];
         };
+        auto shift_frag = [&](Shifted& h, const Frag& f) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { h.s0[q] = f.a[q] - shift[0]; h.s1[q] = f.a[q] - shift[1]; }
+        };
         Frag fr[2];
+        Shifted sh[2];
         read_frag(fr[0], 0);
+        if (BK / 4 > 1) read_frag(fr[1], 1);
+        shift_frag(sh[0], fr[0]);
 #pragma unroll
         for (int g = 0; g < BK / 4; ++g) {
-            if (g + 1 < BK / 4) read_frag(fr[(g + 1) & 1], g + 1);
             __builtin_amdgcn_sched_barrier(0);
             const Frag& f = fr[g & 1];
+            const Shifted& h = sh[g & 1];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q] - shift[0], f.b0[q], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q] - shift[1], f.b1[q], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(h.s0[q], f.b0[q], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(h.s1[q], f.b1[q], acc[1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < BK / 4) shift_frag(sh[(g + 1) & 1], fr[(g + 1) & 1]);      // operands of the next group, while this group's MFMAs run
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < BK / 4) read_frag(fr[g & 1], g + 2);                       // fragments two groups ahead into the set just used
         }
         if (kt + 1 < nkt) {
             lstore(cur ^ 1);
@@ -205,12 +219,198 @@ hipError_t launch_pass_f32(int model, const DefectArgsF32& d, const NodeArgs<flo
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Ring form of the kernel above (round 3): the same tile (64 rows x 128 columns, K tile 32, 4 waves as 2 x 2, shifted-difference
+// contraction), but the operands go global -> LDS by LDS-DMA into a 3-stage ring two K tiles ahead, issued from inline assembly with
+// counted vmcnt waits, and the K loop is software-pipelined: the fragment reads of tile kt+1 and the DMA of tile kt+3 are dealt
+// into the gaps between the MFMAs of tile kt -- the structure that took the f64 kernel from 0.172 to 0.133 ms
+// (emi_symdefect_kernels.hpp, profiles/r02_notes.md section 9).  The register-staged form spends ~450 of every 2048 cycles of a K tile
+// between two tiles' MFMAs (LDS stores, barrier, first fragment reads; 75 % of the matrix pipe busy whatever the occupancy:
+// profiles/r03_notes.md section 6).
+//   * A stage is 192 rows of 128 B (64 of X, 128 of D), 24 DMA wave instructions of 1 KB, six per wave.  A DMA instruction writes
+//     8 rows linearly, so rows cannot be padded: 16-byte chunk c of row r sits at chunk position c ^ ((r >> 1) & 7) (applied to the
+//     per-lane SOURCE address and to the fragment read address).
+//   * The MFMA sums over k, so which k a lane holds is free as long as A and B agree: lane half lk takes k = 4c + 2lk, 4c + 2lk + 1
+//     of chunk c in two consecutive MFMAs -- one ds_read_b64 per operand row and chunk (2-way bank conflict: 32 lanes x 8 B of one
+//     half cannot tile a 256-byte bank row; 4 LDS cycles, what the ds_read_b128 alternative costs too).
+typedef __attribute__((address_space(3))) void* emi_lds_ptr32_t;
+__device__ __forceinline__ constexpr int f32ring_swz(int r) { return (r >> 1) & 7; }
+
+__global__ __launch_bounds__(256, 2) void emi_defect_f32_ring_kernel(DefectArgsF32 a) {
+    constexpr int TM = 64, TN = 128, BK = 32, NST = 3, LOOK = NST - 1;
+    constexpr int ROWS = TM + TN;                 // 192 rows of BK floats
+    constexpr int STAGE = ROWS * BK;              // floats per stage (24 KB)
+    constexpr int L = ROWS * 8 / 64 / 4;          // DMA instructions per wave and stage: 192 rows x 8 chunks / 64 lanes / 4 waves = 6
+    extern __shared__ __attribute__((aligned(16))) float smf[];      // [NST][STAGE]
+
+    const int R = a.R, M = a.M;
+    const int ntiles = M / TN;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: workgroups that share a D column panel share blockIdx % 8
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+        bid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    }
+    const int mtiles = gridDim.x / ntiles;
+    const int ntile = bid / mtiles, mtile = bid - ntile * mtiles;
+    const int m0 = mtile * TM, n0 = ntile * TN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int l32 = lane & 31, lk = lane >> 5;
+
+    const int row = m0 + wr * 32 + l32;
+    float shift[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) shift[c] = row < R ? a.X[(size_t)row * M + n0 + wc * 64 + c * 32 + 16] : 0.f;
+
+    // DMA addressing: instruction t of wave wid moves stage rows 8 (wid + 4t) .. +7, all of X or all of D: wave-uniform 64-bit base,
+    // constant per-lane 32-bit offset, +128 bytes per K tile
+    unsigned voff[L];
+    unsigned long long gnext[L];
+#pragma unroll
+    for (int t = 0; t < L; ++t) {
+        const int r0 = (wid + 4 * t) * 8;                 // wave-uniform first stage row of the instruction
+        const int r = r0 + (lane >> 3), p = lane & 7;     // stage row, chunk position
+        const int c = p ^ f32ring_swz(r);
+        if (r0 < TM) {
+            int gr = m0 + r;
+            gr = gr < R ? gr : R - 1;                     // rows past the batch are never written out
+            voff[t] = (unsigned)(((size_t)gr * M + 4 * c) * sizeof(float));
+            gnext[t] = (unsigned long long)a.X;
+        } else {
+            voff[t] = (unsigned)(((size_t)(n0 + r - TM) * M + 4 * c) * sizeof(float));
+            gnext[t] = (unsigned long long)a.D;
+        }
+    }
+    const unsigned lds0 = (unsigned)(unsigned long)(emi_lds_ptr32_t)smf;
+    const int nkt = M / BK;
+    unsigned st_dma = 0, st_rd = 0;
+    int nd = 0;
+    auto issue_one = [&](int t) {
+        const unsigned dst = lds0 + st_dma + (unsigned)(wid + 4 * t) * 1024u;   // wave-uniform
+        asm volatile("s_mov_b32 m0, %2\n\t" EMI_M0_NOP "global_load_lds_dwordx4 %0, %1" ::"v"(voff[t]), "s"(gnext[t]), "s"(dst) : "memory", "m0");
+        gnext[t] += (unsigned long long)(BK * sizeof(float));
+        if (t == L - 1) {
+            st_dma = st_dma == (unsigned)((NST - 1) * STAGE * 4) ? 0u : st_dma + (unsigned)(STAGE * 4);
+            ++nd;
+        }
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int t = 0; t < L; ++t) issue_one(t);
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+#pragma unroll
+    for (int t = 0; t < LOOK; ++t)
+        if (t < nkt) issue();
+
+    // fragment addresses (floats within a stage): the lane's A row and its two B rows; chunk c of row r at ((c ^ swz(r)) * 4 + 2 lk)
+    const int ra = wr * 32 + l32, rb0 = TM + wc * 64 + l32, rb1 = rb0 + 32;
+    const int sa = f32ring_swz(ra), sb0 = f32ring_swz(rb0 - TM), sb1 = f32ring_swz(rb1 - TM);
+    struct Frag { float2 a[8], b0[8], b1[8], s0[8], s1[8]; };      // s0 / s1: a - shift of the wave's two column tiles
+    constexpr int NR = 24, NM = 32;                       // fragment reads / MFMAs per wave and K tile
+    auto read_one = [&](Frag& f, const float* S, int r) {
+        const int c = r / 3, w = r % 3;
+        if (w == 0) f.a[c] = *reinterpret_cast<const float2*>(S + ra * BK + ((c ^ sa) << 2) + 2 * lk);
+        else if (w == 1) f.b0[c] = *reinterpret_cast<const float2*>(S + rb0 * BK + ((c ^ sb0) << 2) + 2 * lk);
+        else f.b1[c] = *reinterpret_cast<const float2*>(S + rb1 * BK + ((c ^ sb1) << 2) + 2 * lk);
+    };
+    auto rd_stage = [&]() -> const float* {
+        const float* S = smf + (st_rd >> 2);
+        st_rd = st_rd == (unsigned)((NST - 1) * STAGE * 4) ? 0u : st_rd + (unsigned)(STAGE * 4);
+        return S;
+    };
+    auto mfma_one = [&](const Frag& f, int i) {           // chunk c = i >> 2: k = 4c + 2lk (.x) then 4c + 2lk + 1 (.y), both column tiles
+        const int c = i >> 2, sub = i & 3;
+        if ((sub & 1) == 0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((sub & 2) ? f.s0[c].y : f.s0[c].x, (sub & 2) ? f.b0[c].y : f.b0[c].x, acc[0], 0, 0, 0);
+        else                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((sub & 2) ? f.s1[c].y : f.s1[c].x, (sub & 2) ? f.b1[c].y : f.b1[c].x, acc[1], 0, 0, 0);
+    };
+    // the shifted operands of chunk c, formed six gaps after its A fragment was requested (a v_sub directly in front of an MFMA holds
+    // the matrix pipe for its result: no-shift ablation 0.910 -> 0.8245 ms)
+    auto shift_one = [&](Frag& f, int c) {
+        f.s0[c] = make_float2(f.a[c].x - shift[0], f.a[c].y - shift[0]);
+        f.s1[c] = make_float2(f.a[c].x - shift[1], f.a[c].y - shift[1]);
+    };
+    constexpr int GR = NR;                                // one fragment read per gap in the first 24 gaps, then a DMA instruction in each of 6
+    static_assert(GR + L <= NM, "a gap for every read and every DMA instruction");
+    auto step = [&](const Frag& cur, Frag& nxt, int kt) { // kt + 1 < nkt: MFMAs of tile kt, tile kt+1 made ready
+        if (kt + LOOK < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
+        else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0), visible to the compiler's wait counting
+        asm volatile("s_barrier" ::: "memory");           // tile kt+1 has landed for every wave; the stage of tile kt-1... is free
+        const bool more = nd < nkt;
+        const float* S = rd_stage();
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            mfma_one(cur, i);
+            if (i < GR) read_one(nxt, S, i);
+            else if (i < GR + L) { if (more) issue_one(i - GR); }
+            if (i >= 6 && i < 6 + GR && (i - 6) % 3 == 0) shift_one(nxt, (i - 6) / 3);     // A chunk (i - 6) / 3 was requested six gaps ago
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    Frag f0, f1;
+    if (nkt > LOOK - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
+    else                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (LOOK < nkt) issue();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    {
+        const float* S = rd_stage();
+#pragma unroll
+        for (int r = 0; r < NR; ++r) read_one(f0, S, r);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) shift_one(f0, c);
+    }
+    int kt = 0;                                           // nkt = M / 32 is a multiple of 4
+    for (; kt + 2 < nkt; kt += 2) {
+        step(f0, f1, kt);
+        step(f1, f0, kt + 1);
+    }
+    step(f0, f1, kt);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) mfma_one(f1, i);
+
+    // C/D map of the 32x32 f32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n = n0 + wc * 64 + c * 32 + l32;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = m0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * lk;
+            if (r < R) {
+                const int inst = r / a.ns, st = r - inst * a.ns;
+                float* o = a.RES + ((size_t)inst * a.nres + st) * M + n;
+                *o += acc[c][i];
+            }
+        }
+    }
+}
+
 bool defect_f32_mfma_supported(int M) { return M >= 128 && M % 128 == 0; }
 
-hipError_t launch_defect_f32_mfma(const DefectArgsF32& a, hipStream_t s) {
+hipError_t launch_defect_f32_mfma(const DefectArgsF32& a, hipStream_t s, int ring) {
     const int mtiles = (a.R + 63) / 64, ntiles = a.M / 128;
     dim3 grid(mtiles * ntiles), block(256);
-    hipLaunchKernelGGL(emi_defect_f32_mfma_kernel, grid, block, 0, s, a);
+    if (ring) {
+        const size_t lds = (size_t)3 * (64 + 128) * 32 * sizeof(float);      // 72 KB: two workgroups per CU
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute((const void*)emi_defect_f32_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(emi_defect_f32_ring_kernel, grid, block, lds, s, a);
+    } else {
+        hipLaunchKernelGGL(emi_defect_f32_mfma_kernel, grid, block, 0, s, a);
+    }
     return hipGetLastError();
 }
 

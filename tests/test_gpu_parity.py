@@ -303,6 +303,7 @@ def test_f32_pass_as_one_launch_matches_the_sequential_pair_and_the_oracle(built
     ev.set_model(E.MODEL_FIXEDWING12, W.FW_PARAMS)
     ev.set_batch(B)
     dX, dU = torch.from_numpy(X.astype(np.float32)).cuda(), torch.from_numpy(U.astype(np.float32)).cuda()
+    ev.set_option("f32_ring", 0)            # the one-launch kernel holds the register-staged MFMA body: compare like with like
     res = {}
     for mode, name in ((0, "default, one launch allowed"), (1, "sequential"), (3, "one launch")):
         ev.set_option("f32_one_launch", 1 if mode == 0 else 0)          # (by itself the library keeps the sequential pair: it is faster)
@@ -328,6 +329,24 @@ def test_f32_pass_as_one_launch_matches_the_sequential_pair_and_the_oracle(built
     for e in range(rVALS.shape[1]):
         assert np.abs(res[3][1][sub][:, e] - rVALS[:, e]).max() / (np.abs(rVALS[:, e]).max() + 1.0) < 2e-6
     assert np.abs(res[3][2][sub] - rCOST).max() / np.abs(rCOST).max() < 2e-6
+    # the ring form of the MFMA kernel (LDS-DMA operands, software-pipelined K loop; the default): another pairing of the k
+    # terms, same values to f32 accuracy
+    ev.set_option("f32_ring", 1)
+    ev.set_option("overlap_mode", 0)
+    ev.set_option("f32_one_launch", 0)
+    outs = ev.alloc_outputs()
+    for t in outs:
+        t.fill_(float("nan"))
+    torch.cuda.synchronize()
+    ev.eval_dev(dX, dU, *outs)
+    ev.synchronize()
+    torch.cuda.synchronize()
+    assert "emi_defect_f32_ring_kernel" in ev.last_defect_kernel
+    ring = [o.cpu().numpy().astype(np.float64) for o in outs]
+    assert np.array_equal(ring[1], res[1][1]) and np.array_equal(ring[2], res[1][2])          # node kernel outputs: identical
+    assert (np.abs(ring[0][sub] - rRES) / scale).max() < (2e-6 if M <= 512 else 5e-6)
+    full_scale = np.einsum("kj,bij->bik", np.abs(ev.D), np.abs(X)) + np.abs(res[1][0]) + 1.0
+    assert (np.abs(ring[0] - res[1][0]) / full_scale).max() < 2e-6                            # every instance, against the staged form
     ev.close()
 
 
