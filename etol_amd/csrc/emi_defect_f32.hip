@@ -105,39 +105,25 @@ __device__ __forceinline__ void emi_defect_f32_body(const DefectArgsF32& a, cons
         // Fragments one group (two k-steps, four MFMAs) ahead of the matrix pipe, in registers: read just in time, every
         // group waited for its LDS reads with the pipe idle (the ISA had s_waitcnt lgkmcnt(0) in front of two of every four
         // MFMAs).  sched_barrier pins the reads ahead of the MFMAs (the scheduler sinks them otherwise).
-        // The shifted A operands (x - s for the wave's two column tiles) are formed one group AHEAD as well, behind the MFMAs of the
-        // group before: a v_sub directly in front of each MFMA holds the matrix pipe for its result (no-shift ablation of the ring
-        // form: 0.910 -> 0.8245 ms, profiles/r03_notes.md section 6).
         struct Frag { float a[2], b0[2], b1[2]; };
-        struct Shifted { float s0[2], s1[2]; };
         auto read_frag = [&](Frag& f, int g) {
             f.a[0] = Ar[4 * g];  f.a[1] = Ar[4 * g + 2];
             f.b0[0] = B0[4 * g]; f.b0[1] = B0[4 * g + 2];
             f.b1[0] = B1[4 * g]; f.b1[1] = B1[4 * g + 2];
         };
-        auto shift_frag = [&](Shifted& h, const Frag& f) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { h.s0[q] = f.a[q] - shift[0]; h.s1[q] = f.a[q] - shift[1]; }
-        };
         Frag fr[2];
-        Shifted sh[2];
         read_frag(fr[0], 0);
-        if (BK / 4 > 1) read_frag(fr[1], 1);
-        shift_frag(sh[0], fr[0]);
 #pragma unroll
         for (int g = 0; g < BK / 4; ++g) {
+            if (g + 1 < BK / 4) read_frag(fr[(g + 1) & 1], g + 1);
             __builtin_amdgcn_sched_barrier(0);
             const Frag& f = fr[g & 1];
-            const Shifted& h = sh[g & 1];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(h.s0[q], f.b0[q], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(h.s1[q], f.b1[q], acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q] - shift[0], f.b0[q], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[q] - shift[1], f.b1[q], acc[1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (g + 1 < BK / 4) shift_frag(sh[(g + 1) & 1], fr[(g + 1) & 1]);      // operands of the next group, while this group's MFMAs run
-            __builtin_amdgcn_sched_barrier(0);
-            if (g + 2 < BK / 4) read_frag(fr[g & 1], g + 2);                       // fragments two groups ahead into the set just used
         }
         if (kt + 1 < nkt) {
             lstore(cur ^ 1);
