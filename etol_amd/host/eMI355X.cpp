@@ -584,6 +584,29 @@ NlpProblem make_nlp(const Prob& P, NlpEvaluator* ev) {
     return nlp;
 }
 
+// Variable scales of PSOPT's automatic scaling: the larger magnitude of a variable's two bounds (event bounds of the end nodes
+// included), 1 where it has no finite bound or is pinned at zero.
+std::vector<double> bound_scales(const Prob& P) {
+    const size_t ns = P.nstates, nc = P.ncontrols;
+    std::vector<double> s(ns + nc, 1.0);
+    auto mag = [](double a, double m) { return std::isfinite(a) && std::fabs(a) < 1e19 ? std::max(m, std::fabs(a)) : m; };
+    for (size_t i = 0; i < ns; ++i) {
+        double m = 0;
+        m = mag(P.state_lower[i], m);
+        m = mag(P.state_upper[i], m);
+        if (P.event_lower.size() == 2 * ns && P.event_upper.size() == 2 * ns)
+            for (size_t e : {i, ns + i}) { m = mag(P.event_lower[e], m); m = mag(P.event_upper[e], m); }
+        if (m > 0) s[i] = m;
+    }
+    for (size_t j = 0; j < nc; ++j) {
+        double m = 0;
+        m = mag(P.control_lower[j], m);
+        m = mag(P.control_upper[j], m);
+        if (m > 0) s[ns + j] = m;
+    }
+    return s;
+}
+
 // Nodes of a guess that fall inside a keep-out of the record table are moved radially out of it (ellipse: offset
 // from the centre scaled until the quadratic form reaches 1+margin).  Inside a keep-out the row function is concave
 // with a vanishing gradient at the centre, which is the worst place to start a Newton-type iteration from.
@@ -702,6 +725,8 @@ void eMI355X::solve() {
         const bool dev_kkt = _algorithm.linear_solver == "device" ||
                              (_algorithm.linear_solver == "auto" && kkt_rows > 400);
         nlp.kkt = dev_kkt ? static_cast<mi355x::KktBackend*>(_dev.get()) : nullptr;
+        if (_algorithm.scaling == "automatic") nlp.vscale = mi355x::bound_scales(P);
+        else if (_algorithm.scaling != "none") die("Alg::scaling must be \"automatic\" or \"none\"");
         _solution.linear_solver = dev_kkt ? "device: structured KKT factorisation (Schur complement + Cholesky), Woodbury-corrected" : "host LDL^T";
         if (P.guess_lamF.size() == ns * P.nodes) nlp.lamF0 = P.guess_lamF;
         if (P.guess_lamC.size() == P.npath * P.nodes) nlp.lamC0 = P.guess_lamC;

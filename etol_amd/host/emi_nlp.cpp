@@ -408,6 +408,82 @@ class DenseHostKkt : public KktBackend {
 
 }  // namespace
 
+// ---- variable scaling (PSOPT's scaling = "automatic", reference src/ePSOPT/ePSOPT.cpp:63) ------------------------------
+// PSOPT iterates on  z~_v = z_v / s_v  with s_v taken from the variable's bounds, and scales the defect rows of state i like
+// state i ("state-based" defect scaling, its default).  With one scale per state / control (the same at every node) the scaled
+// transcription has the SAME shape as the unscaled one:  (D x_i - h f_i) / s_i = D x~_i - h f_i / s_i,  so D, the node-diagonal
+// Jacobian entries and the packed node blocks of the Hessian keep their layouts and only their values change:
+//     defect rows / s_i;   f-partial (i, v) * s_v / s_i  (the entry (i, i) carries D_kk: factor 1);   path partials and the cost
+//     gradient * s_v;   Hessian entry (v, q) * s_v s_q, evaluated with the multipliers lambda~_i / s_i.
+// The evaluator and the KKT backend of the caller are used as they are (the backend reads D from its own context).
+// The example's defect_scaling = "jacobian-based" (etol_psopt_example1.cpp:91: one scale per defect ROW) would break the
+// D (x) I structure the Newton step is built on and is not offered.
+class ScaledEvaluator : public NlpEvaluator {
+ public:
+    ScaledEvaluator(const NlpProblem& P, const std::vector<std::vector<std::pair<int, int>>>& rv, int npart)
+        : in_(P.ev), s_(P.vscale), rv_(rv), ns_(P.ns), nc_(P.nc), M_(P.M), npart_(npart), z_((size_t)(P.ns + P.nc) * P.M),
+          lam_((size_t)P.ns * P.M) {}
+    int eval(const double* X, const double* U, double* RES, double* VALS, double* COST, bool jac) override {
+        unscale(X, U);
+        const int rc = in_->eval(z_.data(), z_.data() + (size_t)ns_ * M_, RES, VALS, COST, jac);
+        if (rc != 0) return rc;
+        const int nv = ns_ + nc_;
+        for (int i = 0; i < ns_; ++i) {
+            const double inv = 1.0 / s_[i];
+            for (int k = 0; k < M_; ++k) RES[(size_t)i * M_ + k] *= inv;
+        }
+        if (jac && VALS) {
+            for (int i = 0; i < ns_; ++i)
+                for (int v = 0; v < nv; ++v) {
+                    if (v == i) continue;
+                    const double f = s_[v] / s_[i];
+                    double* e = VALS + (size_t)(i * nv + v) * M_;
+                    for (int k = 0; k < M_; ++k) e[k] *= f;
+                }
+            for (const auto& row : rv_)
+                for (const auto& ve : row) {
+                    double* e = VALS + (size_t)ve.second * M_;
+                    for (int k = 0; k < M_; ++k) e[k] *= s_[ve.first];
+                }
+            for (int v = 0; v < nv; ++v) {
+                double* e = VALS + (size_t)(ns_ * nv + npart_ + v) * M_;
+                for (int k = 0; k < M_; ++k) e[k] *= s_[v];
+            }
+        }
+        return 0;
+    }
+    int hess(const double* X, const double* U, const double* lamF, const double* lamC, double sigma, double* H) override {
+        unscale(X, U);
+        for (int i = 0; i < ns_; ++i)
+            for (int k = 0; k < M_; ++k) lam_[(size_t)i * M_ + k] = lamF[(size_t)i * M_ + k] / s_[i];
+        const int rc = in_->hess(z_.data(), z_.data() + (size_t)ns_ * M_, lam_.data(), lamC, sigma, H);
+        if (rc != 0) return rc;
+        const int nv = ns_ + nc_;
+        for (int hi = 0; hi < nv; ++hi)
+            for (int lo = 0; lo <= hi; ++lo) {
+                const double f = s_[hi] * s_[lo];
+                if (f == 1.0) continue;
+                double* e = H + (size_t)(hi * (hi + 1) / 2 + lo) * M_;
+                for (int k = 0; k < M_; ++k) e[k] *= f;
+            }
+        return 0;
+    }
+    std::string last_error() const override { return in_->last_error(); }
+
+ private:
+    void unscale(const double* X, const double* U) {
+        for (int v = 0; v < ns_; ++v)
+            for (int k = 0; k < M_; ++k) z_[(size_t)v * M_ + k] = X[(size_t)v * M_ + k] * s_[v];
+        for (int j = 0; j < nc_; ++j)
+            for (int k = 0; k < M_; ++k) z_[(size_t)(ns_ + j) * M_ + k] = U[(size_t)j * M_ + k] * s_[ns_ + j];
+    }
+    NlpEvaluator* in_;
+    std::vector<double> s_;
+    std::vector<std::vector<std::pair<int, int>>> rv_;
+    int ns_, nc_, M_, npart_;
+    std::vector<double> z_, lam_;
+};
+
 NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vector<double>& z0) {
     NlpResult R;
     const int ns = P.ns, nc = P.nc, np = P.np, M = P.M, nv = ns + nc;
@@ -420,6 +496,38 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     int npart = 0;
     for (const auto& r : rv) npart += (int)r.size();
     const int nvals = ns * nv + npart + nv;
+    if (!P.vscale.empty()) {            // iterate on the scaled variables (ScaledEvaluator above), answer in the caller's
+        if ((int)P.vscale.size() != nv || (int)z0.size() != nz || (int)P.zl.size() != nz || (int)P.zu.size() != nz || !P.ev) {
+            R.msg = "solve_nlp: inconsistent problem sizes (vscale)";
+            return R;
+        }
+        for (double sv : P.vscale)
+            if (!(sv > 0) || !std::isfinite(sv)) { R.msg = "solve_nlp: vscale must be positive"; return R; }
+        NlpProblem Q = P;
+        Q.vscale.clear();
+        Q.row_vars = rv;
+        ScaledEvaluator sev(P, rv, npart);
+        Q.ev = &sev;
+        std::vector<double> zs(z0);
+        for (int v = 0; v < nv; ++v)
+            for (int k = 0; k < M; ++k) {
+                const size_t q = (size_t)v * M + k;
+                const double inv = 1.0 / P.vscale[v];
+                zs[q] *= inv;
+                if (Q.zl[q] > -INF_BOUND) Q.zl[q] *= inv;
+                if (Q.zu[q] < INF_BOUND) Q.zu[q] *= inv;
+                if (P.zl[q] == P.zu[q]) Q.zu[q] = Q.zl[q];
+            }
+        if ((int)Q.lamF0.size() == md)
+            for (int i = 0; i < ns; ++i)
+                for (int k = 0; k < M; ++k) Q.lamF0[(size_t)i * M + k] *= P.vscale[i];
+        NlpResult S = solve_nlp(Q, opt, zs);
+        for (int v = 0; v < nv && (int)S.z.size() == nz; ++v)
+            for (int k = 0; k < M; ++k) S.z[(size_t)v * M + k] *= P.vscale[v];
+        for (int i = 0; i < ns && (int)S.lamF.size() == md; ++i)
+            for (int k = 0; k < M; ++k) S.lamF[(size_t)i * M + k] /= P.vscale[i];
+        return S;
+    }
     if (!P.ev || (int)P.zl.size() != nz || (int)P.zu.size() != nz || (int)P.D.size() != M * M ||
         (int)P.cl.size() != np || (int)P.cu.size() != np || (int)z0.size() != nz) {
         R.msg = "solve_nlp: inconsistent problem sizes";

@@ -63,6 +63,8 @@ struct NlpProblem {
     std::vector<double> zl, zu;         // (ns+nc)*M variable bounds, index v*M+k; zl==zu fixes a variable
     std::vector<double> cl, cu;         // np path-row bounds (same at every node)
     std::vector<double> cscale;         // np positive row scalings applied inside the iteration (empty = 1)
+    std::vector<double> vscale;         // ns+nc positive variable scales: the iteration runs on z_v / vscale[v], defect rows of state i
+                                        // on defect_i / vscale[i] (PSOPT's scaling = "automatic" with state-based defect scaling); empty = none
     std::vector<double> lamF0, lamC0;   // optional warm start of the defect / path-row multipliers (ns*M, np*M)
     NlpEvaluator* ev = nullptr;
     KktBackend* kkt = nullptr;          // null: dense LDL^T on the host (with inertia); else e.g. the device LU

@@ -18,6 +18,8 @@ namespace mi355x {
 NlpProblem make_nlp(const Prob& P, NlpEvaluator* ev);
 // zeros unless Prob::guess_* were pre-filled (reference ePSOPT.cpp:47-56)
 std::vector<double> initial_guess(const Prob& P);
+// variable scales of Alg::scaling = "automatic": max(|lower|, |upper|) per state / control (1 without a finite bound)
+std::vector<double> bound_scales(const Prob& P);
 
 }  // namespace mi355x
 }  // namespace ETOL

@@ -29,6 +29,9 @@ struct Alg {
     std::string hessian = "exact";
     std::string collocation_method = "Legendre";   // Legendre-Gauss-Lobatto, as PSOPT's "Legendre"
     std::string mesh_refinement = "automatic";     // "automatic" or "none" (ePSOPT.cpp:69)
+    std::string scaling = "automatic";             // ePSOPT.cpp:63.  "automatic": the NLP iteration runs on variables scaled by their bounds
+                                                   // (z_v / max(|lower_v|, |upper_v|)) and on defect rows scaled like their state (PSOPT's
+                                                   // state-based defect scaling); "none": unscaled.  Results are always in the caller's units.
     int mr_max_iterations = 10;                    // ePSOPT.cpp:70
     double ode_tolerance = 1.e-4;                  // ePSOPT.cpp:71
     int mr_max_nodes = 513;                        // refinement stops adding nodes here

@@ -182,6 +182,8 @@ struct HostKkt : public mx::KktBackend {
 HostKkt g_host_kkt;
 }  // namespace
 
+int g_scaling = -1;               // -1: defaults (oracle-evaluator solves unscaled, eMI355X as Alg::scaling says); 0 / 1: scaling "none" / "automatic"
+extern "C" void harness_set_scaling(int on) { g_scaling = on; }
 extern "C" int harness_kkt_standin_wrong_inertia(void) { return g_host_kkt.wrong_inertia; }
 
 extern "C" int harness_solve_example1_oracle(const char* xml, const char* oracle_so, int with_obstacles, double tol,
@@ -228,6 +230,7 @@ extern "C" int harness_solve_example1_oracle(const char* xml, const char* oracle
     P.path_lower.assign(P.npath, -1000.0); P.path_upper.assign(P.npath, 0.0);
     oe.P = &P;
     mx::NlpProblem nlp = mx::make_nlp(P, &oe);
+    if (g_scaling == 1) nlp.vscale = mx::bound_scales(P);
     if (g_linear_solver == "device") {   // CPU tests: the KktBackend branch with the host stand-in
         g_host_kkt.P = &P;
         g_host_kkt.wrong_inertia = 0;
@@ -418,6 +421,7 @@ extern "C" int harness_solve_quadrotor(int nsteps, double dt, int ndiscs, double
     solver.getAlgorithm()->mesh_refinement = refine ? "automatic" : "none";
     solver.getAlgorithm()->ode_tolerance = ode_tol;
     solver.getAlgorithm()->linear_solver = g_linear_solver;
+    solver.getAlgorithm()->scaling = g_scaling < 0 ? solver.getAlgorithm()->scaling : (g_scaling ? "automatic" : "none");
     solver.solve();
     g_out2 = solver.getSolution()->linear_solver;
     const mx::Sol* s = solver.getSolution();
@@ -466,6 +470,7 @@ extern "C" int harness_solve_quadrotor_oracle(const char* oracle_so, int nsteps,
     P.path_lower.assign(P.npath, -1000.0); P.path_upper.assign(P.npath, 0.0);
     oe.P = &P;
     mx::NlpProblem nlp = mx::make_nlp(P, &oe);
+    if (g_scaling == 1) nlp.vscale = mx::bound_scales(P);
     if (g_linear_solver == "device") {   // CPU tests: the KktBackend branch with the host stand-in
         g_host_kkt.P = &P;
         g_host_kkt.wrong_inertia = 0;
@@ -588,6 +593,7 @@ extern "C" int harness_solve_fixedwing_oracle(const char* oracle_so, int nsteps,
     for (int i = 0; i < 12; ++i) { P.event_lower.push_back(t.getXf()[i] - t.getXtol()[i]); P.event_upper.push_back(t.getXf()[i] + t.getXtol()[i]); }
     oe.P = &P;
     mx::NlpProblem nlp = mx::make_nlp(P, &oe);
+    if (g_scaling == 1) nlp.vscale = mx::bound_scales(P);
     mx::NlpOptions opt;
     opt.tol = tol; opt.print_level = print_level; opt.max_iter = 300;
     mx::NlpResult r = mx::solve_nlp(nlp, opt, mx::initial_guess(P));
@@ -615,6 +621,7 @@ extern "C" int harness_solve_fixedwing(int nsteps, double tf, double lateral, do
     solver.getAlgorithm()->nlp_iter_max = 300;
     solver.getAlgorithm()->mesh_refinement = "none";
     solver.getAlgorithm()->linear_solver = g_linear_solver;
+    solver.getAlgorithm()->scaling = g_scaling < 0 ? solver.getAlgorithm()->scaling : (g_scaling ? "automatic" : "none");
     solver.solve();
     const mx::Sol* s = solver.getSolution();
     *iters = s->nlp_iterations;
@@ -870,6 +877,7 @@ int harness_solve_example1(const char* xml, int with_obstacles, double tol, int 
     e.solver.getAlgorithm()->nlp_tolerance = tol;
     e.solver.getAlgorithm()->print_level = print_level;
     e.solver.getAlgorithm()->linear_solver = g_linear_solver;
+    e.solver.getAlgorithm()->scaling = g_scaling < 0 ? e.solver.getAlgorithm()->scaling : (g_scaling ? "automatic" : "none");
     if (g_refine >= 0) e.solver.getAlgorithm()->mesh_refinement = g_refine ? "automatic" : "none";
     t->solve();
     g_out2 = e.solver.getSolution()->linear_solver;

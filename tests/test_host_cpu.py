@@ -207,6 +207,42 @@ def test_newton_step_backend_interface_keeps_the_inertia_right(H):
     assert np.abs(out["host"][1] - out["device"][1]).max() < 1e-6
 
 
+def test_scaled_iteration_reaches_the_unscaled_optimum(H, xmls):
+    """Alg::scaling = "automatic" (ePSOPT.cpp:63): the iteration on bound-scaled variables / state-scaled defect rows (quadrotor:
+    scales 10, 10, 1.2, 6, 6, 4 | 25, 1) ends at the trajectory of the unscaled one where the problem has ONE optimum (no
+    keep-outs), in the caller's units; with keep-outs it may settle in another homotopy class (here: 398.4 against 389.3, the
+    other side of the second disc), so that case is checked as what it claims to be: feasible to 1e-8 against the oracle."""
+    D = C.POINTER(C.c_double)
+    H.harness_solve_quadrotor_oracle.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, D,
+                                                 C.POINTER(C.c_int), D, D, C.c_int, C.POINTER(C.c_int)]
+    H.harness_last_message.restype = C.c_char_p
+    H.harness_set_scaling.argtypes = [C.c_int]
+    out = {}
+    try:
+        for nd in (0, 2):
+            for mode in (0, 1):
+                H.harness_set_scaling(mode)
+                X, U = np.zeros(6 * 64), np.zeros(2 * 64)
+                cost, M, it = C.c_double(), C.c_int(), C.c_int()
+                rc = H.harness_solve_quadrotor_oracle(os.path.join(ROOT, "oracle", "liboracle.so").encode(), 24, 0.16, nd, 1e-9,
+                                                      0, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D), 64,
+                                                      C.byref(it))
+                assert rc == 0, H.harness_last_message().decode()
+                m = M.value
+                out[nd, mode] = (cost.value, X[:6 * m].reshape(6, m).copy(), U[:2 * m].reshape(2, m).copy(), it.value)
+    finally:
+        H.harness_set_scaling(-1)
+    a, b = out[0, 0], out[0, 1]
+    assert b[3] <= a[3] and abs(a[0] - b[0]) < 1e-10 * a[0]
+    assert np.abs(a[1] - b[1]).max() < 1e-6 and np.abs(a[2] - b[2]).max() < 1e-5
+    cost, X, U, iters = out[2, 1]
+    m = X.shape[1]
+    recs = np.array([[1, 4.0, 3.2, 0.64, 0, 0, 0, 0], [1, 6.3, 4.4, 0.49, 0, 0, 0, 0]], dtype=float)
+    RES, _, COST = O.evaluate(1, [1.0, 0.01, 9.81, 1.0, 1.0], m, O.lgl(m), 0.0, 24 * 0.16, X[None], U[None], recs)
+    assert iters < 150 and np.abs(RES[0, :6]).max() < 1e-8 and RES[0, 6:].max() < 1e-8 and abs(COST[0] - cost) < 1e-8
+    assert U[0].min() >= -1e-9 and U[0].max() <= 25 + 1e-9 and np.abs(U[1]).max() <= 1 + 1e-9
+
+
 def test_nlp_iteration_fixedwing_lateral_offset(H):
     """The 12-state fixed-wing model as an NLP: trimmed flight at 25 m/s, 8 s, end 10 m to the side.
     Coupled, strongly nonconvex node blocks -- the case that exercises the inertia handling and the
