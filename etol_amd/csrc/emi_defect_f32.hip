@@ -16,6 +16,7 @@
 // two 32x32 accumulators), double-buffered LDS with register prefetch; LDS rows padded to 33 floats
 // (conflict-free ds_read_b32 of the [row = lane & 31][k = lane >> 5] fragments).
 // Requires M % 128 == 0; other shapes take the f64-accumulating fallback in emi_kernels.hip.
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "emi_kernels.hpp"
@@ -216,11 +217,17 @@ hipError_t launch_pass_f32(int model, const DefectArgsF32& d, const NodeArgs<flo
 //   * A stage is 192 rows of 128 B (64 of X, 128 of D), 24 DMA wave instructions of 1 KB, six per wave.  A DMA instruction writes
 //     8 rows linearly, so rows cannot be padded: 16-byte chunk c of row r sits at chunk position c ^ ((r >> 1) & 7) (applied to the
 //     per-lane SOURCE address and to the fragment read address).
-//   * The MFMA sums over k, so which k a lane holds is free as long as A and B agree: lane half lk takes k = 4c + 2lk, 4c + 2lk + 1
-//     of chunk c in two consecutive MFMAs -- one ds_read_b64 per operand row and chunk (2-way bank conflict: 32 lanes x 8 B of one
-//     half cannot tile a 256-byte bank row; 4 LDS cycles, what the ds_read_b128 alternative costs too).
+//   * The MFMA sums over k, so which k a lane holds is free as long as A and B agree: lane half lk takes the 16-byte chunks of its
+//     parity, c = 2q + lk (k = 4c + j in MFMA j of the chunk) -- one ds_read_b128 per operand row and chunk pair, 12 per wave and K
+//     tile (the first ring form read 8 bytes per chunk: 24 reads and 16 address additions per tile; every non-MFMA vector
+//     instruction of a wave costs the matrix pipe 5 - 7 cycles here, profiles/r03_notes.md section 6).
+//   * The K loop is unrolled over the ring (6 steps: 3 stages x 2 fragment sets), so stage offsets are immediates and the 8 per-lane
+//     fragment addresses never change; the shifted operands are formed as packed additions of -shift (v_pk_add_f32).
 typedef __attribute__((address_space(3))) void* emi_lds_ptr32_t;
 __device__ __forceinline__ constexpr int f32ring_swz(int r) { return (r >> 1) & 7; }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 2) void emi_defect_f32_ring_kernel(DefectArgsF32 a) {
     constexpr int TM = 64, TN = 128, BK = 32, NST = 3, LOOK = NST - 1;
@@ -246,9 +253,12 @@ __global__ __launch_bounds__(256, 2) void emi_defect_f32_ring_kernel(DefectArgsF
     const int l32 = lane & 31, lk = lane >> 5;
 
     const int row = m0 + wr * 32 + l32;
-    float shift[2];
+    f32x2 nshift[2];                              // minus the shift of the wave's two column tiles, both halves (packed adds)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) shift[c] = row < R ? a.X[(size_t)row * M + n0 + wc * 64 + c * 32 + 16] : 0.f;
+    for (int c = 0; c < 2; ++c) {
+        const float sh = row < R ? a.X[(size_t)row * M + n0 + wc * 64 + c * 32 + 16] : 0.f;
+        nshift[c] = f32x2{-sh, -sh};
+    }
 
     // DMA addressing: instruction t of wave wid moves stage rows 8 (wid + 4t) .. +7, all of X or all of D: wave-uniform 64-bit base,
     // constant per-lane 32-bit offset, +128 bytes per K tile
@@ -271,20 +281,17 @@ __global__ __launch_bounds__(256, 2) void emi_defect_f32_ring_kernel(DefectArgsF
     }
     const unsigned lds0 = (unsigned)(unsigned long)(emi_lds_ptr32_t)smf;
     const int nkt = M / BK;
-    unsigned st_dma = 0, st_rd = 0;
     int nd = 0;
-    auto issue_one = [&](int t) {
-        const unsigned dst = lds0 + st_dma + (unsigned)(wid + 4 * t) * 1024u;   // wave-uniform
+    // DS = stage the tile goes to (compile-time in the K loop: the loop is unrolled over the ring)
+    auto issue_one = [&](int t, int DS) {
+        const unsigned dst = lds0 + (unsigned)(DS * STAGE * 4) + (unsigned)(wid + 4 * t) * 1024u;   // wave-uniform
         asm volatile("s_mov_b32 m0, %2\n\t" EMI_M0_NOP "global_load_lds_dwordx4 %0, %1" ::"v"(voff[t]), "s"(gnext[t]), "s"(dst) : "memory", "m0");
         gnext[t] += (unsigned long long)(BK * sizeof(float));
-        if (t == L - 1) {
-            st_dma = st_dma == (unsigned)((NST - 1) * STAGE * 4) ? 0u : st_dma + (unsigned)(STAGE * 4);
-            ++nd;
-        }
+        if (t == L - 1) ++nd;
     };
-    auto issue = [&]() {
+    auto issue = [&](int DS) {
 #pragma unroll
-        for (int t = 0; t < L; ++t) issue_one(t);
+        for (int t = 0; t < L; ++t) issue_one(t, DS);
     };
 
     f32x16 acc[2];
@@ -295,74 +302,101 @@ __global__ __launch_bounds__(256, 2) void emi_defect_f32_ring_kernel(DefectArgsF
 
 #pragma unroll
     for (int t = 0; t < LOOK; ++t)
-        if (t < nkt) issue();
+        if (t < nkt) issue(t);
 
-    // fragment addresses (floats within a stage): the lane's A row and its two B rows; chunk c of row r at ((c ^ swz(r)) * 4 + 2 lk)
-    const int ra = wr * 32 + l32, rb0 = TM + wc * 64 + l32, rb1 = rb0 + 32;
-    const int sa = f32ring_swz(ra), sb0 = f32ring_swz(rb0 - TM), sb1 = f32ring_swz(rb1 - TM);
-    struct Frag { float2 a[8], b0[8], b1[8], s0[8], s1[8]; };      // s0 / s1: a - shift of the wave's two column tiles
-    constexpr int NR = 24, NM = 32;                       // fragment reads / MFMAs per wave and K tile
-    auto read_one = [&](Frag& f, const float* S, int r) {
-        const int c = r / 3, w = r % 3;
-        if (w == 0) f.a[c] = *reinterpret_cast<const float2*>(S + ra * BK + ((c ^ sa) << 2) + 2 * lk);
-        else if (w == 1) f.b0[c] = *reinterpret_cast<const float2*>(S + rb0 * BK + ((c ^ sb0) << 2) + 2 * lk);
-        else f.b1[c] = *reinterpret_cast<const float2*>(S + rb1 * BK + ((c ^ sb1) << 2) + 2 * lk);
+    // Fragment addresses.  The lane's A row ra and its B rows rb0, rb1 = rb0 + 32 have the SAME swizzle (l32 >> 1) & 7 (their row numbers
+    // differ by multiples of 16), and lane half lk takes the chunks of its parity, c = 2q + lk: four ds_read_b128 per row and K tile,
+    // at per-lane byte offsets that never change (offA[q], offB[q]); stage and the +32 rows of rb1 are immediate offsets.
+    const int ra = wr * 32 + l32, rb0 = TM + wc * 64 + l32;
+    const int sw = f32ring_swz(ra);
+    const float* pA[4];
+    const float* pB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        pA[q] = smf + ra * BK + (((2 * q + lk) ^ sw) << 2);
+        pB[q] = smf + rb0 * BK + (((2 * q + lk) ^ sw) << 2);
+    }
+    struct Frag { f32x4 b0[4], b1[4]; f32x2 s0[4][2], s1[4][2]; };      // s0 / s1: a - shift of the wave's two column tiles
+    constexpr int NR = 12, NM = 32;                       // fragment reads / MFMAs per wave and K tile
+    // MFMA i of a tile: q = i >> 3, element j = (i >> 1) & 3 of the lane's chunk 2q + lk (k = 4 (2q + lk) + j), column tile i & 1
+    auto mfma_one = [&](const Frag& f, int i) {
+        const int q = i >> 3, j = (i >> 1) & 3;
+        if ((i & 1) == 0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.s0[q][j >> 1][j & 1], f.b0[q][j], acc[0], 0, 0, 0);
+        else              acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.s1[q][j >> 1][j & 1], f.b1[q][j], acc[1], 0, 0, 0);
     };
-    auto rd_stage = [&]() -> const float* {
-        const float* S = smf + (st_rd >> 2);
-        st_rd = st_rd == (unsigned)((NST - 1) * STAGE * 4) ? 0u : st_rd + (unsigned)(STAGE * 4);
-        return S;
-    };
-    auto mfma_one = [&](const Frag& f, int i) {           // chunk c = i >> 2: k = 4c + 2lk (.x) then 4c + 2lk + 1 (.y), both column tiles
-        const int c = i >> 2, sub = i & 3;
-        if ((sub & 1) == 0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((sub & 2) ? f.s0[c].y : f.s0[c].x, (sub & 2) ? f.b0[c].y : f.b0[c].x, acc[0], 0, 0, 0);
-        else                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((sub & 2) ? f.s1[c].y : f.s1[c].x, (sub & 2) ? f.b1[c].y : f.b1[c].x, acc[1], 0, 0, 0);
-    };
-    // the shifted operands of chunk c, formed six gaps after its A fragment was requested (a v_sub directly in front of an MFMA holds
-    // the matrix pipe for its result: no-shift ablation 0.910 -> 0.8245 ms)
-    auto shift_one = [&](Frag& f, int c) {
-        f.s0[c] = make_float2(f.a[c].x - shift[0], f.a[c].y - shift[0]);
-        f.s1[c] = make_float2(f.a[c].x - shift[1], f.a[c].y - shift[1]);
-    };
-    constexpr int GR = NR;                                // one fragment read per gap in the first 24 gaps, then a DMA instruction in each of 6
-    static_assert(GR + L <= NM, "a gap for every read and every DMA instruction");
-    auto step = [&](const Frag& cur, Frag& nxt, int kt) { // kt + 1 < nkt: MFMAs of tile kt, tile kt+1 made ready
+    // K-loop step with everything about the ring known at compile time: the fragments of tile kt+1 come from stage RS, the DMA of
+    // tile kt+3 goes to stage (RS + 2) % 3 (the stage of tile kt, whose fragments were read during the previous step).  One fragment
+    // read in each of the first 12 gaps (A chunk first: its shifted copies are formed four gaps later, as packed adds), then nothing,
+    // then one DMA instruction in each of gaps 24 .. 29.
+    f32x4 araw[4];
+    auto step = [&](const Frag& cur, Frag& nxt, int kt, auto rs_tag) {
+        constexpr int RS = decltype(rs_tag)::value, DS = (RS + 2) % 3;
         if (kt + LOOK < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
         else                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0), visible to the compiler's wait counting
-        asm volatile("s_barrier" ::: "memory");           // tile kt+1 has landed for every wave; the stage of tile kt-1... is free
+        asm volatile("s_barrier" ::: "memory");           // tile kt+1 has landed for every wave; the stage of tile kt is free
         const bool more = nd < nkt;
-        const float* S = rd_stage();
 #pragma unroll
         for (int i = 0; i < NM; ++i) {
             mfma_one(cur, i);
-            if (i < GR) read_one(nxt, S, i);
-            else if (i < GR + L) { if (more) issue_one(i - GR); }
-            if (i >= 6 && i < 6 + GR && (i - 6) % 3 == 0) shift_one(nxt, (i - 6) / 3);     // A chunk (i - 6) / 3 was requested six gaps ago
+            if (i < NR) {
+                const int q = i / 3, w = i % 3;
+                if (w == 0) araw[q] = *reinterpret_cast<const f32x4*>(pA[q] + RS * STAGE);
+                else if (w == 1) nxt.b0[q] = *reinterpret_cast<const f32x4*>(pB[q] + RS * STAGE);
+                else nxt.b1[q] = *reinterpret_cast<const f32x4*>(pB[q] + RS * STAGE + 32 * BK);
+            }
+            if (i >= 4 && i < 4 + NR && (i - 4) % 3 == 0) {
+                const int q = (i - 4) / 3;
+                nxt.s0[q][0] = araw[q].xy + nshift[0];
+                nxt.s0[q][1] = araw[q].zw + nshift[0];
+                nxt.s1[q][0] = araw[q].xy + nshift[1];
+                nxt.s1[q][1] = araw[q].zw + nshift[1];
+            }
+            if (i >= 24 && i < 24 + L) { if (more) issue_one(i - 24, DS); }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    auto multiply = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i) mfma_one(f, i);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
     Frag f0, f1;
     if (nkt > LOOK - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L * (LOOK - 1)) : "memory");
     else                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
-    if (LOOK < nkt) issue();
+    if (LOOK < nkt) issue(LOOK % NST);
     __builtin_amdgcn_s_waitcnt(0xC07F);
-    {
-        const float* S = rd_stage();
 #pragma unroll
-        for (int r = 0; r < NR; ++r) read_one(f0, S, r);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) shift_one(f0, c);
+    for (int q = 0; q < 4; ++q) {                         // tile 0 from stage 0
+        const f32x4 av = *reinterpret_cast<const f32x4*>(pA[q]);
+        f0.b0[q] = *reinterpret_cast<const f32x4*>(pB[q]);
+        f0.b1[q] = *reinterpret_cast<const f32x4*>(pB[q] + 32 * BK);
+        f0.s0[q][0] = av.xy + nshift[0];
+        f0.s0[q][1] = av.zw + nshift[0];
+        f0.s1[q][0] = av.xy + nshift[1];
+        f0.s1[q][1] = av.zw + nshift[1];
     }
-    int kt = 0;                                           // nkt = M / 32 is a multiple of 4
-    for (; kt + 2 < nkt; kt += 2) {
-        step(f0, f1, kt);
-        step(f1, f0, kt + 1);
+    // tile t lives in stage t % 3 and, by turns, in f0 / f1: six steps bring both back to where they started
+    int kt = 0;
+    for (; kt + 6 < nkt; kt += 6) {
+        step(f0, f1, kt, S1{});
+        step(f1, f0, kt + 1, S2{});
+        step(f0, f1, kt + 2, S0{});
+        step(f1, f0, kt + 3, S1{});
+        step(f0, f1, kt + 4, S2{});
+        step(f1, f0, kt + 5, S0{});
     }
-    step(f0, f1, kt);
-#pragma unroll
-    for (int i = 0; i < NM; ++i) mfma_one(f1, i);
+    const int rem = nkt - kt;                             // 1 .. 6 tiles left, tile kt in f0 / stage 0
+    if (rem > 1) step(f0, f1, kt, S1{});
+    if (rem > 2) step(f1, f0, kt + 1, S2{});
+    if (rem > 3) step(f0, f1, kt + 2, S0{});
+    if (rem > 4) step(f1, f0, kt + 3, S1{});
+    if (rem > 5) step(f0, f1, kt + 4, S2{});
+    if (rem & 1) multiply(f0);
+    else         multiply(f1);
 
     // C/D map of the 32x32 f32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
