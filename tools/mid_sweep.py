@@ -32,6 +32,10 @@ FORMS = {
     "one_sw3_first_nt": dict(overlap_mode=3, sym_ct=8, pass_order=1, node_store=2),
     "one_sw3_first": dict(overlap_mode=3, sym_ct=8, pass_order=1),
     "one_sw3_inter": dict(overlap_mode=3, sym_ct=8, pass_order=0),
+    "one_sw1_ks2_first": dict(overlap_mode=3, sym_ct=7, pass_order=1, sym_ksplit=2),
+    "one_sw1_ks4_first": dict(overlap_mode=3, sym_ct=7, pass_order=1, sym_ksplit=4),
+    "one_sw2_ks4_first": dict(overlap_mode=3, sym_ct=6, pass_order=1, sym_ksplit=4),
+    "one_sw1_ks2_inter": dict(overlap_mode=3, sym_ct=7, pass_order=0, sym_ksplit=2),
     "one_sw2_ks2_first": dict(overlap_mode=3, sym_ct=6, pass_order=1, sym_ksplit=2),
     "one_sw3_ks2_first": dict(overlap_mode=3, sym_ct=8, pass_order=1, sym_ksplit=2),
     "one_sw2_front150": dict(overlap_mode=3, sym_ct=6, pass_order=150),
