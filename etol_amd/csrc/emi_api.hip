@@ -840,12 +840,18 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
                 plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 < 128 ? 7 : 6, 1, c->sym_cpart, gblk_auto, c->sym_cx);        // SW = 1 / 2
             else if (plan.ring1) plan = emi::plan_symdefect(c->ns, c->B, c->M, 5, 1, c->sym_cpart, c->sym_gblk, c->sym_cx);
             plan.nst = c->sym_nst;
-            if (c->sym_ksplit > 1) {
-                // "sym_ksplit": the K range of a tile cut into slices, their partial sums combined in-kernel by ticket.
-                // Not chosen by itself: at 128 instances SW = 2 x 2 slices 0.0437 ms against SW = 1 unsplit 0.0446 -- the
-                // fixed parts of the MFMA role (launch, prologue, epilogue: ~15 us) are what a small pass waits for
+            // K slices per tile ("sym_ksplit"; partial sums combined in-kernel by ticket, bitwise the unsplit sum order per slice).
+            // By itself (0, and only in the default dispatch: no variant forced) only where the MFMA role has fewer workgroups than the chip has places for them, i.e. where a pass waits
+            // for one 64-tile dependency chain per workgroup: 4 slices while that keeps the role within 256 workgroups, 2 within 512.
+            // One box, M = 1024, ms per pass unsplit / 2 / 4 slices (tools/mid_sweep.py, profiles/r03_notes.md section 7):
+            // B = 8: 0.0204 / 0.0148 / 0.0140, 16: 0.0235 / 0.0179 / 0.0155, 32: 0.0242 / 0.0190 / 0.0192, 64: 0.0257 / 0.0218 / 0.0261,
+            // 80: 0.0263 / 0.0249 / 0.0312, 96: 0.0288 / 0.0290 / 0.0407, 128: 0.0333 / 0.0387 / 0.0496 (the split role no longer fits
+            // beside the node role: two workgroups of 60 KB LDS per CU).
+            int ks_want = c->sym_ksplit;
+            if (ks_want == 0 && !c->rtc && auto_mode && (c->sym_ct == 0 || c->sym_ct == 4)) ks_want = plan.tiles * 4 <= 256 ? 4 : (plan.tiles * 2 <= 512 ? 2 : 1);
+            if (ks_want > 1) {
                 const int ct_now = plan.sw == c->ns ? 5 : (plan.sw == 2 ? 6 : (plan.sw == 3 ? 8 : 7));
-                plan = emi::plan_symdefect(c->ns, c->B, c->M, ct_now, c->sym_ksplit, c->sym_cpart, c->sym_gblk, c->sym_cx);
+                plan = emi::plan_symdefect(c->ns, c->B, c->M, ct_now, ks_want, c->sym_cpart, c->sym_gblk, c->sym_cx);
                 plan.nst = c->sym_nst;
             } else {
                 plan.ks = 1;

@@ -775,12 +775,17 @@ def _expected_default_form(B, M=1024):
     the multiple of 256 instances (grouped tile order) plus a second launch for the remainder."""
     last = B if (B <= 2048 or B % 256 == 0) else B % 256
     tiles16 = ((last + 15) // 16) * (M // 128)
-    return "emi_pass_f64_kernel<SW=1>" if tiles16 < 128 else "emi_pass_f64_kernel<SW=2>"
+    if tiles16 >= 128:
+        return "emi_pass_f64_kernel<SW=2>"
+    wgs = tiles16 * 6                                  # MFMA workgroups unsplit: 4 K slices within 256 of them, 2 within 512
+    ks = 4 if wgs * 4 <= 256 else (2 if wgs * 2 <= 512 else 1)
+    return "emi_pass_f64_kernel<SW=1> (MFMA + node roles, one launch" + (f", {ks} K slices" if ks > 1 else ")")
 
 
-@pytest.mark.parametrize("B", [128, 256, 512, 1024, 2064, 2560])
+@pytest.mark.parametrize("B", [16, 64, 128, 256, 512, 1024, 2064, 2560])
 def test_default_dispatch_at_the_benchmarked_shapes_matches_the_oracle(built, B):
-    """The shapes bench.py and config 4 actually run -- M = 1024, 20 PER-INSTANCE keep-outs, B = 128 (the shard of config 4:
+    """The shapes bench.py and config 4 actually run -- M = 1024, 20 PER-INSTANCE keep-outs, B = 16 / 64 (SW = 1 with 4 / 2 K slices
+    per tile, combined in-kernel by ticket), 128 (the shard of config 4:
     one launch, SW = 1, MFMA workgroups first, plain stores), 256 (SW = 2, MFMA workgroups first, non-temporal stores), 512 (SW = 2, MFMA
     workgroups at 1.5 x the even density), 1024 (the headline: SW = 2, evenly interleaved, 2 column partitions), 2064 (one launch of
     2048 instances + a 16-instance tail), 2560 (one launch in the grouped tile order) -- through the DEFAULT dispatch (no option

@@ -203,7 +203,7 @@ def test_traced_quadrotor_f32_context(built):
     for a, b in zip(got, hand):
         assert np.abs(a - b).max() / (np.abs(b).max() + 1.0) < 2e-6
     # a traced model takes the same fp32 MFMA defect kernel as the built-in ones (the kernel sees X and D only)
-    assert tr.last_defect_kernel() == bi.last_defect_kernel() == "emi_defect_f32_ring_kernel"
+    assert tr.last_defect_kernel == bi.last_defect_kernel == "emi_defect_f32_ring_kernel"
 
 
 def test_model_source_replaces_and_is_replaced(built):
