@@ -845,8 +845,8 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             // for one 64-tile dependency chain per workgroup: 4 slices while that keeps the role within 256 workgroups, 2 within 512.
             // One box, M = 1024, ms per pass unsplit / 2 / 4 slices (tools/mid_sweep.py, profiles/r03_notes.md section 7):
             // B = 8: 0.0204 / 0.0148 / 0.0140, 16: 0.0235 / 0.0179 / 0.0155, 32: 0.0242 / 0.0190 / 0.0192, 64: 0.0257 / 0.0218 / 0.0261,
-            // 80: 0.0263 / 0.0249 / 0.0312, 96: 0.0288 / 0.0290 / 0.0407, 128: 0.0333 / 0.0387 / 0.0496 (the split role no longer fits
-            // beside the node role: two workgroups of 60 KB LDS per CU).
+            // 80: 0.0263 / 0.0249 / 0.0312, 96: 0.0288 / 0.0290 / 0.0407, 128: 0.0333 / 0.0387 / 0.0496 (from ~500 workgroups the
+            // split loses: three and more MFMA waves per SIMD share the matrix pipe and the node role starts behind them).
             int ks_want = c->sym_ksplit;
             if (ks_want == 0 && !c->rtc && auto_mode && (c->sym_ct == 0 || c->sym_ct == 4)) ks_want = plan.tiles * 4 <= 256 ? 4 : (plan.tiles * 2 <= 512 ? 2 : 1);
             if (ks_want > 1) {
