@@ -378,6 +378,42 @@ EMI_DEV void ring_epilogue_s0(const SymDefectArgs& a, const d4 (&acc_a)[SW], con
     // memory round trip gains (0.2475 against 0.2394 ms per pass at 1024 instances)
     // (keeping this loop rolled -- a quarter of the code, 41 KB for the pass kernel otherwise -- changes nothing: 0.2314
     // against 0.2318 ms, tools/ab_build.sh)
+    if constexpr (SW == 1) {
+        // One state per workgroup is the form of SMALL batches (fewer than 128 sixteen-instance tiles), where a pass waits for
+        // the MFMA role's latency chain and occupancy is no concern: all eight (instance, node) pairs of a lane in one memory
+        // round trip instead of four (measured with the epilogue switched off: 4.2 of the role's 27 us at 128 instances).
+        if (a.ablate & 4) return;
+        double zz[4][2][NV];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int inst = inst0 + kq + 4 * i;
+            inst = inst < B ? inst : B - 1;                // (rows past the batch: loaded from the last instance, not stored)
+            const double* __restrict__ Xb = a.X + (size_t)inst * NS * M;
+            const double* __restrict__ Ub = a.U + (size_t)inst * NC * M;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int node = side == 0 ? node_f : node_m;
+#pragma unroll
+                for (int v = 0; v < NS; ++v) zz[i][side][v] = Xb[(size_t)v * M + node];
+#pragma unroll
+                for (int v = 0; v < NC; ++v) zz[i][side][NS + v] = Ub[(size_t)v * M + node];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int inst = inst0 + kq + 4 * i;
+            if (inst >= B) continue;
+            double* __restrict__ Rb = a.RES + (size_t)inst * a.nres * M;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                double f[NS];
+                Model::f(a.P, zz[i][side], side == 0 ? t_f : t_m, f);
+                const double dx = side == 0 ? acc_a[0][i] + acc_b[0][i] : acc_b[0][i] - acc_a[0][i];
+                Rb[(size_t)S0 * M + (side == 0 ? node_f : node_m)] = dx - a.h * f[S0];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int inst = inst0 + kq + 4 * i;

@@ -73,6 +73,10 @@ FORMS = {
     "one_sw1_sc1": dict(overlap_mode=3, sym_ct=7, node_store=1),
     "one_sw1_first_sc1": dict(overlap_mode=3, sym_ct=7, node_store=1, pass_order=1),
     "one_sw2_first_sc1": dict(overlap_mode=3, sym_ct=6, node_store=1, pass_order=1),
+    "abl1_mfma_off": dict(overlap_mode=3, sym_ct=7, pass_order=1, sym_ablate=16),
+    "abl1_node_off": dict(overlap_mode=3, sym_ct=7, pass_order=1, sym_ablate=32),
+    "abl1_epi_off": dict(overlap_mode=3, sym_ct=7, pass_order=1, sym_ablate=4),
+    "abl1_node_off_epi_off": dict(overlap_mode=3, sym_ct=7, pass_order=1, sym_ablate=36),
     "abl_x": dict(overlap_mode=3, sym_ct=6, sym_ablate=8),
     "abl_panels": dict(overlap_mode=3, sym_ct=6, sym_ablate=64),
     "abl_epi": dict(overlap_mode=3, sym_ct=6, sym_ablate=4),
