@@ -576,16 +576,25 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         off_f[s] = r * BK + ((kq ^ ring_swz(r)) << 1);               // chunk kq: x_(2kq), x_(2kq+1)
         off_m[s] = (TM + r) * BK + (((3 - kq) ^ ring_swz(r)) << 1);  // chunk 3-kq of the mirrored tile
     }
-    // fragments of one K tile: De / Do rows of this wave (B operands), forward and mirrored x of every state (A operands)
+    // fragments of one K tile: De / Do rows of this wave (B operands) and, per state, the A operands of the even / odd products:
+    // sp = forward + mirrored x, dm = forward - mirrored x for the tile's two k-steps.  They are formed when the x fragments have
+    // arrived (in the gaps of the PREVIOUS tile's MFMAs), not in front of the MFMA that consumes them: a v_add_f64 directly ahead of
+    // its MFMA holds the matrix pipe for the result (the same finding as the shift subtractions of the fp32 kernel, r03_notes.md).
     struct Frag {
-        double2 be, bo, xf[SW], xm[SW];
+        double2 be, bo, sp[SW], dm[SW];
     };
+    double2 txf[SW], txm[SW];                           // x fragments between their read and their sums
     constexpr int NR = 2 + 2 * SW, NM = 4 * SW;         // fragment reads / MFMAs per wave and K tile
     auto read_one = [&](Frag& f, const double* S, int r) {
         if (r == 0) f.be = *reinterpret_cast<const double2*>(S + 2 * TM * BK + off_b);
         else if (r == 1) f.bo = *reinterpret_cast<const double2*>(S + (2 * TM + TN) * BK + off_b);
-        else if (r & 1) f.xm[(r - 2) >> 1] = *reinterpret_cast<const double2*>(S + off_m[(r - 2) >> 1]);
-        else f.xf[(r - 2) >> 1] = *reinterpret_cast<const double2*>(S + off_f[(r - 2) >> 1]);
+        else if (r & 1) txm[(r - 2) >> 1] = *reinterpret_cast<const double2*>(S + off_m[(r - 2) >> 1]);
+        else txf[(r - 2) >> 1] = *reinterpret_cast<const double2*>(S + off_f[(r - 2) >> 1]);
+    };
+    // k = 2kq (+1): forward x_k in xf.x (.y), its mirror x_(N-k) at position 7-k of the mirrored tile: xm.y (.x)
+    auto sums_one = [&](Frag& f, int s) {
+        f.sp[s] = double2{txf[s].x + txm[s].y, txf[s].y + txm[s].x};
+        f.dm[s] = double2{txf[s].x - txm[s].y, txf[s].y - txm[s].x};
     };
     auto rd_stage = [&]() -> const double* {            // stage of the next fragment set; moves on
         const double* S = smem + (st_rd >> 3);
@@ -596,15 +605,15 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         const double* S = rd_stage();
 #pragma unroll
         for (int r = 0; r < NR; ++r) read_one(f, S, r);
+#pragma unroll
+        for (int s = 0; s < SW; ++s) sums_one(f, s);
     };
-    // MFMA i of a tile.  k = 2kq (+1): forward x_k in xf.x (.y), its mirror x_(N-k) at position 7-k of the mirrored tile:
-    // xm.y (.x); first the 2 SW MFMAs of the tile's first k-step, then those of the second
+    // MFMA i of a tile: first the 2 SW MFMAs of the tile's first k-step, then those of the second
     auto mfma_one = [&](const Frag& f, int i) {
         const int s = (i % (2 * SW)) >> 1;
         const bool second = i >= 2 * SW, odd = i & 1;
-        const double xa = second ? f.xf[s].y : f.xf[s].x, xb = second ? f.xm[s].x : f.xm[s].y;
-        if (!odd) acc_a[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa + xb, second ? f.be.y : f.be.x, acc_a[s], 0, 0, 0);
-        else      acc_b[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa - xb, second ? f.bo.y : f.bo.x, acc_b[s], 0, 0, 0);
+        if (!odd) acc_a[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(second ? f.sp[s].y : f.sp[s].x, second ? f.be.y : f.be.x, acc_a[s], 0, 0, 0);
+        else      acc_b[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(second ? f.dm[s].y : f.dm[s].x, second ? f.bo.y : f.bo.x, acc_b[s], 0, 0, 0);
     };
     auto multiply = [&](const Frag& f) {
 #pragma unroll
@@ -639,6 +648,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
                 } else if (i < GR + L) {
                     if (more) issue_one(i - GR);
                 }
+                if (i >= NM - SW) sums_one(nxt, i - (NM - SW));     // the A operands of tile kt+1: its x fragments were read >= 2 gaps ago
                 __builtin_amdgcn_sched_barrier(0);
             }
         };

@@ -77,6 +77,12 @@ FORMS = {
     "abl1_node_off": dict(overlap_mode=3, sym_ct=7, pass_order=1, sym_ablate=32),
     "abl1_epi_off": dict(overlap_mode=3, sym_ct=7, pass_order=1, sym_ablate=4),
     "abl1_node_off_epi_off": dict(overlap_mode=3, sym_ct=7, pass_order=1, sym_ablate=36),
+    "sw3_node_off": dict(overlap_mode=3, sym_ct=8, sym_ablate=32),
+    "sw6_node_off": dict(overlap_mode=3, sym_ct=5, sym_ablate=32),
+    "sw2_node_off_epi_off": dict(overlap_mode=3, sym_ct=6, sym_ablate=36),
+    "sw3_node_off_epi_off": dict(overlap_mode=3, sym_ct=8, sym_ablate=36),
+    "sw6_node_off_epi_off": dict(overlap_mode=3, sym_ct=5, sym_ablate=36),
+    "sw1_node_off_epi_off": dict(overlap_mode=3, sym_ct=7, sym_ablate=36),
     "abl_x": dict(overlap_mode=3, sym_ct=6, sym_ablate=8),
     "abl_panels": dict(overlap_mode=3, sym_ct=6, sym_ablate=64),
     "abl_epi": dict(overlap_mode=3, sym_ct=6, sym_ablate=4),
