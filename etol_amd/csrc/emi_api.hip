@@ -180,6 +180,14 @@ bool overlapped_path(emi_ctx_t c) {
     return emi::fused_supported(c->model, c->M, c->sym_ct);
 }
 
+// the one-launch pass in its small-batch form (SW = 1, plain stores) is available to this context by the default dispatch
+bool pass_takes_small_batches(emi_ctx_t c) {
+    if (!overlapped_path(c) || (c->overlap_mode != 0 && c->overlap_mode != 3) || c->M % 128 != 0) return false;
+    if (c->rtc) return emi::rtc_pass_supported(c->rtc, c->B, c->M, 1, 1, 0);
+    const emi::SymPlan p = emi::plan_symdefect(c->ns, c->B, c->M, 7, 1, c->sym_cpart, c->sym_gblk, c->sym_cx);
+    return emi::pass_supported(c->model, c->ns, c->B, c->M, p);
+}
+
 int np_total(emi_ctx_t c) { return c->np + c->np_model; }     // rows of the record table, then the model's own (traced) rows
 int nvals_of(emi_ctx_t c) { return c->ns * (c->ns + c->nc) + 2 * c->np + c->np_model * (int)c->pvars.size() + (c->ns + c->nc); }
 int nres_of(emi_ctx_t c) { return c->ns + np_total(c); }
@@ -791,8 +799,11 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         HIP_TRY(c, emi::defect_f64_set_attr());
         c->attr_set = true;
     }
-    // a handful of instances: the MFMA kernels would have a few workgroups to run; a skinny streaming product wins
-    const bool small = defect && !c->f32 && c->B * c->ns <= c->small_rows && emi::defect_small_supported(c->B * c->ns);
+    // a handful of instances: the stand-alone MFMA kernels would have a few workgroups to run and a skinny streaming product wins
+    // (21 us at B = 1) -- unless the whole pass can go as ONE launch with its K range sliced, which is faster still (13 - 15 us for
+    // any batch up to 16 instances: profiles/r03_notes.md section 7)
+    const bool small = defect && !c->f32 && c->B * c->ns <= c->small_rows && emi::defect_small_supported(c->B * c->ns) &&
+                       !(nodes && jac && pass_takes_small_batches(c));
     const bool fused = nodes && defect && !small && overlapped_path(c);
     ProfEvents* pe = nullptr;
     if (c->profile) {
@@ -1340,7 +1351,8 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
 
 int emi_last_path(emi_ctx_t c, int* fused) {
     if (!c || !fused) return EMI_ERR_ARG;
-    const bool small = !c->f32 && c->B > 0 && c->B * c->ns <= c->small_rows && emi::defect_small_supported(c->B * c->ns);
+    const bool small = !c->f32 && c->B > 0 && c->B * c->ns <= c->small_rows && emi::defect_small_supported(c->B * c->ns) &&
+                       !pass_takes_small_batches(c);
     *fused = (!small && overlapped_path(c)) ? 1 : 0;
     return EMI_OK;
 }

@@ -196,7 +196,8 @@ inline PassRole pass_role_of(int j, int nm, int nn, int order) {
 struct PassArgs {
     SymDefectArgs s;
     NodeArgs<double> n;
-    int nm8, nn8;           // MFMA / node workgroups per XCD
+    int nm8, nn8;           // MFMA / node workgroups per XCD (counts rounded up to a multiple of 8 ...
+    int nm, nn;             // ... the workgroups past these real counts do nothing)
     int nbx;                // node chunks per instance
 };
 

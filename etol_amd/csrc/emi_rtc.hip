@@ -271,9 +271,7 @@ int rtc_pass_sw_large(const RtcModel* m) { return m ? m->sw_large : 0; }
 bool rtc_pass_supported(const RtcModel* m, int B, int M, int sw, int ks, int store_mode) {
     if (!m || !m->pass_small || ks > 1 || M % 128 != 0) return false;
     if (!((sw == 1 && store_mode != 2) || (sw == m->sw_large && store_mode == 2))) return false;
-    const int nm = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64) * (m->ns / sw);
-    const int nn = ((M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS)) * B;
-    return nm % 8 == 0 && nn % 8 == 0;
+    return B >= 1 && m->ns % sw == 0;
 }
 
 hipError_t rtc_launch_pass(RtcModel* m, const SymDefectArgs& sa, const NodeArgs<double>& na, int sw, hipStream_t s) {
@@ -284,11 +282,12 @@ hipError_t rtc_launch_pass(RtcModel* m, const SymDefectArgs& sa, const NodeArgs<
     const int nm = mtiles * ntiles * (m->ns / sw);
     a.nbx = (na.M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS);
     const int nn = a.nbx * na.B;
-    if (nm % 8 || nn % 8) return hipErrorInvalidConfiguration;
-    a.nm8 = nm / 8;
-    a.nn8 = nn / 8;
+    a.nm = nm;
+    a.nn = nn;
+    a.nm8 = (nm + 7) / 8;
+    a.nn8 = (nn + 7) / 8;
     const size_t lds = (size_t)3 * ((2 * sw * FUSED_TI + 2 * 64 + 63) / 64 * 64) * 8 * sizeof(double);     // 3 ring stages
-    return launch(na.store_mode == 2 ? m->pass_large : m->pass_small, dim3(nm + nn), dim3(256), lds, s, &a, sizeof a);
+    return launch(na.store_mode == 2 ? m->pass_large : m->pass_small, dim3(8 * (a.nm8 + a.nn8)), dim3(256), lds, s, &a, sizeof a);
 }
 
 hipError_t rtc_launch_nodes_nt(RtcModel* m, const NodeArgs<double>& a, hipStream_t s) {

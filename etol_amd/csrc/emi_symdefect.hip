@@ -171,9 +171,10 @@ static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<doub
     const int nm = mtiles * ntiles * (NS / SW) * (sa.ksplit > 1 ? sa.ksplit : 1);
     a.nbx = (na.M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS);
     const int nn = a.nbx * na.B;
-    if (nm % 8 || nn % 8) return hipErrorInvalidConfiguration;
-    a.nm8 = nm / 8;
-    a.nn8 = nn / 8;
+    a.nm = nm;
+    a.nn = nn;
+    a.nm8 = (nm + 7) / 8;
+    a.nn8 = (nn + 7) / 8;
     const size_t lds = (size_t)NST * ((2 * SW * FUSED_TI + 2 * 64 + 63) / 64 * 64) * 8 * sizeof(double);
     static bool attr_done[4] = {false, false, false, false};
     const int st = (na.store_mode >= 0 && na.store_mode <= 3) ? na.store_mode : 0;   // result stores: plain / sc1 (write-through) / non-temporal / nt sc1
@@ -184,7 +185,7 @@ static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<doub
         if (e != hipSuccess) return e;
         attr_done[st] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(nm + nn), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(8 * (a.nm8 + a.nn8)), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -206,9 +207,7 @@ static hipError_t launch_pass_planned(const SymDefectArgs& sa, const NodeArgs<do
 bool pass_supported(int model, int ns, int B, int M, const SymPlan& p) {
     if (p.ring1 || p.sw < 1 || (model != EMI_MODEL_POINTMASS2D && model != EMI_MODEL_QUADROTOR2D)) return false;
     if (M % 128 != 0 || ns % p.sw != 0) return false;
-    const int nm = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64) * (ns / p.sw) * (p.ks > 1 ? p.ks : 1);
-    const int nn = ((M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS)) * B;
-    return nm % 8 == 0 && nn % 8 == 0;
+    return B >= 1;
 }
 
 hipError_t launch_pass(int model, const SymDefectArgs& sa, const NodeArgs<double>& na, hipStream_t s, const SymPlan& p) {

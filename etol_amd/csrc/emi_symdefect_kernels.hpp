@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void emi_symdefect_combine_kernel(SymDefectArg
 // Roles are dealt per XCD (blocks b, b+8, ... share one): block j of an XCD is an MFMA block when
 // floor((j+1) nm / t) > floor(j nm / t), nm of the XCD's t blocks being MFMA blocks -- evenly interleaved, so both
 // roles are resident on every CU throughout, and the MFMA blocks of an XCD are a contiguous run of tiles (they
-// share X and De/Do panels in that XCD's L2).  Requires nm % 8 == 0 and nn % 8 == 0 (the launcher checks).
+// share X and De/Do panels in that XCD's L2).  Counts that are no multiple of 8 are rounded up: the surplus workgroups return at once.
 // ---------------------------------------------------------------------------------------------
 
 #define EMI_STR2(x) #x
@@ -802,12 +802,15 @@ __global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs
     const PassRole role = pass_role_of(j, a.nm8, a.nn8, a.s.mfma_first);
     if (a.s.ablate & (role.mfma ? 16 : 32)) return;    // diagnostics: one of the two roles does nothing
     if (role.mfma) {
+        const int tid = xcd * a.nm8 + role.index;
+        if (tid >= a.nm) return;                        // (the role's count rounded up to a multiple of 8: whole workgroup, before any barrier)
         // the MFMA role is the latency chain of a small pass (64 dependent K tiles); the streaming role beside it on the
         // same SIMDs waits on memory most of the time: instruction arbitration goes to the MFMA waves first
         __builtin_amdgcn_s_setprio(3);
-        emi_ring2_body<Model, SW, NST>(a.s, xcd * a.nm8 + role.index);
+        emi_ring2_body<Model, SW, NST>(a.s, tid);
     } else {
         const int nid = xcd * a.nn8 + role.index;
+        if (nid >= a.nn) return;
         emi_nodes_body<double, Model, VEC, true, false, ST>(a.n, nid % a.nbx, nid / a.nbx, a.nbx);
     }
 }

@@ -216,9 +216,9 @@ def test_fused_and_general_kernels_agree(built):
             recs[:, :, 1:4] = np.random.default_rng(2).uniform(0.5, 3, (B, nobs, 3))
         ev.set_batch(B)
         ev.set_path(recs, 0, 1)
-        small_rows = B * X.shape[1] <= 24          # few instances: the skinny streaming defect kernel is the default
-        assert ev.uses_fused_kernel == (not small_rows)
+        assert ev.uses_fused_kernel                # (few instances too: the one-launch pass with a sliced K range, not the skinny kernel)
         by_default = ev.eval_host(X, U)
+        assert "emi_pass_f64_kernel" in ev.last_defect_kernel
         ev.set_option("small_rows", 0)             # the MFMA paths, whatever the batch
         assert ev.uses_fused_kernel
         fused = ev.eval_host(X, U)
@@ -249,7 +249,12 @@ def test_fused_and_general_kernels_agree(built):
         check(c, ev, by_default, ref)
         assert np.array_equal(by_default[1], fused[1]) and np.array_equal(by_default[2], fused[2])
         assert np.array_equal(fused[1], general[1])            # node work is the same arithmetic
-        assert np.array_equal(fused_nojac[0], fused[0]) and np.array_equal(fused_nojac[2], fused[2])
+        # (without the Jacobian the pass goes as two launches with an unsplit K range: the defect rows of a small batch agree
+        # with the K-sliced one-launch sum to rounding, everything else bit for bit)
+        ns = X.shape[1]
+        s = np.einsum("kj,bij->bik", np.abs(ev.D), np.abs(X)) + 1.0
+        assert (np.abs(fused_nojac[0][:, :ns] - fused[0][:, :ns]) / s).max() < 1e-13
+        assert np.array_equal(fused_nojac[0][:, ns:], fused[0][:, ns:]) and np.array_equal(fused_nojac[2], fused[2])
 
 
 def test_f32_context_fixedwing(built):
@@ -701,7 +706,7 @@ def test_default_dispatch_on_random_shapes_matches_the_general_path(built):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     worst, kinds = mod.run(argparse.Namespace(cases=30, seed=7, big=False))
-    assert worst < 1e-11 and len(kinds) >= 3, (worst, kinds)
+    assert worst < 1e-11 and len(kinds) >= 2, (worst, kinds)      # (since the grid is padded, every shape goes as the one-launch pass: SW = 1 / 2)
 
 
 def test_very_large_batches_are_evaluated_in_slices_with_the_same_results(built):
@@ -782,10 +787,11 @@ def _expected_default_form(B, M=1024):
     return "emi_pass_f64_kernel<SW=1> (MFMA + node roles, one launch" + (f", {ks} K slices" if ks > 1 else ")")
 
 
-@pytest.mark.parametrize("B", [16, 64, 128, 256, 512, 1024, 2064, 2560])
+@pytest.mark.parametrize("B", [1, 3, 5, 16, 64, 128, 256, 512, 1024, 2064, 2560])
 def test_default_dispatch_at_the_benchmarked_shapes_matches_the_oracle(built, B):
-    """The shapes bench.py and config 4 actually run -- M = 1024, 20 PER-INSTANCE keep-outs, B = 16 / 64 (SW = 1 with 4 / 2 K slices
-    per tile, combined in-kernel by ticket), 128 (the shard of config 4:
+    """The shapes bench.py and config 4 actually run -- M = 1024, 20 PER-INSTANCE keep-outs, B = 1 / 3 / 5 (role counts that are no
+    multiple of 8: the grid is padded with workgroups that return at once), 16 / 64 (SW = 1 with 4 / 2 K slices per tile, combined
+    in-kernel by ticket), 128 (the shard of config 4:
     one launch, SW = 1, MFMA workgroups first, plain stores), 256 (SW = 2, MFMA workgroups first, non-temporal stores), 512 (SW = 2, MFMA
     workgroups at 1.5 x the even density), 1024 (the headline: SW = 2, evenly interleaved, 2 column partitions), 2064 (one launch of
     2048 instances + a 16-instance tail), 2560 (one launch in the grouped tile order) -- through the DEFAULT dispatch (no option

@@ -83,6 +83,7 @@ FORMS = {
     "sw3_node_off_epi_off": dict(overlap_mode=3, sym_ct=8, sym_ablate=36),
     "sw6_node_off_epi_off": dict(overlap_mode=3, sym_ct=5, sym_ablate=36),
     "sw1_node_off_epi_off": dict(overlap_mode=3, sym_ct=7, sym_ablate=36),
+    "no_skinny": dict(small_rows=0),
     "abl_x": dict(overlap_mode=3, sym_ct=6, sym_ablate=8),
     "abl_panels": dict(overlap_mode=3, sym_ct=6, sym_ablate=64),
     "abl_epi": dict(overlap_mode=3, sym_ct=6, sym_ablate=4),
@@ -121,7 +122,7 @@ FORMS = {
     "one_sw1_g4c4": dict(overlap_mode=3, sym_ct=7, sym_gblk=4, sym_cx=4),
     "one_sw3_cp4": dict(overlap_mode=3, sym_ct=8, sym_cpart=4),
 }
-RESET = dict(overlap_mode=0, sym_ct=0, pass_order=-1, slice=0, node_store=-1, sym_cpart=0, sym_gblk=0, sym_cx=0, sym_nst=3, sym_ksplit=0, sym_ablate=0)
+RESET = dict(small_rows=24, overlap_mode=0, sym_ct=0, pass_order=-1, slice=0, node_store=-1, sym_cpart=0, sym_gblk=0, sym_cx=0, sym_nst=3, sym_ksplit=0, sym_ablate=0)
 
 
 def main():
