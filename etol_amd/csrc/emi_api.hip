@@ -858,22 +858,21 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             // B = 8: 0.0204 / 0.0148 / 0.0140, 16: 0.0235 / 0.0179 / 0.0155, 32: 0.0242 / 0.0190 / 0.0192, 64: 0.0257 / 0.0218 / 0.0261,
             // 80: 0.0263 / 0.0249 / 0.0312, 96: 0.0288 / 0.0290 / 0.0407, 128: 0.0333 / 0.0387 / 0.0496 (from ~500 workgroups the
             // split loses: three and more MFMA waves per SIMD share the matrix pipe and the node role starts behind them).
-            int ks_want = c->sym_ksplit;
-            if (ks_want == 0 && !c->rtc && auto_mode && (c->sym_ct == 0 || c->sym_ct == 4)) ks_want = plan.tiles * 4 <= 256 ? 4 : (plan.tiles * 2 <= 512 ? 2 : 1);
-            if (ks_want > 1) {
-                const int ct_now = plan.sw == c->ns ? 5 : (plan.sw == 2 ? 6 : (plan.sw == 3 ? 8 : 7));
-                plan = emi::plan_symdefect(c->ns, c->B, c->M, ct_now, ks_want, c->sym_cpart, c->sym_gblk, c->sym_cx);
-                plan.nst = c->sym_nst;
-            } else {
-                plan.ks = 1;
-            }
             if (c->rtc) {
                 // a run-time compiled model holds two instantiations of the pass kernel: SW = 1 with plain stores (small
                 // batches) and SW = 2 (1 for an odd number of states) with non-temporal stores (large ones)
                 const int swl = emi::rtc_pass_sw_large(c->rtc);
                 plan = emi::plan_symdefect(c->ns, c->B, c->M, (na.store_mode == 2 && swl == 2) ? 6 : 7, 1, c->sym_cpart, gblk_auto, c->sym_cx);
-                plan.nst = 3;
             }
+            int ks_want = c->sym_ksplit;
+            if (ks_want == 0 && auto_mode && (c->sym_ct == 0 || c->sym_ct == 4)) ks_want = plan.tiles * 4 <= 256 ? 4 : (plan.tiles * 2 <= 512 ? 2 : 1);
+            if (ks_want > 1) {
+                const int ct_now = plan.sw == c->ns ? 5 : (plan.sw == 2 ? 6 : (plan.sw == 3 ? 8 : 7));
+                plan = emi::plan_symdefect(c->ns, c->B, c->M, ct_now, ks_want, c->sym_cpart, c->rtc ? gblk_auto : c->sym_gblk, c->sym_cx);
+            } else {
+                plan.ks = 1;
+            }
+            plan.nst = c->rtc ? 3 : c->sym_nst;
             // (round 2 measured "first" against "interleaved" WITH PLAIN STORES at 256 instances and found interleaved ahead,
             // 0.0727 / 0.0748; with non-temporal stores "first" wins up to 448 instances: 256: 0.0581 against 0.0756 interleaved)
             sa.mfma_first = c->pass_order >= 0 ? c->pass_order : (tiles16 < 240 ? 1 : (tiles16 < 384 ? 150 : 0));

@@ -269,7 +269,7 @@ int rtc_pass_sw_large(const RtcModel* m) { return m ? m->sw_large : 0; }
 
 // as pass_supported (emi_symdefect.hip) for the two instantiations a model program holds
 bool rtc_pass_supported(const RtcModel* m, int B, int M, int sw, int ks, int store_mode) {
-    if (!m || !m->pass_small || ks > 1 || M % 128 != 0) return false;
+    if (!m || !m->pass_small || ks < 1 || M % 128 != 0) return false;       // (K slices are a run-time argument of the kernel)
     if (!((sw == 1 && store_mode != 2) || (sw == m->sw_large && store_mode == 2))) return false;
     return B >= 1 && m->ns % sw == 0;
 }
@@ -279,7 +279,7 @@ hipError_t rtc_launch_pass(RtcModel* m, const SymDefectArgs& sa, const NodeArgs<
     a.s = sa;
     a.n = na;
     const int mtiles = (sa.B + FUSED_TI - 1) / FUSED_TI, ntiles = (sa.M / 2) / 64;
-    const int nm = mtiles * ntiles * (m->ns / sw);
+    const int nm = mtiles * ntiles * (m->ns / sw) * (sa.ksplit > 1 ? sa.ksplit : 1);
     a.nbx = (na.M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS);
     const int nn = a.nbx * na.B;
     a.nm = nm;
