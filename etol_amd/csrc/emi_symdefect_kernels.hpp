@@ -414,34 +414,55 @@ EMI_DEV void ring_epilogue_s0(const SymDefectArgs& a, const d4 (&acc_a)[SW], con
         }
         return;
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int inst = inst0 + kq + 4 * i;
-        if (inst >= B || (a.ablate & 4)) continue;
+    // ... so the four instances go through a two-deep pipeline instead: the X / U values of instance i+1 are requested before f of
+    // instance i is evaluated and stored (one exposed memory round trip per workgroup instead of four; the epilogue is 8 % of the
+    // pass at 1024 instances, measured by switching it off: profiles/r03_notes.md section 8)
+    if (a.ablate & 4) return;
+    auto load_z = [&](double (&z)[2][NV], int i) {
+        int inst = inst0 + kq + 4 * i;
+        inst = inst < B ? inst : B - 1;                    // (rows past the batch: loaded from the last instance, never stored)
         const double* __restrict__ Xb = a.X + (size_t)inst * NS * M;
         const double* __restrict__ Ub = a.U + (size_t)inst * NC * M;
-        double* __restrict__ Rb = a.RES + (size_t)inst * a.nres * M;
-        double hf[2][SW];
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
             const int node = side == 0 ? node_f : node_m;
-            double z[NV], f[NS];
 #pragma unroll
-            for (int v = 0; v < NS; ++v) z[v] = Xb[(size_t)v * M + node];
+            for (int v = 0; v < NS; ++v) z[side][v] = Xb[(size_t)v * M + node];
 #pragma unroll
-            for (int v = 0; v < NC; ++v) z[NS + v] = Ub[(size_t)v * M + node];
-            Model::f(a.P, z, side == 0 ? t_f : t_m, f);
-#pragma unroll
-            for (int s = 0; s < SW; ++s) hf[side][s] = a.h * f[S0 + s];
+            for (int v = 0; v < NC; ++v) z[side][NS + v] = Ub[(size_t)v * M + node];
         }
+    };
+    double zc[2][NV], zn[2][NV];
+    load_z(zc, 0);
 #pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const int node = side == 0 ? node_f : node_m;
+    for (int i = 0; i < 4; ++i) {
+        if (i < 3) load_z(zn, i + 1);
+        const int inst = inst0 + kq + 4 * i;
+        if (inst < B) {
+            double* __restrict__ Rb = a.RES + (size_t)inst * a.nres * M;
+            double hf[2][SW];
 #pragma unroll
-            for (int s = 0; s < SW; ++s) {
-                const double dx = side == 0 ? acc_a[s][i] + acc_b[s][i] : acc_b[s][i] - acc_a[s][i];
-                Rb[(size_t)(S0 + s) * M + node] = dx - hf[side][s];
+            for (int side = 0; side < 2; ++side) {
+                double f[NS];
+                Model::f(a.P, zc[side], side == 0 ? t_f : t_m, f);
+#pragma unroll
+                for (int s = 0; s < SW; ++s) hf[side][s] = a.h * f[S0 + s];
             }
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int node = side == 0 ? node_f : node_m;
+#pragma unroll
+                for (int s = 0; s < SW; ++s) {
+                    const double dx = side == 0 ? acc_a[s][i] + acc_b[s][i] : acc_b[s][i] - acc_a[s][i];
+                    Rb[(size_t)(S0 + s) * M + node] = dx - hf[side][s];
+                }
+            }
+        }
+        if (i < 3) {
+#pragma unroll
+            for (int side = 0; side < 2; ++side)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) zc[side][v] = zn[side][v];
         }
     }
 }
