@@ -750,6 +750,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         }
         if (tid == 0) __hip_atomic_store(a.tile_ticket + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __builtin_amdgcn_s_setprio(0);      // the epilogue gives the instruction arbiter back to the waves still in their K loops (0.5 - 1 % of the pass)
     ring_epilogue<Model, SW>(a, acc_a, acc_b, inst0, i0, s0, wid, r16, kq);
 }
 
