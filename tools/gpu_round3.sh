@@ -19,7 +19,7 @@ cd $R
 say "pmc traffic"; bash tools/pmc_traffic.sh "1024 128 16384" > gpurun_out/pmc_traffic.log 2>&1; grep "fetch" gpurun_out/pmc_traffic.log
 say "pmc busy"; bash tools/pmc_busy.sh > gpurun_out/pmc_busy.log 2>&1; grep "rc=" gpurun_out/pmc_busy.log | tr '\n' ' '; echo
 say "batch sweep"; timeout -k 10 600 python tools/batch_sweep.py > gpurun_out/batch_sweep.log 2>&1; tail -3 gpurun_out/batch_sweep.log | cut -c1-200
-say "mid sweep"; rm -f gpurun_out/mid_sweep.jsonl; timeout -k 10 500 python tools/mid_sweep.py --batches 64,128,192,256,320,384,448,512,576,640,704,768,896,1024,2048,4096,16384 --forms default --rounds 3 --ms 40 > gpurun_out/mid_sweep.log 2>&1; tail -2 gpurun_out/mid_sweep.log | cut -c1-100
+say "mid sweep"; rm -f gpurun_out/mid_sweep.jsonl; timeout -k 10 500 python tools/mid_sweep.py --batches 1,4,16,64,128,192,256,320,384,448,512,576,640,704,768,896,1024,2048,4096,16384 --forms default --rounds 3 --ms 40 > gpurun_out/mid_sweep.log 2>&1; tail -2 gpurun_out/mid_sweep.log | cut -c1-100
 say "solve times"; timeout -k 10 300 python tools/solve_times.py > gpurun_out/solve_times.log 2>&1; tail -8 gpurun_out/solve_times.log | cut -c1-160
 export EMI_MC_GATHER=0
 : > gpurun_out/montecarlo.jsonl
