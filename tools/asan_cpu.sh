@@ -29,7 +29,9 @@ H.harness_solve_example1_oracle.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c
 H.harness_solve_quadrotor_oracle.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, D, C.POINTER(C.c_int), D, D, C.c_int, C.POINTER(C.c_int)]
 H.harness_set_linear_solver.argtypes = [C.c_char_p]
 orc = (ROOT + "/oracle/liboracle.so").encode()
-for ls in (b"host", b"device"):
+H.harness_set_scaling.argtypes = [C.c_int]
+for sc, ls in ((-1, b"host"), (-1, b"device"), (1, b"host"), (1, b"device")):      # (1: Alg::scaling = "automatic", the ScaledEvaluator wrapper)
+    H.harness_set_scaling(sc)
     H.harness_set_linear_solver(ls)
     for wo in (0, 1):
         X, U = np.zeros(128), np.zeros(128); cost, M, it = C.c_double(), C.c_int(), C.c_int()
@@ -39,6 +41,7 @@ for ls in (b"host", b"device"):
         X, U = np.zeros(6 * 64), np.zeros(2 * 64); cost, M, it = C.c_double(), C.c_int(), C.c_int()
         rc = H.harness_solve_quadrotor_oracle(orc, 24, 0.16, nd, 1e-8, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D), 64, C.byref(it))
         print("quadrotor", ls, nd, rc, cost.value, it.value, H.harness_last_message().decode())
+H.harness_set_scaling(-1)
 H.harness_solve_fixedwing_oracle.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, D, C.POINTER(C.c_int), D, D, C.c_int, C.POINTER(C.c_int)]
 H.harness_set_linear_solver(b"device")
 X, U = np.zeros(12 * 32), np.zeros(4 * 32); cost, M, it = C.c_double(), C.c_int(), C.c_int()
