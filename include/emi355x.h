@@ -299,11 +299,16 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * "sym_order" (default 1): workgroup -> tile order within an XCD (sym_ct 1..3).
  * "overlap_mode": how the two kernels share the chip.  0 (default) = by batch size;
  * 2 = two streams (fork / join through events); 3 = ONE launch, MFMA-role and
- * node-role workgroups in one grid with COST finished in-kernel (chosen below 192
- * tiles, e.g. the 128-instance shard of config 4, and from 384 tiles, i.e. from
- * 768 instances at 1024 nodes); 1 = one stream, back to back.
- * "sym_ksplit": K slices per tile of the state-split ring (0 = none unless forced;
- * > 1: partial sums through a slab, summed in slice order).  "sym_combine": 1
+ * node-role workgroups in one grid with COST finished in-kernel (what 0 chooses at
+ * every batch size, one instance included, where the model has a pass instantiation);
+ * 1 = one stream, back to back.
+ * "sym_ksplit": K slices per tile of the state-split ring: 0 (default) = chosen by the
+ * default dispatch for small batches (4 slices while the MFMA role stays within 256
+ * workgroups, 2 within 512: up to 16 / 80 instances at 1024 nodes), 1 = never,
+ * 2 / 4 / 8 forced; partial sums through a slab, summed in slice order (bitwise
+ * reproducible, not bitwise the unsplit sum).
+ * "small_rows" (default 24): up to this many rows B*ns the skinny streaming defect
+ * kernel takes a pass that cannot go as one launch (0: never).  "sym_combine": 1
  * (default) the workgroup that draws a tile's last ticket adds the slices
  * in-kernel, 0 a second launch does; bitwise the same result.
  * "sym_cpart": tile order of the state-split ring.  0 (default) = by mesh and batch
@@ -324,8 +329,8 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * the Schur path starts at the dual regularisation level that worked last on this
  * mesh; "kkt_debug", "kkt_cholesky", "kkt_chol_panel", "kkt_batched_max_nodes",
  * "kkt_potrf_lock": diagnostics, see csrc/emi_kkt.hip).
- * "slice": batches above 2 * slice instances are evaluated in pieces of `slice` instances (default 1024; 0 = never,
- * one launch over the whole batch).
+ * "slice": > 0: batches above 2 * slice instances are evaluated in pieces of `slice` instances; 0 (default): a batch above
+ * 2048 instances goes as one launch over its multiple of 256 instances plus one for the remainder.
  * "sym_ablate": diagnostics only, results invalid.                             */
 int emi_set_option(emi_ctx_t ctx, const char* name, int value);
 /* 1 if emi_eval(EMI_EVAL_ALL) currently takes the overlapped path             */
