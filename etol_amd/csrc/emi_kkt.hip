@@ -43,7 +43,8 @@ namespace emi {
 // Diagnostic switches of the factorisation (process-wide, set through emi_set_option "kkt_*"; the defaults are what
 // every number in profiles/ was measured with)
 struct KktTuning {
-    std::atomic<int> own_cholesky{1};       // "kkt_cholesky": 1 the library's blocked Cholesky, 0 rocsolver_dpotrf (+ confirmation on a copy)
+    std::atomic<int> chol_outer{768};       // "kkt_chol_outer": columns of an outer panel of the two-level Cholesky
+    std::atomic<int> own_cholesky{2};       // "kkt_cholesky": 2 the library's blocked Cholesky in two-level form from 1024 rows (default), 1 one level, 0 rocsolver_dpotrf (+ confirmation on a copy)
     std::atomic<int> own_panel{1};          // "kkt_chol_panel": 1 own panel kernel, 0 rocblas_dtrsm
     std::atomic<int> batched_max_nodes{256};// "kkt_batched_max_nodes": largest mesh with the batched Schur-block build
     std::atomic<int> debug{0};              // "kkt_debug": 1 retries and fallbacks on stderr, 2 also the blocks around a failing pivot
@@ -54,7 +55,8 @@ struct KktTuning {
 };
 static KktTuning g_tune;
 bool kkt_set_option(const char* name, int value) {
-    if (!strcmp(name, "kkt_cholesky")) { g_tune.own_cholesky = value != 0; return true; }
+    if (!strcmp(name, "kkt_chol_outer")) { g_tune.chol_outer = value; return true; }
+    if (!strcmp(name, "kkt_cholesky")) { g_tune.own_cholesky = value < 0 ? 0 : (value > 2 ? 2 : value); return true; }
     if (!strcmp(name, "kkt_chol_panel")) { g_tune.own_panel = value != 0; return true; }
     if (!strcmp(name, "kkt_batched_max_nodes")) { g_tune.batched_max_nodes = value; return true; }
     if (!strcmp(name, "kkt_debug")) { g_tune.debug = value; return true; }
@@ -564,9 +566,52 @@ int chol_blocked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, 
     return EMI_OK;
 }
 
-// which Cholesky: 1 (default) the blocked one above, 0 rocsolver_dpotrf with the confirmation on a copy
+// Two-level form of chol_blocked: the 64-column steps update only the rest of their 512-column OUTER panel (one small dgemm
+// each), and the trailing matrix beyond the outer panel gets one rank-512 dsyrk per outer step instead of eight rank-64 ones
+// (same flops, 12 large updates instead of 96 small ones at 6144 rows).  The inner dgemm writes whole rectangles, so the strict
+// upper triangle inside an outer panel's diagonal block is scratch afterwards -- every consumer of the factor reads its lower
+// triangle only (dtrtri / dtrsm / dpotrs with fill_lower, the gemv updates of blk_potrs on blocks below the diagonal).
+int chol_blocked2(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, rocblas_int* hinfo, std::string* err) {
+    const int NB2 = std::max(128, (g_tune.chol_outer.load() / CHOL_NB) * CHOL_NB);
+    KKT_HIP(hipMemsetAsync(w->info, 0, sizeof(rocblas_int), stream));
+    if (!w->chol_blk) KKT_HIP(hipMalloc((void**)&w->chol_blk, (CHOL_NB * CHOL_NB + CHOL_NB) * sizeof(double)));
+    const double one = 1.0, mone = -1.0;
+    for (int J0 = 0; J0 < n; J0 += NB2) {
+        const int Jend = std::min((int)n, J0 + NB2);
+        for (int j0 = J0; j0 < Jend; j0 += CHOL_NB) {
+            const int nb = std::min(CHOL_NB, (int)n - j0), rest = (int)n - j0 - nb;
+            hipLaunchKernelGGL(emi_chol_diag_kernel, dim3(1), dim3(256), 0, stream, A, (int)n, j0, nb, (int*)w->info, w->chol_blk);
+            if (rest <= 0) continue;
+            hipLaunchKernelGGL(emi_chol_panel_kernel, dim3((rest + 63) / 64), dim3(64), 0, stream, A, (int)n, (int)n, j0,
+                               (const double*)w->chol_blk);
+            const int wc = Jend - (j0 + nb);            // columns of the outer panel right of this step
+            if (wc > 0) {
+                double* P = A + (size_t)j0 * n + j0 + nb;                 // rest x nb, the step's panel below its diagonal block
+                double* A22 = A + (size_t)(j0 + nb) * n + j0 + nb;        // rest x wc
+                KKT_RB(rocblas_dgemm(w->handle, rocblas_operation_none, rocblas_operation_transpose, rest, wc, nb, &mone, P, n, P, n, &one,
+                                     A22, n));
+            }
+        }
+        const int rest2 = (int)n - Jend, W = Jend - J0;
+        if (rest2 > 0) {
+            double* P2 = A + (size_t)J0 * n + Jend;                       // rest2 x W
+            double* A33 = A + (size_t)Jend * n + Jend;
+            KKT_RB(rocblas_dsyrk(w->handle, rocblas_fill_lower, rocblas_operation_none, rest2, W, &mone, P2, n, &one, A33, n));
+        }
+    }
+    KKT_HIP(hipGetLastError());
+    KKT_HIP(hipMemcpyAsync(hinfo, w->info, sizeof *hinfo, hipMemcpyDeviceToHost, stream));
+    KKT_HIP(hipStreamSynchronize(stream));
+    return EMI_OK;
+}
+
+// which Cholesky ("kkt_cholesky"): 2 (default) the two-level form from 1024 rows (below: the one-level one), 1 one level always,
+// 0 rocsolver_dpotrf with the confirmation on a copy.  Factorisation of the 1024 / 512 / 256-node Schur complement (S build
+// included; tools/scratch/chol_time.py, one box): one level 16.85 / 7.38 / 3.36 ms, outer panels of 256 / 512 / 768 / 1024
+// columns 14.68 / 13.96 / 13.36 / 13.28 ms at 1024 nodes, 5.79 and 2.64 ms with 768 at 512 and 256 nodes.
 int cholesky(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, rocblas_int* hinfo, std::string* err) {
     const int own = g_tune.own_cholesky.load();
+    if (own == 2 && n >= 2 * 512) return chol_blocked2(w, stream, n, A, hinfo, err);
     return own ? chol_blocked(w, stream, n, A, hinfo, err) : potrf_checked(w, stream, n, A, hinfo, err);
 }
 

@@ -327,8 +327,9 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * library's block-inverse triangular solves instead of rocBLAS trsv; "kkt_primal_levels" 1 (default): primal regularisation levels behind the
  * dual ones before the LU fallback; "kkt_sticky_reg" 1 (default):
  * the Schur path starts at the dual regularisation level that worked last on this
- * mesh; "kkt_debug", "kkt_cholesky", "kkt_chol_panel", "kkt_batched_max_nodes",
- * "kkt_potrf_lock": diagnostics, see csrc/emi_kkt.hip).
+ * mesh; "kkt_cholesky" 2 (default): the library's blocked Cholesky in two-level form from 1024 rows
+ * (outer panels of "kkt_chol_outer" columns, default 768), 1: one level, 0: rocsolver_dpotrf;
+ * "kkt_debug", "kkt_chol_panel", "kkt_batched_max_nodes", "kkt_potrf_lock": diagnostics, see csrc/emi_kkt.hip).
  * "slice": > 0: batches above 2 * slice instances are evaluated in pieces of `slice` instances; 0 (default): a batch above
  * 2048 instances goes as one launch over its multiple of 256 instances plus one for the remainder.
  * "sym_ablate": diagnostics only, results invalid.                             */

@@ -123,6 +123,55 @@ def test_block_inverse_triangular_solves_match_rocblas_trsv(built, M):
     assert np.abs(sols[1] - sols[0]).max() < 1e-9 * (np.abs(sols[0]).max() + 1)
 
 
+@pytest.mark.parametrize("M", [171, 256, 300])
+def test_two_level_cholesky_matches_the_one_level_form(built, M):
+    """"kkt_cholesky" 2 (default from 1024 rows of the Schur complement: 171 nodes and up for 6 states): 64-column steps that update
+    only the rest of their outer panel, one rank-768 dsyrk per outer panel for everything behind it -- against the one-level form
+    (1) and the numpy matrix, with outer panels of 128 / 768 / 2048 columns (partial last panels; one panel = the whole matrix)."""
+    import etol_amd as E
+    from etol_amd import workloads as W
+    ns, nv, nh = 6, 8, 36
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 4.0)
+    ev.set_model(1, W.QUAD_PARAMS)
+    ev.set_batch(1)
+    rng = np.random.default_rng(2000 + M)
+    Qblk = np.zeros((nh, M))
+    for k in range(M):
+        A = rng.standard_normal((nv, nv))
+        Qk = A @ A.T + nv * np.eye(nv)
+        for v in range(nv):
+            for q in range(v + 1):
+                Qblk[v * (v + 1) // 2 + q, k] = Qk[v, q]
+    Jblk = rng.standard_normal((ns * nv, M))
+    for i in range(ns):
+        Jblk[i * nv + i] += np.diag(ev.D)
+    fixed = np.zeros(nv * M, dtype=np.uint8)
+    fixed[np.arange(ns) * M] = 1
+    K = dense_kkt(ev.D, Qblk, Jblk, fixed, 1e-9, M, ns, nv)
+    rhs = rng.standard_normal((nv + ns) * M)
+    b = rhs.copy()
+    b[np.nonzero(fixed)[0]] = 0
+    sols = {}
+    try:
+        for mode, outer in ((1, 768), (2, 128), (2, 768), (2, 2048)):
+            ev.set_option("kkt_cholesky", mode)
+            ev.set_option("kkt_chol_outer", outer)
+            assert ev.kkt_factor(Qblk, Jblk, fixed, 1e-9) == 0
+            x = ev.kkt_solve(rhs)
+            assert np.abs(K @ x - b).max() < 1e-10 * (np.abs(K).max() * np.abs(x).max() + 1), (mode, outer)
+            sols[mode, outer] = x
+            # the low-rank path factorises a second, small matrix with the same routine and solves many right-hand sides (dpotrs)
+            X3 = ev.kkt_solve(np.stack([rhs, 2 * rhs, -rhs]))
+            assert np.abs(X3[0] - x).max() < 1e-9 * (np.abs(x).max() + 1)
+    finally:
+        ev.set_option("kkt_cholesky", 2)
+        ev.set_option("kkt_chol_outer", 768)
+    for k, x in sols.items():
+        assert np.abs(x - sols[1, 768]).max() < 1e-9 * (np.abs(x).max() + 1), k
+    ev.close()
+
+
 def test_schur_method_falls_back_to_lu_for_indefinite_blocks(built):
     """Method 1 needs positive definite node blocks; anything else must silently take the general LU."""
     import etol_amd as E
