@@ -84,6 +84,16 @@ FORMS = {
     "sw6_node_off_epi_off": dict(overlap_mode=3, sym_ct=5, sym_ablate=36),
     "sw1_node_off_epi_off": dict(overlap_mode=3, sym_ct=7, sym_ablate=36),
     "no_skinny": dict(small_rows=0),
+    "po0": dict(pass_order=0),
+    "po1": dict(pass_order=1),
+    "po125": dict(pass_order=125),
+    "po150": dict(pass_order=150),
+    "po200": dict(pass_order=200),
+    "po300": dict(pass_order=300),
+    "po150_cp1": dict(pass_order=150, sym_cpart=1),
+    "po150_cp2": dict(pass_order=150, sym_cpart=2),
+    "po150_cp4": dict(pass_order=150, sym_cpart=4),
+    "po0_cp2": dict(pass_order=0, sym_cpart=2),
     "abl_x": dict(overlap_mode=3, sym_ct=6, sym_ablate=8),
     "abl_panels": dict(overlap_mode=3, sym_ct=6, sym_ablate=64),
     "abl_epi": dict(overlap_mode=3, sym_ct=6, sym_ablate=4),
