@@ -842,7 +842,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             // 448: 0.1035 / 0.1038, 512: 0.1188 / 0.1162, 576: 0.1332 / 0.1777, 640: 0.146 / 0.155, 704: 0.160 / 0.181.
             //   * SW (states per MFMA workgroup): 1 below 128 sixteen-instance x 128-node tiles (more workgroups than CUs), else 2;
             //   * block order (pass_role_of): MFMA workgroups first below 208 tiles (their 64-tile dependency chains start at
-            //     once, the streaming workgroups fill in behind), at 1.25 x the even density up to 384 tiles, evenly
+            //     once, the streaming workgroups fill in behind), at 1.25 x the even density up to 384 tiles, at 1.1 x up to 768, evenly
             //     interleaved from there (B >= 768, where "first" would hold the node role back: 0.288 against 0.222 at 1024);
             //   * stores: fill_node_args (non-temporal from about 256 instances).
             emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, 1, c->sym_cpart, c->sym_gblk, c->sym_cx);
@@ -876,8 +876,9 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             // (round 2 measured "first" against "interleaved" WITH PLAIN STORES at 256 instances and found interleaved ahead,
             // 0.0727 / 0.0748; with non-temporal stores "first" wins up to 448 instances: 256: 0.0581 against 0.0756 interleaved)
             // (end of round 3, one box, e9 node-evals/s at first / 1.25 x / 1.5 x / even: 448 instances 4.21 / 4.41 / 4.22 / 4.31, 512: 3.60 / 4.32 / 4.38 / 4.22,
-            // 640: 3.76 / 4.48 / 4.37 / 4.37, 704: 3.89 / 4.63 / 4.45 / 4.50)
-            sa.mfma_first = c->pass_order >= 0 ? c->pass_order : (tiles16 < 208 ? 1 : (tiles16 < 384 ? 125 : 0));
+            // 640: 3.76 / 4.48 / 4.37 / 4.37, 704: 3.89 / 4.63 / 4.45 / 4.50; ms per pass at even / 1.1 x / 1.25 x: 768: 0.1747 / 0.1696 / 0.1760,
+            // 896: 0.1964 / 0.1959 / 0.2022, 1024: 0.2230 / 0.2200 / 0.2304, 1536: 0.3215 / 0.3219 / 0.3411, 2048: 0.4239 / 0.4227 / 0.4415)
+            sa.mfma_first = c->pass_order >= 0 ? c->pass_order : (tiles16 < 208 ? 1 : (tiles16 < 384 ? 125 : (tiles16 < 768 ? 110 : 0)));
             if (c->rtc ? emi::rtc_pass_supported(c->rtc, c->B, c->M, plan.sw, plan.ks, na.store_mode)
                        : emi::pass_supported(c->model, c->ns, c->B, c->M, plan)) {
                 sa.cpart = plan.cpart; sa.cx = plan.cx;

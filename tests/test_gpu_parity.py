@@ -793,7 +793,7 @@ def test_default_dispatch_at_the_benchmarked_shapes_matches_the_oracle(built, B)
     multiple of 8: the grid is padded with workgroups that return at once), 16 / 64 (SW = 1 with 4 / 2 K slices per tile, combined
     in-kernel by ticket), 128 (the shard of config 4:
     one launch, SW = 1, MFMA workgroups first, plain stores), 256 (SW = 2, MFMA workgroups first, non-temporal stores), 512 (SW = 2, MFMA
-    workgroups at 1.25 x the even density), 1024 (the headline: SW = 2, evenly interleaved, 2 column partitions), 2064 (one launch of
+    workgroups at 1.25 x the even density), 1024 (the headline: SW = 2, MFMA workgroups at 1.1 x the even density, 2 column partitions), 2064 (one launch of
     2048 instances + a 16-instance tail), 2560 (one launch in the grouped tile order) -- through the DEFAULT dispatch (no option
     set), device-pointer form as bench.py calls it, against the CPU oracle on sampled instances that sit on every tile
     edge: 0, 15, 16, B/2, B-1, first / last of every slice.  Outputs are poisoned first: a tile or a role left out shows."""

@@ -86,6 +86,7 @@ FORMS = {
     "no_skinny": dict(small_rows=0),
     "po0": dict(pass_order=0),
     "po1": dict(pass_order=1),
+    "po110": dict(pass_order=110),
     "po125": dict(pass_order=125),
     "po150": dict(pass_order=150),
     "po200": dict(pass_order=200),
