@@ -50,7 +50,7 @@ struct KktTuning {
     std::atomic<int> debug{0};              // "kkt_debug": 1 retries and fallbacks on stderr, 2 also the blocks around a failing pivot
     std::atomic<int> potrf_lock{0};         // "kkt_potrf_lock": serialise rocsolver_dpotrf calls of different host threads
     std::atomic<int> sticky_reg{1};         // "kkt_sticky_reg": start the Schur path at the regularisation level that worked last on this mesh
-    std::atomic<int> block_trsv{1};         // "kkt_block_trsv": 1 single right-hand sides through the block-inverse triangular solves below, 0 rocsolver_dpotrs (trsv)
+    std::atomic<int> block_trsv{1};         // "kkt_block_trsv": 1 single right-hand sides through the block-inverse triangular solves below (gemv form), 2 the same with the library's own diagonal-block kernel, 0 rocsolver_dpotrs (trsv)
     std::atomic<int> primal_levels{1};      // "kkt_primal_levels": 1 primal regularisation levels behind the dual ones before the LU fallback, 0 the round-2 ladder
 };
 static KktTuning g_tune;
@@ -62,7 +62,7 @@ bool kkt_set_option(const char* name, int value) {
     if (!strcmp(name, "kkt_debug")) { g_tune.debug = value; return true; }
     if (!strcmp(name, "kkt_potrf_lock")) { g_tune.potrf_lock = value != 0; return true; }
     if (!strcmp(name, "kkt_sticky_reg")) { g_tune.sticky_reg = value != 0; return true; }
-    if (!strcmp(name, "kkt_block_trsv")) { g_tune.block_trsv = value != 0; return true; }
+    if (!strcmp(name, "kkt_block_trsv")) { g_tune.block_trsv = value < 0 ? 0 : (value > 2 ? 2 : value); return true; }
     if (!strcmp(name, "kkt_primal_levels")) { g_tune.primal_levels = value != 0; return true; }
     return false;
 }
@@ -111,6 +111,8 @@ struct KktWorkspace {
     int linv_n = 0;                // order of the factor the inverses belong to (0: none -- rocsolver_dpotrs is used)
     double* trsv_tmp = nullptr;    // [512] x_j while its block is being multiplied
     size_t cap_trsv_tmp = 0;
+    double* trsv_y = nullptr;      // [n] forward-sweep solution of the gemv form of blk_potrs
+    size_t cap_trsv_y = 0;
     double* chol_blk = nullptr;    // [64][64] + [64]: factorised diagonal block and reciprocal diagonal of the current block column
     double* chol_copy = nullptr;   // the matrix handed to dpotrf, kept until the factorisation is confirmed (potrf_checked)
     size_t cap_chol_copy = 0;
@@ -632,29 +634,53 @@ int blk_invert(KktWorkspace* w, hipStream_t stream, rocblas_int n, const double*
     return EMI_OK;
 }
 
-// x <- (L L^T)^-1 x for ONE right-hand side through the block inverses (w->linv_n == n)
+// x <- (L L^T)^-1 x for ONE right-hand side through the block inverses (w->linv_n == n).  Two rocBLAS gemv per block column and sweep:
+// the inverted diagonal block (stored dense, zeros above its diagonal) against the block's part of the vector, then the update of
+// everything not yet solved.  The forward sweep leaves its solution in a second vector y, the backward sweep reads y and writes x, so
+// no step works in place.  (The library's own one-row-per-thread product for the diagonal blocks took 28 us per launch plus a copy
+// kernel: 0.67 of the 1.23 ms of a solve at 6144 rows; "kkt_block_trsv" 2 keeps that form.)
 int blk_potrs(KktWorkspace* w, hipStream_t stream, rocblas_int n, const double* L, double* x, std::string* err) {
     const int nblk = (n + TRSV_NB - 1) / TRSV_NB;
-    const double one = 1.0, mone = -1.0;
-    KKT_ENSURE(w->trsv_tmp, w->cap_trsv_tmp, (size_t)TRSV_NB * sizeof(double));
-    for (int j = 0; j < nblk; ++j) {            // forward: L y = b
+    const double one = 1.0, mone = -1.0, zero = 0.0;
+    if (g_tune.block_trsv.load() == 2) {
+        KKT_ENSURE(w->trsv_tmp, w->cap_trsv_tmp, (size_t)TRSV_NB * sizeof(double));
+        for (int j = 0; j < nblk; ++j) {            // forward: L y = b
+            const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, (int)n - j0), rest = (int)n - j0 - bs;
+            hipLaunchKernelGGL(emi_trsv_diag_kernel, dim3((bs + 63) / 64), dim3(64), 0, stream, (const double*)w->Linv + (size_t)j * TRSV_NB * TRSV_NB,
+                               bs, 0, x + j0, w->trsv_tmp);
+            hipLaunchKernelGGL(emi_trsv_copy_kernel, dim3((bs + 255) / 256), dim3(256), 0, stream, (const double*)w->trsv_tmp, x + j0, bs);
+            if (rest > 0)           // b_rest -= L[rest rows, block j] y_j
+                KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_none, rest, bs, &mone, L + (size_t)j0 * n + j0 + bs, n, x + j0, 1, &one,
+                                     x + j0 + bs, 1));
+        }
+        for (int j = nblk - 1; j >= 0; --j) {       // backward: L^T x = y
+            const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, (int)n - j0);
+            hipLaunchKernelGGL(emi_trsv_diag_kernel, dim3((bs + 63) / 64), dim3(64), 0, stream, (const double*)w->Linv + (size_t)j * TRSV_NB * TRSV_NB,
+                               bs, 1, x + j0, w->trsv_tmp);
+            hipLaunchKernelGGL(emi_trsv_copy_kernel, dim3((bs + 255) / 256), dim3(256), 0, stream, (const double*)w->trsv_tmp, x + j0, bs);
+            if (j0 > 0)             // y_(0 .. j0) -= L[block row j, 0 .. j0)^T x_j
+                KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_transpose, bs, j0, &mone, L + j0, n, x + j0, 1, &one, x, 1));
+        }
+        KKT_HIP(hipGetLastError());
+        return EMI_OK;
+    }
+    KKT_ENSURE(w->trsv_y, w->cap_trsv_y, (size_t)n * sizeof(double));
+    double* y = w->trsv_y;
+    for (int j = 0; j < nblk; ++j) {                // forward: L y = b (b in x, consumed block by block)
         const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, (int)n - j0), rest = (int)n - j0 - bs;
-        hipLaunchKernelGGL(emi_trsv_diag_kernel, dim3((bs + 63) / 64), dim3(64), 0, stream, (const double*)w->Linv + (size_t)j * TRSV_NB * TRSV_NB,
-                           bs, 0, x + j0, w->trsv_tmp);
-        hipLaunchKernelGGL(emi_trsv_copy_kernel, dim3((bs + 255) / 256), dim3(256), 0, stream, (const double*)w->trsv_tmp, x + j0, bs);
-        if (rest > 0)           // b_rest -= L[rest rows, block j] y_j
-            KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_none, rest, bs, &mone, L + (size_t)j0 * n + j0 + bs, n, x + j0, 1, &one,
+        KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_none, bs, bs, &one, w->Linv + (size_t)j * TRSV_NB * TRSV_NB, TRSV_NB, x + j0, 1, &zero,
+                             y + j0, 1));
+        if (rest > 0)               // b_rest -= L[rest rows, block j] y_j
+            KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_none, rest, bs, &mone, L + (size_t)j0 * n + j0 + bs, n, y + j0, 1, &one,
                                  x + j0 + bs, 1));
     }
-    for (int j = nblk - 1; j >= 0; --j) {       // backward: L^T x = y
+    for (int j = nblk - 1; j >= 0; --j) {           // backward: L^T x = y (y consumed block by block)
         const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, (int)n - j0);
-        hipLaunchKernelGGL(emi_trsv_diag_kernel, dim3((bs + 63) / 64), dim3(64), 0, stream, (const double*)w->Linv + (size_t)j * TRSV_NB * TRSV_NB,
-                           bs, 1, x + j0, w->trsv_tmp);
-        hipLaunchKernelGGL(emi_trsv_copy_kernel, dim3((bs + 255) / 256), dim3(256), 0, stream, (const double*)w->trsv_tmp, x + j0, bs);
-        if (j0 > 0)             // y_(0 .. j0) -= L[block row j, 0 .. j0)^T x_j
-            KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_transpose, bs, j0, &mone, L + j0, n, x + j0, 1, &one, x, 1));
+        KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_transpose, bs, bs, &one, w->Linv + (size_t)j * TRSV_NB * TRSV_NB, TRSV_NB, y + j0, 1, &zero,
+                             x + j0, 1));
+        if (j0 > 0)                 // y_(0 .. j0) -= L[block row j, 0 .. j0)^T x_j
+            KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_transpose, bs, j0, &mone, L + j0, n, x + j0, 1, &one, y, 1));
     }
-    KKT_HIP(hipGetLastError());
     return EMI_OK;
 }
 
@@ -664,7 +690,7 @@ void kkt_destroy(KktWorkspace* w) {
     if (!w) return;
     if (w->handle) (void)rocblas_destroy_handle(w->handle);
     void* bufs[] = {w->K, w->ipiv, w->info, w->Q, w->J, w->rhs, w->fixed, w->S, w->Pinv, w->G, w->Rk, w->Doff, w->W, w->gemm_ptrs, w->T,
-                    w->Cb, w->flag, w->chol_blk, w->chol_copy, w->Linv, w->trsv_tmp, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
+                    w->Cb, w->flag, w->chol_blk, w->chol_copy, w->Linv, w->trsv_tmp, w->trsv_y, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete w;

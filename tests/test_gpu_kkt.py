@@ -109,7 +109,7 @@ def test_block_inverse_triangular_solves_match_rocblas_trsv(built, M):
     K = dense_kkt(ev.D, Qblk, Jblk, fixed, 1e-9, M, ns, nv)
     rhs = rng.standard_normal((3, (nv + ns) * M))
     sols = {}
-    for mode in (1, 0):
+    for mode in (1, 2, 0):                                                  # gemv form (default), own diagonal-block kernel, rocBLAS trsv
         ev.set_option("kkt_block_trsv", mode)
         assert ev.kkt_factor(Qblk, Jblk, fixed, 1e-9) == 0
         sols[mode] = np.array([ev.kkt_solve(b) for b in rhs])           # one right-hand side per call
@@ -121,6 +121,7 @@ def test_block_inverse_triangular_solves_match_rocblas_trsv(built, M):
         assert np.array_equal(again, sols[mode])                        # fixed summation order: bitwise reproducible
     ev.set_option("kkt_block_trsv", 1)
     assert np.abs(sols[1] - sols[0]).max() < 1e-9 * (np.abs(sols[0]).max() + 1)
+    assert np.abs(sols[2] - sols[0]).max() < 1e-9 * (np.abs(sols[0]).max() + 1)
 
 
 @pytest.mark.parametrize("M", [171, 256, 300])

@@ -15,7 +15,7 @@ Jblk = rng.standard_normal((ns * nv, M))
 for i in range(ns): Jblk[i * nv + i] += np.diag(ev.D)
 fixed = np.zeros(nv * M, dtype=np.uint8); fixed[np.arange(ns) * M] = 1
 rhs = rng.standard_normal((nv + ns) * M)
-for mode in (1, 0, 1, 0):
+for mode in (1, 2, 0, 1, 2):
     ev.set_option("kkt_block_trsv", mode)
     t0 = time.perf_counter(); ev.kkt_factor(Qblk, Jblk, fixed, 1e-9); tf = time.perf_counter() - t0
     ev.kkt_solve(rhs)
