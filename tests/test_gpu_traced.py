@@ -49,7 +49,9 @@ def test_traced_quadrotor_matches_oracle_and_builtin_kernel(built, name, ring):
     c, tr, bi = _quad_evaluators(name)
     assert tr.layout.model == E.MODEL_SOURCE
     ref0 = O.evaluate(c["model"], c["params"], c["M"], (tr.tau, tr.w, tr.D), c["t0"], c["tf"], c["X"], c["U"], c.get("recs"))
-    check(c, tr, tr.eval_host(c["X"], c["U"]), ref0)      # default dispatch (few instances: skinny defect kernel)
+    check(c, tr, tr.eval_host(c["X"], c["U"]), ref0)      # default dispatch
+    if ring:                                              # ... is the one-launch pass (K sliced for few instances) for a traced model too
+        assert "emi_pass_f64_kernel" in tr.last_defect_kernel, tr.last_defect_kernel
     tr.set_option("small_rows", 0)
     bi.set_option("small_rows", 0)
     assert tr.uses_fused_kernel == ring          # even/odd MFMA kernel instantiated for the traced struct
