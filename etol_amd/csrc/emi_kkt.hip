@@ -108,6 +108,8 @@ struct KktWorkspace {
     // single-right-hand-side solves with the Cholesky factor of S (blk_potrs): inverses of its 512 x 512 diagonal blocks
     double* Linv = nullptr;        // [nblk][512][512] column-major, zeros above the diagonal
     size_t cap_Linv = 0;
+    double* LinvT = nullptr;       // the same blocks transposed (the forward sweep multiplies with op T as well)
+    size_t cap_LinvT = 0;
     int linv_n = 0;                // order of the factor the inverses belong to (0: none -- rocsolver_dpotrs is used)
     double* trsv_tmp = nullptr;    // [512] x_j while its block is being multiplied
     size_t cap_trsv_tmp = 0;
@@ -460,6 +462,49 @@ __global__ __launch_bounds__(64) void emi_trsv_diag_kernel(const double* __restr
     }
     out[r] = acc;
 }
+// transposes of the inverted diagonal blocks (512 x 512 each, 32 x 32 tiles through LDS): the forward sweep then multiplies with
+// op T like the backward one (rocBLAS gemvt 5 us a call, gemvn 22 us on a 512 x 512 block: eight workgroups)
+__global__ __launch_bounds__(256) void emi_trsv_transpose_kernel(const double* __restrict__ src, double* __restrict__ dst) {
+    __shared__ double tile[32][33];
+    const double* S = src + (size_t)blockIdx.z * TRSV_NB * TRSV_NB;
+    double* D = dst + (size_t)blockIdx.z * TRSV_NB * TRSV_NB;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = S[(size_t)(c0 + ty + 8 * k) * TRSV_NB + r0 + tx];      // element (r0 + tx, c0 + ty + 8k)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) D[(size_t)(r0 + ty + 8 * k) * TRSV_NB + c0 + tx] = tile[tx][ty + 8 * k];      // dst(c, r) = src(r, c)
+}
+// y[0 .. m) -= A x for a TALL block A (m x nc, column-major, leading dimension lda; nc <= 512): 64 rows per workgroup, its four waves
+// take a quarter of the columns each and add up through LDS in wave order (fixed summation order).  The forward sweep's update of
+// everything below a block column; rocBLAS gemvn takes 22 us for it at 5632 x 512.
+__global__ __launch_bounds__(256) void emi_trsv_update_kernel(const double* __restrict__ A, int lda, int m, int nc,
+                                                              const double* __restrict__ x, double* __restrict__ y) {
+    __shared__ double xs[TRSV_NB];
+    __shared__ double part[4][64];
+    for (int i = threadIdx.x; i < TRSV_NB; i += 256) xs[i] = i < nc ? x[i] : 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row = blockIdx.x * 64 + lane;
+    const int q = (nc + 3) / 4, c0 = w * q, c1 = min(nc, c0 + q);
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};      // eight loads of a lane in flight (the kernel is latency-bound otherwise)
+    if (row < m) {
+        const double* a = A + row;
+        int c = c0;
+        for (; c + 7 < c1; c += 8) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = a[(size_t)(c + k) * lda];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[k] * xs[c + k];
+        }
+        for (; c < c1; ++c) acc[0] += a[(size_t)c * lda] * xs[c];
+    }
+    part[w][lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (w == 0 && row < m) y[row] -= ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
 __global__ void emi_trsv_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
@@ -630,6 +675,9 @@ int blk_invert(KktWorkspace* w, hipStream_t stream, rocblas_int n, const double*
     if (tail > 0)
         KKT_RB(rocblas_dtrtri(w->handle, rocblas_fill_lower, rocblas_diagonal_non_unit, tail, L + (size_t)full * TRSV_NB * (n + 1), n,
                               w->Linv + (size_t)full * TRSV_NB * TRSV_NB, TRSV_NB));
+    KKT_ENSURE(w->LinvT, w->cap_LinvT, (size_t)nblk * TRSV_NB * TRSV_NB * sizeof(double));
+    hipLaunchKernelGGL(emi_trsv_transpose_kernel, dim3(TRSV_NB / 32, TRSV_NB / 32, nblk), dim3(256), 0, stream, (const double*)w->Linv, w->LinvT);
+    KKT_HIP(hipGetLastError());
     w->linv_n = n;
     return EMI_OK;
 }
@@ -668,11 +716,12 @@ int blk_potrs(KktWorkspace* w, hipStream_t stream, rocblas_int n, const double* 
     double* y = w->trsv_y;
     for (int j = 0; j < nblk; ++j) {                // forward: L y = b (b in x, consumed block by block)
         const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, (int)n - j0), rest = (int)n - j0 - bs;
-        KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_none, bs, bs, &one, w->Linv + (size_t)j * TRSV_NB * TRSV_NB, TRSV_NB, x + j0, 1, &zero,
-                             y + j0, 1));
+        // y_j = Linv_j b_j as a product with the TRANSPOSE of the transposed copy (gemvt: 5 us, gemvn 22 us on 512 x 512)
+        KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_transpose, bs, bs, &one, w->LinvT + (size_t)j * TRSV_NB * TRSV_NB, TRSV_NB, x + j0, 1,
+                             &zero, y + j0, 1));
         if (rest > 0)               // b_rest -= L[rest rows, block j] y_j
-            KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_none, rest, bs, &mone, L + (size_t)j0 * n + j0 + bs, n, y + j0, 1, &one,
-                                 x + j0 + bs, 1));
+            hipLaunchKernelGGL(emi_trsv_update_kernel, dim3((rest + 63) / 64), dim3(256), 0, stream, L + (size_t)j0 * n + j0 + bs, (int)n, rest, bs,
+                               (const double*)(y + j0), x + j0 + bs);
     }
     for (int j = nblk - 1; j >= 0; --j) {           // backward: L^T x = y (y consumed block by block)
         const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, (int)n - j0);
@@ -681,6 +730,7 @@ int blk_potrs(KktWorkspace* w, hipStream_t stream, rocblas_int n, const double* 
         if (j0 > 0)                 // y_(0 .. j0) -= L[block row j, 0 .. j0)^T x_j
             KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_transpose, bs, j0, &mone, L + j0, n, x + j0, 1, &one, y, 1));
     }
+    KKT_HIP(hipGetLastError());
     return EMI_OK;
 }
 
@@ -690,7 +740,7 @@ void kkt_destroy(KktWorkspace* w) {
     if (!w) return;
     if (w->handle) (void)rocblas_destroy_handle(w->handle);
     void* bufs[] = {w->K, w->ipiv, w->info, w->Q, w->J, w->rhs, w->fixed, w->S, w->Pinv, w->G, w->Rk, w->Doff, w->W, w->gemm_ptrs, w->T,
-                    w->Cb, w->flag, w->chol_blk, w->chol_copy, w->Linv, w->trsv_tmp, w->trsv_y, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
+                    w->Cb, w->flag, w->chol_blk, w->chol_copy, w->Linv, w->LinvT, w->trsv_tmp, w->trsv_y, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete w;
