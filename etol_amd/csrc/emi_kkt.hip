@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void emi_chol_diag_kernel(double* __restrict__
                 if (tid == 0 && *info == 0) *info = j0 + c + 1;
                 d = 1.0;
             }
-            const double piv = sqrt(d), inv = 1.0 / piv;
+            const double inv = rsqrt(d), piv = d * inv;       // (one reciprocal square root instead of a square root and a division on the per-column chain)
             const double lrc = col[c & 1][r] * inv;
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
