@@ -45,7 +45,7 @@ namespace emi {
 struct KktTuning {
     std::atomic<int> chol_outer{768};       // "kkt_chol_outer": columns of an outer panel of the two-level Cholesky
     std::atomic<int> own_cholesky{2};       // "kkt_cholesky": 2 the library's blocked Cholesky in two-level form from 1024 rows (default), 1 one level, 0 rocsolver_dpotrf (+ confirmation on a copy)
-    std::atomic<int> own_panel{1};          // "kkt_chol_panel": 1 own panel kernel, 0 rocblas_dtrsm
+    std::atomic<int> own_panel{2};          // "kkt_chol_panel": 2 own panel kernel on the matrix pipe (default), 1 its scalar form, 0 rocblas_dtrsm
     std::atomic<int> batched_max_nodes{256};// "kkt_batched_max_nodes": largest mesh with the batched Schur-block build
     std::atomic<int> debug{0};              // "kkt_debug": 1 retries and fallbacks on stderr, 2 also the blocks around a failing pivot
     std::atomic<int> potrf_lock{0};         // "kkt_potrf_lock": serialise rocsolver_dpotrf calls of different host threads
@@ -57,7 +57,7 @@ static KktTuning g_tune;
 bool kkt_set_option(const char* name, int value) {
     if (!strcmp(name, "kkt_chol_outer")) { g_tune.chol_outer = value; return true; }
     if (!strcmp(name, "kkt_cholesky")) { g_tune.own_cholesky = value < 0 ? 0 : (value > 2 ? 2 : value); return true; }
-    if (!strcmp(name, "kkt_chol_panel")) { g_tune.own_panel = value != 0; return true; }
+    if (!strcmp(name, "kkt_chol_panel")) { g_tune.own_panel = value < 0 ? 0 : (value > 2 ? 2 : value); return true; }
     if (!strcmp(name, "kkt_batched_max_nodes")) { g_tune.batched_max_nodes = value; return true; }
     if (!strcmp(name, "kkt_debug")) { g_tune.debug = value; return true; }
     if (!strcmp(name, "kkt_potrf_lock")) { g_tune.potrf_lock = value != 0; return true; }
@@ -413,9 +413,12 @@ __global__ __launch_bounds__(256) void emi_chol_diag_kernel(double* __restrict__
 }
 // rows i >= j0 + 64 of the block column j0: x <- x L^-T with L the factorised 64 x 64 diagonal block (Lb, wave-uniform
 // addresses: scalar loads, no LDS)
-__global__ __launch_bounds__(64) void emi_chol_panel_kernel(double* __restrict__ A, int lda, int n, int j0,
+#ifndef EMI_PANEL_THREADS
+#define EMI_PANEL_THREADS 64        // build-time experiment (tools/ab_build.sh): rows (threads) per workgroup of the panel kernel
+#endif
+__global__ __launch_bounds__(EMI_PANEL_THREADS) void emi_chol_panel_kernel(double* __restrict__ A, int lda, int n, int j0,
                                                            const double* __restrict__ Lb) {
-    const int row = j0 + CHOL_NB + blockIdx.x * 64 + threadIdx.x;
+    const int row = j0 + CHOL_NB + blockIdx.x * EMI_PANEL_THREADS + threadIdx.x;
     if (row >= n) return;
     double y[CHOL_NB];
     double* x = A + (size_t)j0 * lda + row;
@@ -430,6 +433,90 @@ __global__ __launch_bounds__(64) void emi_chol_panel_kernel(double* __restrict__
     }
 #pragma unroll
     for (int c = 0; c < CHOL_NB; ++c) x[(size_t)c * lda] = y[c];
+}
+
+// The same panel solve on the matrix pipe.  With L in 16 x 16 blocks L_ab and the panel transposed, L Y^T = X^T is a blocked forward
+// substitution:  Y_a^T = inv(L_aa) (X_a^T - sum_{b<a} L_ab Y_b^T)  -- ten 16 x 16 x 16 products per 16 panel rows, 40
+// v_mfma_f64_16x16x4_f64, against 2080 dependent-latency FMAs per row in the scalar form above (28.7 us per launch at 6144 rows:
+// every step waits for its scalar loads of the block).  Layouts of the instruction: A[row = lane % 16][k = lane / 16],
+// B[k = lane / 16][col = lane % 16], C[row = lane / 16 + 4 i][col = lane % 16] in register i.  The k-step ks of a product takes
+// k = lane / 16 + 4 ks (any assignment is fine as long as A and B agree), so register i of a finished block IS the B operand of
+// k-step i of the next product: no shuffles between the ten products.  One wave per workgroup: 64 panel rows as four 16-row
+// groups interleaved (independent accumulators); the inverses of the four diagonal 16 x 16 blocks are formed by the wave itself
+// (a 16-step substitution per lane) and pass through LDS into the A layout.
+typedef double chol_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void emi_chol_panel_mfma_kernel(double* __restrict__ A, int lda, int n, int j0,
+                                                                const double* __restrict__ Lb) {
+    __shared__ double inv_s[4][16][17];
+    const int lane = threadIdx.x, r16 = lane & 15, kq = lane >> 4;
+    {   // lane (a = kq, j = r16): column j of inv(L_aa); L_aa[r][c] = Lb[(16 a + c) * 64 + 16 a + r], reciprocal diagonal behind the block
+        const double* La = Lb + (size_t)(16 * kq) * CHOL_NB + 16 * kq;
+        const double* rd = Lb + CHOL_NB * CHOL_NB + 16 * kq;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double sacc = r == r16 ? 1.0 : 0.0;
+#pragma unroll
+            for (int c = 0; c < r; ++c) sacc -= La[(size_t)c * CHOL_NB + r] * x[c];
+            x[r] = sacc * rd[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) inv_s[kq][r][r16] = x[r];
+    }
+    __syncthreads();
+    // A operands: inv(L_aa) and -L_ab (a > b), element [r16][kq + 4 ks] for k-step ks
+    double Ainv[4][4], Aoff[6][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) Ainv[a][ks] = inv_s[a][r16][kq + 4 * ks];
+#pragma unroll
+    for (int a = 1; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < a; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                Aoff[a * (a - 1) / 2 + b][ks] = -Lb[(size_t)(16 * b + kq + 4 * ks) * CHOL_NB + 16 * a + r16];
+    // the panel: element (panel row, column 16 a + kq + 4 i) in T[g][a][i]
+    const int row0 = j0 + CHOL_NB + blockIdx.x * 64;
+    chol_d4 T[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int row = row0 + 16 * g + r16;
+        row = row < n ? row : n - 1;                       // (rows past the matrix: loaded from the last row, not stored)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) T[g][a][i] = A[(size_t)(j0 + 16 * a + kq + 4 * i) * lda + row];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < a; ++b)                        // X_a^T -= L_ab Y_b^T
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    T[g][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(Aoff[a * (a - 1) / 2 + b][ks], T[g][b][ks], T[g][a], 0, 0, 0);
+        chol_d4 Y[4];                                      // Y_a^T = inv(L_aa) (...)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Y[g] = chol_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Y[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[a][ks], T[g][a][ks], Y[g], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) T[g][a] = Y[g];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row = row0 + 16 * g + r16;
+        if (row >= n) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A[(size_t)(j0 + 16 * a + kq + 4 * i) * lda + row] = T[g][a][i];
+    }
 }
 
 // ---- single-right-hand-side triangular solves with a Cholesky factor (lower, column-major) -----------------------------------
@@ -595,8 +682,12 @@ int chol_blocked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, 
             // own kernel by default; rocblas_dtrsm (EMI_CHOL_PANEL=0) is 5 % faster on a single 1024-node solve and 20-40 %
             // slower on eight concurrent 129-node solves (profiles/r01_notes.md)
             const int own_panel = g_tune.own_panel.load();
-            if (own_panel) {
-                hipLaunchKernelGGL(emi_chol_panel_kernel, dim3((rest + 63) / 64), dim3(64), 0, stream, A, (int)n, (int)n, j0,
+            if (own_panel == 2) {
+                hipLaunchKernelGGL(emi_chol_panel_mfma_kernel, dim3((rest + 63) / 64), dim3(64), 0, stream, A, (int)n, (int)n, j0,
+                                   (const double*)w->chol_blk);
+                KKT_HIP(hipGetLastError());
+            } else if (own_panel) {
+                hipLaunchKernelGGL(emi_chol_panel_kernel, dim3((rest + EMI_PANEL_THREADS - 1) / EMI_PANEL_THREADS), dim3(EMI_PANEL_THREADS), 0, stream, A, (int)n, (int)n, j0,
                                    (const double*)w->chol_blk);
                 KKT_HIP(hipGetLastError());
             } else {
@@ -629,7 +720,11 @@ int chol_blocked2(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A,
             const int nb = std::min(CHOL_NB, (int)n - j0), rest = (int)n - j0 - nb;
             hipLaunchKernelGGL(emi_chol_diag_kernel, dim3(1), dim3(256), 0, stream, A, (int)n, j0, nb, (int*)w->info, w->chol_blk);
             if (rest <= 0) continue;
-            hipLaunchKernelGGL(emi_chol_panel_kernel, dim3((rest + 63) / 64), dim3(64), 0, stream, A, (int)n, (int)n, j0,
+            if (g_tune.own_panel.load() == 2)
+                hipLaunchKernelGGL(emi_chol_panel_mfma_kernel, dim3((rest + 63) / 64), dim3(64), 0, stream, A, (int)n, (int)n, j0,
+                                   (const double*)w->chol_blk);
+            else
+                hipLaunchKernelGGL(emi_chol_panel_kernel, dim3((rest + EMI_PANEL_THREADS - 1) / EMI_PANEL_THREADS), dim3(EMI_PANEL_THREADS), 0, stream, A, (int)n, (int)n, j0,
                                (const double*)w->chol_blk);
             const int wc = Jend - (j0 + nb);            // columns of the outer panel right of this step
             if (wc > 0) {
