@@ -45,6 +45,7 @@ namespace emi {
 struct KktTuning {
     std::atomic<int> chol_outer{768};       // "kkt_chol_outer": columns of an outer panel of the two-level Cholesky
     std::atomic<int> own_cholesky{2};       // "kkt_cholesky": 2 the library's blocked Cholesky in two-level form from 1024 rows (default), 1 one level, 0 rocsolver_dpotrf (+ confirmation on a copy)
+    std::atomic<int> own_diag{2};           // "kkt_chol_diag": 2 the diagonal block by one wave with matrix-pipe updates (default), 1 the 256-thread column-by-column kernel
     std::atomic<int> own_panel{2};          // "kkt_chol_panel": 2 own panel kernel on the matrix pipe (default), 1 its scalar form, 0 rocblas_dtrsm
     std::atomic<int> batched_max_nodes{256};// "kkt_batched_max_nodes": largest mesh with the batched Schur-block build
     std::atomic<int> debug{0};              // "kkt_debug": 1 retries and fallbacks on stderr, 2 also the blocks around a failing pivot
@@ -57,6 +58,7 @@ static KktTuning g_tune;
 bool kkt_set_option(const char* name, int value) {
     if (!strcmp(name, "kkt_chol_outer")) { g_tune.chol_outer = value; return true; }
     if (!strcmp(name, "kkt_cholesky")) { g_tune.own_cholesky = value < 0 ? 0 : (value > 2 ? 2 : value); return true; }
+    if (!strcmp(name, "kkt_chol_diag")) { g_tune.own_diag = value; return true; }
     if (!strcmp(name, "kkt_chol_panel")) { g_tune.own_panel = value < 0 ? 0 : (value > 2 ? 2 : value); return true; }
     if (!strcmp(name, "kkt_batched_max_nodes")) { g_tune.batched_max_nodes = value; return true; }
     if (!strcmp(name, "kkt_debug")) { g_tune.debug = value; return true; }
@@ -452,13 +454,14 @@ __global__ __launch_bounds__(64) void emi_chol_panel_mfma_kernel(double* __restr
     {   // lane (a = kq, j = r16): column j of inv(L_aa); L_aa[r][c] = Lb[(16 a + c) * 64 + 16 a + r], reciprocal diagonal behind the block
         const double* La = Lb + (size_t)(16 * kq) * CHOL_NB + 16 * kq;
         const double* rd = Lb + CHOL_NB * CHOL_NB + 16 * kq;
-        double x[16];
+        double x[16];                                       // right-looking: a finished x[c] leaves every later row at once (no long dependent chain)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            double sacc = r == r16 ? 1.0 : 0.0;
+        for (int r = 0; r < 16; ++r) x[r] = r == r16 ? 1.0 : 0.0;
 #pragma unroll
-            for (int c = 0; c < r; ++c) sacc -= La[(size_t)c * CHOL_NB + r] * x[c];
-            x[r] = sacc * rd[r];
+        for (int c = 0; c < 16; ++c) {
+            x[c] *= rd[c];
+#pragma unroll
+            for (int r = c + 1; r < 16; ++r) x[r] -= La[(size_t)c * CHOL_NB + r] * x[c];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) inv_s[kq][r][r16] = x[r];
@@ -517,6 +520,129 @@ __global__ __launch_bounds__(64) void emi_chol_panel_mfma_kernel(double* __restr
 #pragma unroll
             for (int i = 0; i < 4; ++i) A[(size_t)(j0 + 16 * a + kq + 4 * i) * lda + row] = T[g][a][i];
     }
+}
+
+// The 64 x 64 diagonal block in the same 16 x 16 block form, by ONE wave: blocked right-looking Cholesky whose panel and trailing
+// updates are matrix-pipe products (layouts as in emi_chol_panel_mfma_kernel: block (b, c) is held transposed, element (row 16 b +
+// lane % 16, column 16 c + lane / 16 + 4 i) in register i, which makes a finished block A and B operand of the next products without
+// any shuffle), and whose four 16 x 16 diagonal blocks are factorised inside the wave with lane shuffles (16 columns each instead of
+// one 64-column chain with an LDS hand-over and a workgroup barrier per column: emi_chol_diag_kernel, 38 us per launch).
+// Full blocks only (nb == 64); the last, partial block of a matrix goes through emi_chol_diag_kernel.  Outputs as that kernel's.
+__global__ __launch_bounds__(64) void emi_chol_diag_mfma_kernel(double* __restrict__ A, int lda, int j0, int* __restrict__ info,
+                                                               double* __restrict__ Lout) {
+    __shared__ double Ls[16][17];
+    __shared__ double inv_s[16][17];
+    const int lane = threadIdx.x, r16 = lane & 15, kq = lane >> 4;
+    double* blk = A + (size_t)j0 * lda + j0;
+    chol_d4 T[10];                                         // block (b, c), b >= c, at b (b + 1) / 2 + c
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int c = 0; c <= b; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * b + r16, col = 16 * c + kq + 4 * i;
+                T[b * (b + 1) / 2 + c][i] = row >= col ? blk[(size_t)col * lda + row] : 0.0;
+            }
+    int bad = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        chol_d4& D = T[a * (a + 1) / 2 + a];
+        double rdiag[16];                                  // reciprocals of the diagonal of L_aa (wave-uniform)
+        // 1. L_aa: lane (r = r16, q = kq) holds the columns q + 4 m of its row in D[m].  Four columns at a time (4 s .. 4 s + 3 = register s
+        //    of the four lane groups): a column step updates only the rest of its group of four (one shuffle each for the pivot, the lane's
+        //    row and the lane's column), and the columns behind the group get ONE rank-4 update, D -= L4 L4^T, which in this layout is a
+        //    single instruction: register s is the A operand (row kappa = lane % 16, k = lane / 16) and the B operand (k, col r = lane % 16).
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = 4 * sb + t;
+                const double dsrc = D[sb];
+                double d = __shfl(dsrc, c + 16 * t);
+                if (!(d > 0.0)) {
+                    if (!bad) bad = 16 * a + c + 1;
+                    d = 1.0;
+                }
+                // the next pivot waits for this column's update, and the update needs 1 / d only (L[r][c] L[cc][c] = A[r][c] A[cc][c] / d):
+                // a reciprocal with two Newton steps is on that chain, the reciprocal square root the column itself needs is not
+                double rd = __builtin_amdgcn_rcp(d);
+                rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+                rd = __builtin_fma(__builtin_fma(-d, rd, 1.0), rd, rd);
+                const double inv = rsqrt(d), piv = d * inv;
+                rdiag[c] = inv;
+                const double ar = __shfl(dsrc, r16 + 16 * t);                  // A[r][c] of this lane's row (unscaled)
+                if (t < 3) {
+                    const int cc = 4 * sb + kq;                                // this lane's column of the group
+                    const double acc = __shfl(dsrc, cc + 16 * t);              // A[cc][c]
+                    if (kq > t) D[sb] -= (ar * acc) * rd;
+                }
+                if (kq == t) D[sb] = r16 == c ? piv : (r16 > c ? ar * inv : 0.0);
+            }
+            if (sb < 3) {
+                const chol_d4 U = __builtin_amdgcn_mfma_f64_16x16x4f64(-D[sb], D[sb], D, 0, 0, 0);
+#pragma unroll
+                for (int i = sb + 1; i < 4; ++i) D[i] = U[i];
+            }
+        }
+        // 2. inv(L_aa): column j = r16 of it per lane (the four lane groups do the same work), through LDS into the A layout
+        __syncthreads();                                    // (the previous block's readers of Ls / inv_s are done)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) Ls[r16][kq + 4 * m] = D[m];
+        __syncthreads();
+        {
+            double x[16];                                   // (right-looking, as in the panel kernel)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] = r == r16 ? 1.0 : 0.0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                x[c] *= rdiag[c];
+#pragma unroll
+                for (int r = c + 1; r < 16; ++r) x[r] -= Ls[r][c] * x[c];
+            }
+            if (kq == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) inv_s[r][r16] = x[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (lane == c) Lout[CHOL_NB * CHOL_NB + 16 * a + c] = rdiag[c];
+        if (a == 3) break;
+        double Ainv[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) Ainv[ks] = inv_s[r16][kq + 4 * ks];
+        // 3. the blocks below: L_ba^T = inv(L_aa) A_ba^T
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) {
+            chol_d4 Y = chol_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) Y = __builtin_amdgcn_mfma_f64_16x16x4f64(Ainv[ks], T[b * (b + 1) / 2 + a][ks], Y, 0, 0, 0);
+            T[b * (b + 1) / 2 + a] = Y;
+        }
+        // 4. trailing blocks: A_bc -= L_ba L_ca^T
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b)
+#pragma unroll
+            for (int c = a + 1; c <= b; ++c)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    T[b * (b + 1) / 2 + c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[c * (c + 1) / 2 + a][ks], T[b * (b + 1) / 2 + a][ks],
+                                                                                 T[b * (b + 1) / 2 + c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * b + r16, col = 16 * c + kq + 4 * i;
+                const double v = (c <= b && row >= col) ? T[(c <= b ? b * (b + 1) / 2 + c : 0)][i] : 0.0;
+                if (row >= col) blk[(size_t)col * lda + row] = v;
+                Lout[col * CHOL_NB + row] = v;
+            }
+    if (bad && lane == 0 && *info == 0) *info = j0 + bad;
 }
 
 // ---- single-right-hand-side triangular solves with a Cholesky factor (lower, column-major) -----------------------------------
@@ -676,7 +802,10 @@ int chol_blocked(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A, 
     const double one = 1.0, mone = -1.0;
     for (int j0 = 0; j0 < n; j0 += CHOL_NB) {
         const int nb = std::min(CHOL_NB, (int)n - j0), rest = (int)n - j0 - nb;
-        hipLaunchKernelGGL(emi_chol_diag_kernel, dim3(1), dim3(256), 0, stream, A, (int)n, j0, nb, (int*)w->info, w->chol_blk);
+        if (nb == CHOL_NB && g_tune.own_diag.load() == 2)
+            hipLaunchKernelGGL(emi_chol_diag_mfma_kernel, dim3(1), dim3(64), 0, stream, A, (int)n, j0, (int*)w->info, w->chol_blk);
+        else
+            hipLaunchKernelGGL(emi_chol_diag_kernel, dim3(1), dim3(256), 0, stream, A, (int)n, j0, nb, (int*)w->info, w->chol_blk);
         if (rest > 0) {
             double* P = A + (size_t)j0 * n + j0 + nb;
             // own kernel by default; rocblas_dtrsm (EMI_CHOL_PANEL=0) is 5 % faster on a single 1024-node solve and 20-40 %
@@ -718,6 +847,9 @@ int chol_blocked2(KktWorkspace* w, hipStream_t stream, rocblas_int n, double* A,
         const int Jend = std::min((int)n, J0 + NB2);
         for (int j0 = J0; j0 < Jend; j0 += CHOL_NB) {
             const int nb = std::min(CHOL_NB, (int)n - j0), rest = (int)n - j0 - nb;
+            if (nb == CHOL_NB && g_tune.own_diag.load() == 2)
+            hipLaunchKernelGGL(emi_chol_diag_mfma_kernel, dim3(1), dim3(64), 0, stream, A, (int)n, j0, (int*)w->info, w->chol_blk);
+        else
             hipLaunchKernelGGL(emi_chol_diag_kernel, dim3(1), dim3(256), 0, stream, A, (int)n, j0, nb, (int*)w->info, w->chol_blk);
             if (rest <= 0) continue;
             if (g_tune.own_panel.load() == 2)

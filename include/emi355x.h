@@ -329,6 +329,7 @@ int emi_profile_read(emi_ctx_t ctx, float* node_ms, int* node_launches,
  * the Schur path starts at the dual regularisation level that worked last on this
  * mesh; "kkt_cholesky" 2 (default): the library's blocked Cholesky in two-level form from 1024 rows
  * (outer panels of "kkt_chol_outer" columns, default 768), 1: one level, 0: rocsolver_dpotrf;
+ * "kkt_chol_diag" 2 (default): the 64 x 64 diagonal block of a Cholesky step by one wave with matrix-pipe block updates, 1: column by column by 256 threads;
  * "kkt_chol_panel" 2 (default): the panel solve of a Cholesky step as 16 x 16 block products on the matrix pipe, 1: one row per thread, 0: rocblas_dtrsm;
  * "kkt_debug", "kkt_batched_max_nodes", "kkt_potrf_lock": diagnostics, see csrc/emi_kkt.hip).
  * "slice": > 0: batches above 2 * slice instances are evaluated in pieces of `slice` instances; 0 (default): a batch above

@@ -156,14 +156,17 @@ def test_two_level_cholesky_matches_the_one_level_form(built, M):
     sols = {}
     try:
         # (last entry of a tuple: "kkt_chol_panel" 2 = the panel solve on the matrix pipe (default), 1 its scalar form, 0 rocBLAS dtrsm)
-        for mode, outer, panel in ((1, 768, 1), (2, 128, 2), (2, 768, 2), (2, 2048, 2), (1, 768, 2), (2, 768, 1), (2, 768, 0)):
+        # ("kkt_chol_diag" 2 = the 64 x 64 diagonal block by one wave with matrix-pipe updates (default), 1 = column by column by 256 threads)
+        for mode, outer, panel, diag in ((1, 768, 1, 1), (2, 128, 2, 2), (2, 768, 2, 2), (2, 2048, 2, 2), (1, 768, 2, 2), (2, 768, 1, 2), (2, 768, 0, 2),
+                                         (2, 768, 2, 1), (1, 768, 1, 2)):
             ev.set_option("kkt_cholesky", mode)
             ev.set_option("kkt_chol_outer", outer)
             ev.set_option("kkt_chol_panel", panel)
+            ev.set_option("kkt_chol_diag", diag)
             assert ev.kkt_factor(Qblk, Jblk, fixed, 1e-9) == 0
             x = ev.kkt_solve(rhs)
-            assert np.abs(K @ x - b).max() < 1e-10 * (np.abs(K).max() * np.abs(x).max() + 1), (mode, outer, panel)
-            sols[mode, outer, panel] = x
+            assert np.abs(K @ x - b).max() < 1e-10 * (np.abs(K).max() * np.abs(x).max() + 1), (mode, outer, panel, diag)
+            sols[mode, outer, panel, diag] = x
             # the low-rank path factorises a second, small matrix with the same routine and solves many right-hand sides (dpotrs)
             X3 = ev.kkt_solve(np.stack([rhs, 2 * rhs, -rhs]))
             assert np.abs(X3[0] - x).max() < 1e-9 * (np.abs(x).max() + 1)
@@ -171,8 +174,9 @@ def test_two_level_cholesky_matches_the_one_level_form(built, M):
         ev.set_option("kkt_cholesky", 2)
         ev.set_option("kkt_chol_outer", 768)
         ev.set_option("kkt_chol_panel", 2)
+        ev.set_option("kkt_chol_diag", 2)
     for k, x in sols.items():
-        assert np.abs(x - sols[1, 768, 1]).max() < 1e-9 * (np.abs(x).max() + 1), k
+        assert np.abs(x - sols[1, 768, 1, 1]).max() < 1e-9 * (np.abs(x).max() + 1), k
     ev.close()
 
 
