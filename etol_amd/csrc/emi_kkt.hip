@@ -235,6 +235,72 @@ __global__ __launch_bounds__(64) void emi_kkt_node_inverse_kernel(const double* 
             Rk[(size_t)(i * ns + ip) * M + k] = sum;
         }
 }
+// The same with the block sizes known at compile time: every loop unrolled, the 8 x 8 arrays in registers (the generic kernel above
+// indexes its arrays with run-time bounds and runs out of 6.3 KB of scratch memory per thread: 252 us per launch whatever the mesh,
+// 14 % of a factorisation at 256 nodes).  Same operations in the same order: bitwise the generic kernel's results.
+template <int NS_, int NV_>
+__global__ __launch_bounds__(64) void emi_kkt_node_inverse_fixed_kernel(const double* __restrict__ Q, const double* __restrict__ J,
+                                                                 const unsigned char* __restrict__ fixed, int M,
+                                                                 double* __restrict__ Pinv, double* __restrict__ G,
+                                                                 double* __restrict__ Rk, int* __restrict__ flag, double dw) {
+    constexpr int ns = NS_, nv = NV_;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    double A[NV_][NV_], X[NV_][NV_];
+    bool fx[NV_];
+    _Pragma("unroll") for (int v = 0; v < nv; ++v) fx[v] = fixed[v * M + k] != 0;
+    _Pragma("unroll") for (int v = 0; v < nv; ++v)
+        _Pragma("unroll") for (int q = 0; q <= v; ++q)
+            A[v][q] = (fx[v] || fx[q]) ? (v == q ? 1.0 : 0.0) : Q[(size_t)(v * (v + 1) / 2 + q) * M + k] + ((v == q && v < ns) ? dw : 0.0);
+    bool ok = true;
+    _Pragma("unroll") for (int i = 0; i < nv; ++i)
+        _Pragma("unroll") for (int j = 0; j <= i; ++j) {
+            double sum = A[i][j];
+            _Pragma("unroll") for (int t = 0; t < j; ++t) sum -= A[i][t] * A[j][t];
+            if (i == j) {
+                if (!(sum > 0.0)) { ok = false; sum = 1.0; }
+                A[i][i] = sqrt(sum);
+            } else {
+                A[i][j] = sum / A[j][j];
+            }
+        }
+    if (!ok) atomicExch(flag, 1);
+    // X = A^-1 (A = L L^T): columns of the identity through forward and backward substitution
+    _Pragma("unroll") for (int c = 0; c < nv; ++c) {
+        double y[NV_];
+        _Pragma("unroll") for (int i = 0; i < nv; ++i) {
+            double sum = i == c ? 1.0 : 0.0;
+            _Pragma("unroll") for (int t = 0; t < i; ++t) sum -= A[i][t] * y[t];
+            y[i] = sum / A[i][i];
+        }
+        _Pragma("unroll") for (int i = nv - 1; i >= 0; --i) {
+            double sum = y[i];
+            _Pragma("unroll") for (int t = i + 1; t < nv; ++t) sum -= A[t][i] * X[t][c];
+            X[i][c] = sum / A[i][i];
+        }
+    }
+    _Pragma("unroll") for (int v = 0; v < nv; ++v)
+        _Pragma("unroll") for (int q = 0; q < nv; ++q) {
+            const double val = (fx[v] || fx[q]) ? 0.0 : X[v][q];
+            X[v][q] = val;
+            Pinv[(size_t)(v * nv + q) * M + k] = val;
+        }
+    // PJ[v][i'] = sum_q P[v][q] J[i'][q]
+    double PJ[NV_][NS_];
+    _Pragma("unroll") for (int v = 0; v < nv; ++v)
+        _Pragma("unroll") for (int ip = 0; ip < ns; ++ip) {
+            double sum = 0;
+            _Pragma("unroll") for (int q = 0; q < nv; ++q) sum += X[v][q] * J[(size_t)(ip * nv + q) * M + k];
+            PJ[v][ip] = sum;
+        }
+    _Pragma("unroll") for (int i = 0; i < ns; ++i)
+        _Pragma("unroll") for (int ip = 0; ip < ns; ++ip) {
+            G[(size_t)(i * ns + ip) * M + k] = PJ[i][ip];
+            double sum = 0;
+            _Pragma("unroll") for (int v = 0; v < nv; ++v) sum += J[(size_t)(i * nv + v) * M + k] * PJ[v][ip];
+            Rk[(size_t)(i * ns + ip) * M + k] = sum;
+        }
+}
 
 // Doff = D with zero diagonal (same memory order as D: [k][j] row-major)
 __global__ void emi_kkt_doff_kernel(const double* __restrict__ D, double* __restrict__ Doff, int M) {
@@ -1080,7 +1146,14 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
             if (LV_DW[attempt] != dw_done) {        // node blocks (re)inverted with this level's primal shift
                 dw_done = LV_DW[attempt];
                 KKT_HIP(hipMemsetAsync(w->flag, 0, sizeof(int), stream));
-                hipLaunchKernelGGL(emi_kkt_node_inverse_kernel, dim3((M + 63) / 64), dim3(64), 0, stream, w->Q, w->J, w->fixed, M, ns, nv,
+                if (ns == 6 && nv == 8)
+                    hipLaunchKernelGGL((emi_kkt_node_inverse_fixed_kernel<6, 8>), dim3((M + 63) / 64), dim3(64), 0, stream, w->Q, w->J, w->fixed, M,
+                                   w->Pinv, w->G, w->Rk, w->flag, dw_done);
+                else if (ns == 2 && nv == 4)
+                    hipLaunchKernelGGL((emi_kkt_node_inverse_fixed_kernel<2, 4>), dim3((M + 63) / 64), dim3(64), 0, stream, w->Q, w->J, w->fixed, M,
+                                   w->Pinv, w->G, w->Rk, w->flag, dw_done);
+                else
+                    hipLaunchKernelGGL(emi_kkt_node_inverse_kernel, dim3((M + 63) / 64), dim3(64), 0, stream, w->Q, w->J, w->fixed, M, ns, nv,
                                    w->Pinv, w->G, w->Rk, w->flag, dw_done);
                 KKT_HIP(hipGetLastError());
             }
