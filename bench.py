@@ -9,6 +9,7 @@ Inputs are resident in HBM before the timed region.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--scenarios S] [--batch B] [--config c3|c5]
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+       (or plain `python bench.py --gpus N`: it then starts the N ranks itself, as child processes, before touching the GPU)
 The batch is the 1024-scenario obstacle-field Monte-Carlo of config 4: it is STRONG-scaled, rank r evaluates
 scenarios [r*S/N, (r+1)*S/N) (S/N = 128 per GPU at N = 8) with no data-path collective; `value` = S*M*K / time.
 The same run then repeats the measurement weak-scaled (1024 scenarios per GPU) and reports it as a second field.
@@ -36,7 +37,7 @@ def load_pmc_traffic(kernel, B, M):
     under profiles/ holds an entry for exactly that (kernel, B, M) -- a figure collected at another batch size is not this
     run's traffic.  Returns (bytes or None, provenance or None); the counters are not collected inside bench.py (rocprofv3
     serialises dispatches while it counts)."""
-    for tag in ("r03",):
+    for tag in ("r04", "r03"):
         path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
         try:
             for e in json.load(open(path)).get("entries", []):
@@ -159,6 +160,25 @@ def roofline_of(m, def_name, key, n_obs, B, M, ns, ms_per_step):
 PRE_WARM_S = 0.25      # untimed clock warm-up ahead of the W warm-up steps (see measure())
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as children of this (GPU-free) process the
+    way the driver's multi-GPU command does, relay what they print, return the launcher's exit code.  With fewer devices
+    visible than ranks the ranks share devices (rank r -> device r mod visible; main() then puts the control plane on gloo,
+    because RCCL refuses two ranks on one device) and the bench line says so (config.ranks_share_device)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def measure(ev, dX, dU, outs, steps, warmup, barrier, torch):
     """W untimed passes (profiled at level 1 to find the dominant kernel), then exactly `steps` passes between
     barrier + synchronize, with ONE pair of HIP events per pass around that kernel on its own launch stream (one-launch
@@ -222,6 +242,12 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started like the single-GPU run (`python bench.py --gpus N`): this process becomes the launcher.  Decided BEFORE
+        # anything touches the GPU, and the ranks are fresh CHILD processes of `python -m torch.distributed.run` (a process that
+        # has initialised the GPU must never be replaced by another program on this pool); rank 0's JSON line is relayed.
+        sys.exit(launch_ranks(a.gpus))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -229,16 +255,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        a.gpus = world
+    a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    # rehearsal knobs (never set by the driver): control plane over gloo, all ranks on one GPU
+    # ranks that must share a device (fewer GPUs visible than ranks: the launcher above sets these; EMI_BENCH_SHARE_GPU is the
+    # older rehearsal knob): RCCL refuses two ranks on one device, so the control plane goes over gloo, and the line says so
     backend = os.environ.get("EMI_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    shared = world > max(ndev, 1) or os.environ.get("EMI_BENCH_SHARE_GPU") == "1"
     if os.environ.get("EMI_BENCH_SHARE_GPU") == "1":
         local = 0
+    elif local >= max(ndev, 1):
+        local = local % ndev
+    if shared and backend == "nccl" and world > 1:
+        backend = "gloo"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -369,7 +399,8 @@ def main():
             "dtype": "f32" if c5 else "f64", "data": "synthetic",
             "config": {"workload": workload, "nodes": M, "scenarios": S, "instances_per_gpu": B,
                        "path_rows": n_obs, "parallelism": f"instances sharded x{world}", "gather_ms": gather_ms,
-                       "pre_warm_s": PRE_WARM_S},
+                       "pre_warm_s": PRE_WARM_S, "devices_visible": ndev, "ranks_share_device": bool(shared and world > 1),
+                       "control_plane": backend if world > 1 else None},
             "roofline": roof,
         }
         if weak:
@@ -398,7 +429,17 @@ def main():
             torch.cuda.empty_cache()
         if world == 1 and not a.no_cpu_baseline and not c5:
             line["cpu_baseline"] = cpu_baseline(M, n_obs, a.cpu_budget)
+        bad = checked is not None and not checked["ok"]
+        if bad:
+            # a pass that left wrong results in HBM has no throughput: the number is withheld and the run fails
+            line["value_withheld"] = line["value"]
+            line["value"] = None
+            line["error"] = "outputs of the timed passes disagree with oracle/emi_oracle.c (see `checked`)"
         print(json.dumps(line), flush=True)
+        if bad:
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit(3)
     if world > 1:
         dist.destroy_process_group()
 

@@ -61,6 +61,7 @@ SYMBOLS = {
     "emi_check_model_source": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     "emi_kkt_factor": (C.c_int, [_P, _D, _D, C.POINTER(C.c_ubyte), C.c_double, C.POINTER(C.c_int)]),
     "emi_kkt_solve": (C.c_int, [_P, _D, C.c_int]),
+    "emi_kkt_last_regularisation": (C.c_int, [_P, _D, _D]),
     "emi_kkt_lowrank": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _D, _D, C.POINTER(C.c_int)]),
     "emi_set_batch": (C.c_int, [_P, C.c_int]),
     "emi_set_path": (C.c_int, [_P, C.c_int, C.c_int, _D, C.c_int, C.c_int]),

@@ -438,8 +438,7 @@ int emi_set_mesh(emi_ctx_t c, int M, const double* tau, const double* w, const d
         c->symmetric = false;
         c->points_only = true;
         c->delay_dirty = true;
-    c->h_tau.assign(tau, tau + M);
-        c->delay_dirty = true;
+        c->h_tau.assign(tau, tau + M);
         c->h_w.assign(w, w + M);
         c->M = M; c->t0 = t0; c->tf = tf;
         c->ntracks = 0; c->track_sets = 0;
@@ -508,6 +507,7 @@ int emi_set_mesh(emi_ctx_t c, int M, const double* tau, const double* w, const d
     c->M = M;
     c->t0 = t0;
     c->tf = tf;
+    c->delay_dirty = true;      // W(delay) is built for one mesh: [nd][M][M] on these nodes and this horizon
     // tables sized by M are stale now
     c->ntracks = 0;
     c->track_sets = 0;
@@ -1172,6 +1172,13 @@ int emi_kkt_lowrank(emi_ctx_t c, int r, const int* node, const double* vec, cons
     const int st = emi::kkt_lowrank(c->kkt, c->stream, (c->ns + c->nc) * c->M, r, node, vec, delta, exact, &err);
     if (st) c->err = err;
     return st;
+}
+
+int emi_kkt_last_regularisation(emi_ctx_t c, double* dc, double* dw) {
+    if (!c || (!dc && !dw)) return EMI_ERR_ARG;
+    if (!c->kkt) return fail(c, EMI_ERR_STATE, "emi_kkt_last_regularisation: no factorisation");
+    emi::kkt_last_regularisation(c->kkt, dc, dw);
+    return EMI_OK;
 }
 
 int emi_kkt_solve(emi_ctx_t c, double* rhs, int nrhs) {

@@ -74,5 +74,6 @@ bool kkt_set_option(const char* name, int value);   // process-wide diagnostics 
 int kkt_lowrank(KktWorkspace* w, hipStream_t stream, int nz, int r, const int* node, const double* vec, const double* delta,
                 int* exact, std::string* err);
 void kkt_destroy(KktWorkspace* w);
+void kkt_last_regularisation(const KktWorkspace* w, double* dc, double* dw);
 
 }  // namespace emi

@@ -107,6 +107,7 @@ struct KktWorkspace {
     // a wandering solve (inertia search: many trial matrices per iteration) stuck there with 209 of 585 factorisations
     // at 85 ms each where the Cholesky path, tried, takes 10 ms (513 nodes, profiles/r02_notes.md section 12).
     int reg_level = 0, reg_hits = 0, reg_M = 0, reg_ns = 0, reg_nv = 0;
+    double reg_dc_applied = 0.0, reg_dw_applied = 0.0;    // what the current factorisation really holds (kkt_last_regularisation)
     // single-right-hand-side solves with the Cholesky factor of S (blk_potrs): inverses of its 512 x 512 diagonal blocks
     double* Linv = nullptr;        // [nblk][512][512] column-major, zeros above the diagonal
     size_t cap_Linv = 0;
@@ -187,6 +188,22 @@ __global__ __launch_bounds__(64) void emi_kkt_node_inverse_kernel(const double* 
         for (int q = 0; q <= v; ++q)
             A[v][q] = (fx[v] || fx[q]) ? (v == q ? 1.0 : 0.0) : Q[(size_t)(v * (v + 1) / 2 + q) * M + k] + ((v == q && v < ns) ? dw : 0.0);
     bool ok = true;
+    if (dw > 0.0) {
+        // the verdict "this block is positive definite" is about the matrix the CALLER built, not about the shifted one: a block that
+        // is indefinite by less than dw must not pass as quasi-definite because a sticky regularisation level starts with dw > 0
+        double L0[KKT_NV_MAX][KKT_NV_MAX];
+        for (int i = 0; i < nv; ++i)
+            for (int j = 0; j <= i; ++j) {
+                double sum = A[i][j] - ((i == j && i < ns && !fx[i]) ? dw : 0.0);
+                for (int t = 0; t < j; ++t) sum -= L0[i][t] * L0[j][t];
+                if (i == j) {
+                    if (!(sum > 0.0)) { ok = false; sum = 1.0; }
+                    L0[i][i] = sqrt(sum);
+                } else {
+                    L0[i][j] = sum / L0[j][j];
+                }
+            }
+    }
     for (int i = 0; i < nv; ++i)
         for (int j = 0; j <= i; ++j) {
             double sum = A[i][j];
@@ -253,6 +270,20 @@ __global__ __launch_bounds__(64) void emi_kkt_node_inverse_fixed_kernel(const do
         _Pragma("unroll") for (int q = 0; q <= v; ++q)
             A[v][q] = (fx[v] || fx[q]) ? (v == q ? 1.0 : 0.0) : Q[(size_t)(v * (v + 1) / 2 + q) * M + k] + ((v == q && v < ns) ? dw : 0.0);
     bool ok = true;
+    if (dw > 0.0) {         // positive definiteness is judged on the caller's block, not on the shifted one (see the generic kernel)
+        double L0[NV_][NV_];
+        _Pragma("unroll") for (int i = 0; i < nv; ++i)
+            _Pragma("unroll") for (int j = 0; j <= i; ++j) {
+                double sum = A[i][j] - ((i == j && i < ns && !fx[i]) ? dw : 0.0);
+                _Pragma("unroll") for (int t = 0; t < j; ++t) sum -= L0[i][t] * L0[j][t];
+                if (i == j) {
+                    if (!(sum > 0.0)) { ok = false; sum = 1.0; }
+                    L0[i][i] = sqrt(sum);
+                } else {
+                    L0[i][j] = sum / L0[j][j];
+                }
+            }
+    }
     _Pragma("unroll") for (int i = 0; i < nv; ++i)
         _Pragma("unroll") for (int j = 0; j <= i; ++j) {
             double sum = A[i][j];
@@ -1048,6 +1079,8 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
     w->factored = false;
     w->lr_active = false;
     w->linv_n = 0;
+    w->reg_dc_applied = dc;
+    w->reg_dw_applied = 0.0;
     if (!w->handle) {
         KKT_RB(rocblas_create_handle(&w->handle));
         // split-K kernels that accumulate with atomics make the factorisation, and with it the iteration path of
@@ -1188,6 +1221,8 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         if (hinfo == 0 && hflag == 0) {
             if (int st = blk_invert(w, stream, (rocblas_int)md, w->S, err)) return st;
             if (attempt == first_attempt) ++w->reg_hits; else { w->reg_level = attempt; w->reg_hits = 0; }
+            w->reg_dc_applied = dc_schur;
+            w->reg_dw_applied = dw_done;
             *info = 0;
             w->factored = true;
             w->method_used = 1;
@@ -1237,6 +1272,13 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
     *info = (int)hinfo;
     w->factored = hinfo == 0;
     return EMI_OK;
+}
+
+// The regularisation the current factorisation holds: the matrix factorised is [[Q + dw I_x, J^T], [J, -dc I]] with dw on the
+// free STATE variables' diagonal only.  dc is at least the caller's; both exceed the nominal values when the Schur path climbed its ladder.
+void kkt_last_regularisation(const KktWorkspace* w, double* dc, double* dw) {
+    if (dc) *dc = w ? w->reg_dc_applied : 0.0;
+    if (dw) *dw = w ? w->reg_dw_applied : 0.0;
 }
 
 // X [N][nrhs] on the device, in place: X <- K~^-1 X with the current factorisation

@@ -61,6 +61,12 @@ class Evaluator:
         self.device = torch.device("cuda", int(device))
         self.dtype = torch.float32 if f32 else torch.float64
         self._keep = []
+        self._lay = None        # cached emi_get_layout / emi_get_delays answers: eval_dev is the timed call of bench.py and of any
+        self._nd = None         # batched user, and two ctypes round trips per pass show at 14 - 20 us passes; reset by every set_*
+
+    def _changed(self):
+        self._lay = None
+        self._nd = None
 
     def close(self):
         if self.ctx:
@@ -81,12 +87,14 @@ class Evaluator:
         tau, w, D = mesh if mesh is not None else lgl(M)
         self.tau, self.w, self.D = (np.ascontiguousarray(a, dtype=np.float64) for a in (tau, w, D))
         self._ck(self.lib.emi_set_mesh(self.ctx, M, _dp(self.tau), _dp(self.w), _dp(self.D), t0, tf), "emi_set_mesh")
+        self._changed()
         self.node_t = t0 + (tf - t0) / 2.0 * (self.tau + 1.0)
 
     def set_model(self, model, params=(), maximize=False):
         p = np.ascontiguousarray(params, dtype=np.float64)
         self._ck(self.lib.emi_set_model(self.ctx, model, _dp(p) if p.size else None, p.size, int(maximize)),
                  "emi_set_model")
+        self._changed()
 
     def set_model_source(self, struct_name, source, ns, nc, params=(), maximize=False, npath=0, path_vars=()):
         """Install a model given as the text of a model struct (compiled for gfx950 here).  npath rows traced from
@@ -97,20 +105,25 @@ class Evaluator:
                                                pv.ctypes.data_as(C.POINTER(C.c_int)) if pv.size else None, pv.size,
                                                _dp(p) if p.size else None, p.size, int(maximize)),
                  "emi_set_model_source")
+        self._changed()
 
     def set_batch(self, B):
         self._ck(self.lib.emi_set_batch(self.ctx, B), "emi_set_batch")
+        self._changed()
 
     def set_delays(self, x_horizon, u_horizon, dt):
         """Delayed states / controls as extra inputs of the node functions (include/emi355x.h, emi_set_delays): the model is
         written on nc + (x_horizon - 1) ns + u_horizon nc controls, evaluations keep taking U[B][nc][M]."""
         self._ck(self.lib.emi_set_delays(self.ctx, int(x_horizon), int(u_horizon), float(dt)), "emi_set_delays")
+        self._changed()
 
     @property
     def n_delayed(self):
-        n = C.c_int()
-        self._ck(self.lib.emi_get_delays(self.ctx, None, None, C.byref(n)), "emi_get_delays")
-        return n.value
+        if self._nd is None:
+            n = C.c_int()
+            self._ck(self.lib.emi_get_delays(self.ctx, None, None, C.byref(n)), "emi_get_delays")
+            self._nd = n.value
+        return self._nd
 
     def set_path(self, recs, px=0, py=1):
         recs = np.ascontiguousarray(recs, dtype=np.float64)
@@ -118,6 +131,7 @@ class Evaluator:
             recs = recs[None]
         nsets, npth = recs.shape[0], recs.shape[1]
         self._ck(self.lib.emi_set_path(self.ctx, npth, nsets, _dp(recs) if recs.size else None, px, py), "emi_set_path")
+        self._changed()
 
     def set_tracks(self, xc, yc):
         xc = np.ascontiguousarray(xc, dtype=np.float64)
@@ -125,15 +139,18 @@ class Evaluator:
         if xc.ndim == 2:
             xc, yc = xc[None], yc[None]
         self._ck(self.lib.emi_set_tracks(self.ctx, xc.shape[1], xc.shape[0], _dp(xc), _dp(yc)), "emi_set_tracks")
+        self._changed()
 
     def use_stream(self, stream_ptr):
         self._ck(self.lib.emi_set_stream(self.ctx, C.c_void_p(stream_ptr)), "emi_set_stream")
 
     @property
     def layout(self):
-        lay = L.Layout()
-        self._ck(self.lib.emi_get_layout(self.ctx, C.byref(lay)), "emi_get_layout")
-        return lay
+        if self._lay is None:
+            lay = L.Layout()
+            self._ck(self.lib.emi_get_layout(self.ctx, C.byref(lay)), "emi_get_layout")
+            self._lay = lay
+        return self._lay
 
     def jac_structure(self):
         lay = self.layout

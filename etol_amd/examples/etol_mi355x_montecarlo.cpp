@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -77,48 +78,61 @@ size_t record_doubles(int M) { return REC_HEAD + (size_t)(6 + 2 + 1) * M; }
 // The 128-byte RCCL id goes from rank 0 to the others through a file (one node, shared /tmp), AT START-UP, before any
 // solving: the ranks of a launch start within seconds of each other, so a bounded wait means something there (after the
 // solves rank 0 may be minutes behind the others).  The name carries what the launcher gives to tell runs apart (launcher
-// pid, MASTER_PORT, torchrun's run id and restart count); a file older than a minute before this process started is a
-// leftover of a crashed run and is not read; rank 0 removes leftovers before it writes and removes its own file once the
-// communicator exists on every rank (comm_file_done).
+// pid, MASTER_PORT, torchrun's run id and restart count).  The file holds, behind the id, that same launch key and rank 0's
+// start time: a reader takes the id only from a file whose key is its own AND whose writer started within
+// EMI_COMM_SKEW_S (15 s) of the reader -- a leftover of a crashed earlier launch under the same name (a quick relaunch from
+// the same shell) fails the second test, where a test on the file's age alone would let it through and the ranks would
+// then wait in ncclCommInitRank on different ids with no diagnostic.  Rank 0 removes leftovers before it writes and its own
+// file once the communicator exists on every rank (comm_file_done).
+std::string comm_launch_key() {
+    auto env = [](const char* n, const char* d) { const char* v = getenv(n); return std::string(v ? v : d); };
+    return std::to_string((long)getppid()) + "_" + env("MASTER_PORT", "0") + "_" + env("TORCHELASTIC_RUN_ID", "run") + "_" +
+           env("TORCHELASTIC_RESTART_COUNT", "0");
+}
 std::string comm_file_path() {
     if (getenv("EMI_COMM_FILE")) return getenv("EMI_COMM_FILE");
-    auto env = [](const char* n, const char* d) { const char* v = getenv(n); return std::string(v ? v : d); };
-    return "/tmp/emi_comm_" + std::to_string((long)getppid()) + "_" + env("MASTER_PORT", "0") + "_" + env("TORCHELASTIC_RUN_ID", "run") +
-           "_" + env("TORCHELASTIC_RESTART_COUNT", "0") + ".id";
+    return "/tmp/emi_comm_" + comm_launch_key() + ".id";
 }
+constexpr size_t COMM_KEY_BYTES = 160;
 bool exchange_id(int rank, char* id, double process_start_s, std::string* why) {
-    const std::string path = comm_file_path();
+    const std::string path = comm_file_path(), key = comm_launch_key();
     if (rank == 0) {
         unlink(path.c_str());                            // a leftover of an earlier run under the same name
         if (emi_comm_unique_id(id) != EMI_OK) { *why = std::string("emi_comm_unique_id: ") + emi_comm_last_error(nullptr); return false; }
+        char keybuf[COMM_KEY_BYTES] = {0};
+        strncpy(keybuf, key.c_str(), COMM_KEY_BYTES - 1);
         const std::string tmp = path + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id, 1, EMI_COMM_ID_BYTES, f) != EMI_COMM_ID_BYTES) { *why = "cannot write " + tmp; if (f) fclose(f); return false; }
+        if (!f || fwrite(id, 1, EMI_COMM_ID_BYTES, f) != EMI_COMM_ID_BYTES || fwrite(keybuf, 1, COMM_KEY_BYTES, f) != COMM_KEY_BYTES ||
+            fwrite(&process_start_s, sizeof process_start_s, 1, f) != 1) {
+            *why = "cannot write " + tmp;
+            if (f) fclose(f);
+            return false;
+        }
         fclose(f);
         if (rename(tmp.c_str(), path.c_str()) != 0) { *why = "cannot rename " + tmp; return false; }
         return true;
     }
     const int timeout_s = std::max(1, env_int("EMI_COMM_TIMEOUT_S", 120));
+    const double skew_s = std::max(1, env_int("EMI_COMM_SKEW_S", 15));
     bool stale = false;
     for (int tries = 0; tries < timeout_s * 10; ++tries) {
-        struct stat sb;
-        if (stat(path.c_str(), &sb) == 0) {
-            const double mt = (double)sb.st_mtim.tv_sec + 1e-9 * (double)sb.st_mtim.tv_nsec;
-            if (mt < process_start_s - 60.0) {
-                stale = true;                            // not this launch's file: wait for rank 0 to replace it
-            } else {
-                FILE* f = fopen(path.c_str(), "rb");
-                if (f) {
-                    const size_t n = fread(id, 1, EMI_COMM_ID_BYTES, f);
-                    fclose(f);
-                    if (n == EMI_COMM_ID_BYTES) return true;
-                }
-            }
+        FILE* f = fopen(path.c_str(), "rb");
+        if (f) {
+            char keybuf[COMM_KEY_BYTES] = {0};
+            double writer_start = 0;
+            const bool whole = fread(id, 1, EMI_COMM_ID_BYTES, f) == EMI_COMM_ID_BYTES && fread(keybuf, 1, COMM_KEY_BYTES, f) == COMM_KEY_BYTES &&
+                               fread(&writer_start, sizeof writer_start, 1, f) == 1;
+            fclose(f);
+            keybuf[COMM_KEY_BYTES - 1] = 0;
+            if (whole && key == keybuf && std::fabs(writer_start - process_start_s) <= skew_s) return true;
+            if (whole) stale = true;                     // not this launch's file: wait for rank 0 to replace it
         }
         usleep(100000);
     }
     *why = "no RCCL id from rank 0 in " + path + " after " + std::to_string(timeout_s) + " s (EMI_COMM_TIMEOUT_S)" +
-           (stale ? "; only a file of an earlier run is there" : "") + ": is rank 0 running, and is /tmp shared between the ranks?";
+           (stale ? "; only a file of another launch is there (launch key or start time differ: EMI_COMM_SKEW_S)" : "") +
+           ": is rank 0 running, and is /tmp shared between the ranks?";
     return false;
 }
 void comm_file_done(int rank) {

@@ -117,6 +117,7 @@ struct eMI355X::Device : public mi355x::NlpEvaluator, public mi355x::KktBackend 
         return st == EMI_OK ? 0 : -1;
     }
     int solve(double* rhs, int nrhs) override { return emi_kkt_solve(ctx, rhs, nrhs) == EMI_OK ? 0 : -1; }
+    void applied_regularisation(double* dc, double* dw) override { (void)emi_kkt_last_regularisation(ctx, dc, dw); }
     std::string last_error() const override { return ctx ? emi_last_error(ctx) : "no device context"; }
 };
 

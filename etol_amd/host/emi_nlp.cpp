@@ -731,7 +731,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     std::vector<unsigned char> fixed_mask(nz);
     for (int q = 0; q < nz; ++q) fixed_mask[q] = fidx[q] < 0 ? 1 : 0;
     std::vector<BlockMod> mods;
-    std::vector<double> Qexact, rhs_keep(NN0), resid(NN0);
+    std::vector<double> Qexact, rhs_keep(NN0), resid(NN0), x_prev(NN0);
     bool exact_step = false;
     const int max_lowrank = 4096;        // more modified eigenpairs than this: take the modified step untested
     std::vector<double> dz(nz), ds(mc), de1(mc), de2(mc), dlam(md), dy(mc), dzL(nz), dzU(nz), dvL(mc), dvU(mc),
@@ -1066,24 +1066,46 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             if (!finite) { dc = dc == 0.0 ? 1e-8 * std::pow(mu, 0.25) : dc * 100.0; continue; }
             // iterative refinement against the matrix the step belongs to (K if exact, K~ otherwise): the
             // factorisation of a 1000-node KKT matrix leaves residuals that would stall the Newton
-            // iteration some orders above the requested tolerance
+            // iteration some orders above the requested tolerance.  The backend may have factorised a MORE regularised
+            // matrix than it was given (applied_regularisation: the Schur path's ladder); the refinement then is a
+            // stationary iteration with (K + E)^-1 that need not contract, so a correction that makes the residual worse
+            // is taken back, and the residual the step is finally used with is recorded (an inexact Newton step: the
+            // line search below still decides; R.worst_step_residual lets a caller see how inexact).
             {
                 const std::vector<double>& Qm = exact_step ? Qexact : Qblk;
+                double dc_applied = dc, dw_applied = 0.0;
+                kkt->applied_regularisation(&dc_applied, &dw_applied);
+                const bool shifted = dw_applied > 0.0 || dc_applied > std::max(dc, 1e-9) * 1.0001;
+                if (shifted) ++R.n_backend_shifted;
                 double bmax = 0;
                 for (size_t r = 0; r < NN; ++r) bmax = std::max(bmax, std::fabs(rhs_keep[r]));
-                double prev = 1e300;
+                double prev = 1e300, rlast = 0.0;
+                bool have_prev = false;
                 for (int ir = 0; ir < 8; ++ir) {      // (8 since the backend may have regularised the factorised matrix: linear convergence)
                     { const auto tm = now(); kkt_matvec(Qm.data(), rhs_full.data(), resid.data(), dc); R.t_matvec += secs(tm, now()); }
                     double rmax = 0;
                     for (size_t r = 0; r < NN; ++r) { resid[r] = rhs_keep[r] - resid[r]; rmax = std::max(rmax, std::fabs(resid[r])); }
+                    if (have_prev && !(rmax < prev)) {          // the last correction did harm: undo it and stop
+                        for (size_t r = 0; r < NN; ++r) rhs_full[r] = x_prev[r];
+                        ++R.n_refine_reverted;
+                        rlast = prev;
+                        break;
+                    }
+                    rlast = rmax;
                     if (!(rmax > 1e-14 * std::max(1.0, bmax)) || !(rmax < 0.5 * prev)) break;
                     prev = rmax;
                     { const auto ts = now(); const int rs = kkt->solve(resid.data(), 1); R.t_solve += secs(ts, now()); ++R.n_solve; if (rs != 0) break; }
                     bool fin = true;
                     for (size_t r = 0; r < NN && fin; ++r) fin = std::isfinite(resid[r]);
                     if (!fin) break;
+                    x_prev.assign(rhs_full.begin(), rhs_full.begin() + NN);
+                    have_prev = true;
                     for (size_t r = 0; r < NN; ++r) rhs_full[r] += resid[r];
                 }
+                const double rel = rlast / std::max(1.0, bmax);
+                R.worst_step_residual = std::max(R.worst_step_residual, rel);
+                if (opt.print_level >= 5 && shifted && rel > 1e-6)
+                    printf("          backend factorised with dc %.1e dw %.1e; step used with relative residual %.2e\n", dc_applied, dw_applied, rel);
             }
             if (exact_step) dw = dw_shift;     // the log shows delta_w of an exact step, else the largest reflected shift
             factored = true;

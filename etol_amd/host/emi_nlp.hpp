@@ -50,6 +50,9 @@ class KktBackend {
     // correction kept by the backend), otherwise for K~.  r = 0 clears.  0 on success.
     virtual int lowrank(int r, const int* node, const double* vec, const double* delta, bool* exact) = 0;
     virtual int solve(double* rhs, int nrhs) = 0;   // rhs [nrhs][nz+md], in place; 0 on success
+    // what the last factor() really factorised: [[Q + dw I_x, J^T], [J, -dc I]] (dw on the free state variables).  A backend
+    // that never regularises on its own leaves both untouched (the caller presets them to its nominal dc and 0).
+    virtual void applied_regularisation(double* dc, double* dw) { (void)dc; (void)dw; }
     virtual std::string last_error() const { return std::string(); }
 };
 
@@ -103,6 +106,9 @@ struct NlpResult {
     int n_factor = 0, n_solve = 0;      // factorisations (inertia-search trials included) and solve calls
     double t_jt = 0, t_matvec = 0, t_blocks = 0, t_hess = 0;   // host: J^T lambda, refinement matvecs, node-block assembly + eigen-decompositions; Hessian calls
     double rho = 0;                     // penalty weight the solve ended with (warm start of the next mesh)
+    int n_backend_shifted = 0;          // factorisations the backend regularised beyond the nominal matrix (applied_regularisation)
+    int n_refine_reverted = 0;          // refinement corrections taken back because they made the residual worse
+    double worst_step_residual = 0;     // largest relative residual |b - K x| / max(1, |b|) a Newton step was used with
 };
 
 NlpResult solve_nlp(const NlpProblem& prob, const NlpOptions& opt, const std::vector<double>& z0);

@@ -237,6 +237,14 @@ int emi_kkt_factor(emi_ctx_t ctx, const double* Qblk, const double* Jblk,
  * solutions of K (Woodbury), else of K~.  r = 0 clears the correction.       */
 int emi_kkt_lowrank(emi_ctx_t ctx, int r, const int* node, const double* vec,
                     const double* delta, int* exact);
+/* What the last emi_kkt_factor really factorised: [[Q + dw I_x, J^T], [J, -dc I]]
+ * with dw on the diagonal of the free STATE variables.  dc >= the caller's and
+ * dw >= 0; they exceed the nominal (dc, 0) when the Schur path had to climb its
+ * regularisation ladder (csrc/emi_kkt.hip).  A caller that refines its step
+ * against the nominal matrix reads them to know the step is inexact -- what
+ * IPOPT's delta_w / delta_c tell its own iteration
+ * (reference src/ePSOPT/ePSOPT.cpp:62-66: nlp_method "IPOPT").                */
+int emi_kkt_last_regularisation(emi_ctx_t ctx, double* dc, double* dw);
 /* rhs [nrhs][N] (one right-hand side after the other) in, solutions out;
  * may be called repeatedly after one factor.                               */
 int emi_kkt_solve(emi_ctx_t ctx, double* rhs, int nrhs);

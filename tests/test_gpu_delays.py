@@ -176,3 +176,37 @@ def test_delay_declarations_are_checked(built):
     assert lib.emi_set_delays(ev.ctx, 0, 1, C.c_double(0.1)) == 0                 # 2 = 1 free control + its delayed copy
     assert ev.n_delayed == 1
     ev.close()
+
+
+def test_mesh_change_after_set_delays_rebuilds_the_interpolation_matrices(built):
+    """set_mesh(33) -> set_delays -> eval -> set_mesh(128) -> eval (a refinement loop's order of calls): W(delay) is built per
+    mesh ([nd][M][M] on ITS nodes and horizon), so a new mesh must mark it stale -- left alone, the second evaluation reads a
+    33 x 33 operator as 128 x 128 (past the allocation) or, with an unchanged M and a new horizon, returns wrong delayed values."""
+    import etol_amd as E
+    h = _harness()
+    z = np.zeros(4 * 9)
+    res, vals = np.zeros(64 * 9), np.zeros(256 * 9)
+    cost, nres, nvals = C.c_double(), C.c_int(), C.c_int()
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    assert h.harness_delay_demo(8, C.c_double(0.5), 3, 1, 0, dp(z), dp(res), res.size, dp(vals), vals.size, C.byref(cost),
+                                C.byref(nres), C.byref(nvals)) == 0
+    source = h.harness_last_message().decode()
+    dt, B = 0.2, 3
+    ev = E.Evaluator(0)
+    ev.set_mesh(33, 0.0, 6.0)
+    ev.set_model_source("TracedModel", source, 2, 8)
+    ev.set_delays(3, 1, dt)
+    ev.set_batch(B)
+    ev.set_path(DISC, 0, 1)
+    for M, t0, tf in ((33, 0.0, 6.0), (128, 0.0, 6.0), (128, 0.0, 9.0), (33, 1.0, 4.0)):      # larger mesh, new horizon, smaller mesh
+        ev.set_mesh(M, t0, tf)
+        ev.set_path(DISC, 0, 1)
+        rng = np.random.default_rng(M + int(tf))
+        t = ev.node_t
+        X = np.ascontiguousarray(np.stack([1 + 0.5 * np.sin(0.7 * t + rng.uniform(0, 3, (B, 1))),
+                                           2 - 0.1 * t + 0.3 * np.cos(t + rng.uniform(0, 3, (B, 1)))], axis=1))
+        U = np.ascontiguousarray(np.stack([0.3 * np.cos(t + rng.uniform(0, 3, (B, 1))),
+                                           0.2 + 0.1 * np.sin(2 * t + rng.uniform(0, 3, (B, 1)))], axis=1))
+        ref = O.evaluate(3, P3, M, (ev.tau, ev.w, ev.D), t0, tf, X, _extended(X, U, ev.tau, t0, tf, dt), DISC)
+        _check(*ev.eval_host(X, U), ref, X, ev.D)
+    ev.close()
