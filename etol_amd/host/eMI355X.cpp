@@ -420,7 +420,9 @@ void eMI355X::configureDevice(Device* dev) {
              "emi_set_model");
         dev->installed_source.clear();
     }
-    must(emi_set_delays(c, (int)P.xhorizon, (int)P.uhorizon, P.delay_dt > 0 ? P.delay_dt : 1.0), c, "emi_set_delays");
+    // (lifted: solve() iterates on the delayed values as variables of their node and ties them to their sources itself)
+    if (P.lifted) must(emi_set_delays(c, 0, 0, 1.0), c, "emi_set_delays");
+    else must(emi_set_delays(c, (int)P.xhorizon, (int)P.uhorizon, P.delay_dt > 0 ? P.delay_dt : 1.0), c, "emi_set_delays");
     must(emi_set_batch(c, 1), c, "emi_set_batch");
     if (P.ntracks)
         must(emi_set_tracks(c, (int)P.ntracks, 1, P.track_x.data(), P.track_y.data()), c, "emi_set_tracks");
@@ -536,14 +538,14 @@ double eMI355X::odeError(const std::vector<double>& z, std::vector<double>* z_fi
 namespace mi355x {
 
 NlpProblem make_nlp(const Prob& P, NlpEvaluator* ev) {
-    const size_t ns = P.nstates, nc = P.ncontrols, M = P.nodes, nv = ns + nc;
+    const size_t ns = P.nstates, ncf = P.ncontrols, nc = ncf + (P.lifted ? P.ndelayed : 0), M = P.nodes, nv = ns + nc;
     NlpProblem nlp;
     nlp.ns = (int)ns; nlp.nc = (int)nc; nlp.np = (int)P.npath; nlp.M = (int)M;
     nlp.px = (int)P.px; nlp.py = (int)P.py;
     // (variable, VALS entry) pairs of every path row: table rows two partials on (px, py), traced rows one per variable
     // of the model's list
     {
-        const int nv = (int)(P.nstates + P.ncontrols), base = (int)P.nstates * nv;
+        const int nv = (int)(P.nstates + nc), base = (int)P.nstates * nv;
         const int ntab = (int)(P.npath - P.npath_traced), pw = (int)P.path_vars.size();
         nlp.row_vars.clear();
         for (int j = 0; j < ntab; ++j) nlp.row_vars.push_back({{(int)P.px, base + 2 * j}, {(int)P.py, base + 2 * j + 1}});
@@ -567,9 +569,27 @@ NlpProblem make_nlp(const Prob& P, NlpEvaluator* ev) {
         }
     for (size_t j = 0; j < nc; ++j)
         for (size_t k = 0; k < M; ++k) {
-            nlp.zl[(ns + j) * M + k] = P.control_lower[j];
-            nlp.zu[(ns + j) * M + k] = P.control_upper[j];
+            nlp.zl[(ns + j) * M + k] = j < ncf ? P.control_lower[j] : -1e20;        // delayed values: free
+            nlp.zu[(ns + j) * M + k] = j < ncf ? P.control_upper[j] : 1e20;
         }
+    if (P.lifted) {
+        // coupling rows, in the order ePSOPT::dae appends the delayed values (reference ePSOPT.cpp:231-248; emi_set_delays):
+        // x(t - i dt) of every state for i = 1 .. xhorizon - 1, then u(t - i dt) of every control for i = 1 .. uhorizon
+        std::vector<double> W(M * M);
+        size_t slot = ns + ncf;
+        auto add = [&](size_t src, double delay) {
+            if (emi_delay_matrix((int)M, P.tau.data(), P.w.data(), P.t0, P.tf, delay, W.data()) != EMI_OK) return;
+            NlpLink L;
+            L.dst = (int)slot++;
+            L.src = (int)src;
+            L.W = W;
+            nlp.links.push_back(std::move(L));
+        };
+        for (size_t i = 1; i < P.xhorizon; ++i)
+            for (size_t st = 0; st < ns; ++st) add(st, (double)i * P.delay_dt);
+        for (size_t i = 1; i <= P.uhorizon; ++i)
+            for (size_t c = 0; c < ncf; ++c) add(ns + c, (double)i * P.delay_dt);
+    }
     nlp.cl = P.path_lower;
     nlp.cu = P.path_upper;
     // keep-out rows are iterated on normalised: ellipse / (a^2 b^2), disc / r^2
@@ -604,6 +624,12 @@ std::vector<double> bound_scales(const Prob& P) {
         m = mag(P.control_lower[j], m);
         m = mag(P.control_upper[j], m);
         if (m > 0) s[ns + j] = m;
+    }
+    if (P.lifted) {          // a delayed value is scaled like its source, so its coupling row keeps the interpolation operator as it is
+        for (size_t i = 1; i < P.xhorizon; ++i)
+            for (size_t st = 0; st < ns; ++st) s.push_back(s[st]);
+        for (size_t i = 1; i <= P.uhorizon; ++i)
+            for (size_t c = 0; c < nc; ++c) s.push_back(s[ns + c]);
     }
     return s;
 }
@@ -669,6 +695,25 @@ std::vector<double> initial_guess(const Prob& P) {
     if (P.guess_states.size() == ns * M) std::copy(P.guess_states.begin(), P.guess_states.end(), z0.begin());
     if (P.guess_controls.size() == nc * M)
         std::copy(P.guess_controls.begin(), P.guess_controls.end(), z0.begin() + ns * M);
+    if (P.lifted && P.ndelayed > 0) {
+        // delayed values start consistent with their sources (coupling rows satisfied): W(i dt) . guess
+        z0.resize((ns + nc + P.ndelayed) * M, 0.0);
+        std::vector<double> W(M * M);
+        size_t slot = ns + nc;
+        auto fill = [&](size_t src, double delay) {
+            if (emi_delay_matrix((int)M, P.tau.data(), P.w.data(), P.t0, P.tf, delay, W.data()) != EMI_OK) return;
+            for (size_t k = 0; k < M; ++k) {
+                double acc = 0;
+                for (size_t j = 0; j < M; ++j) acc += W[k * M + j] * z0[src * M + j];
+                z0[slot * M + k] = acc;
+            }
+            ++slot;
+        };
+        for (size_t i = 1; i < P.xhorizon; ++i)
+            for (size_t st = 0; st < ns; ++st) fill(st, (double)i * P.delay_dt);
+        for (size_t i = 1; i <= P.uhorizon; ++i)
+            for (size_t c = 0; c < nc; ++c) fill(ns + c, (double)i * P.delay_dt);
+    }
     return z0;
 }
 
@@ -693,10 +738,30 @@ void eMI355X::evaluate(const std::vector<double>& z, std::vector<double>* res, s
 void eMI355X::solve() {
     if (!_dev || !_dev->ctx) die("solve() called before setup()");
     mi355x::Prob& P = _problem;
-    if (P.ndelayed > 0)
-        die("solve(): delayed states / controls are evaluated on the device (setup(), evaluate()), but the Newton step of this "
-            "backend is built on a node-diagonal Jacobian plus D (x) I; the interpolation operator of a delayed value couples a "
-            "node to the whole trajectory and has no place in it yet (INTEGRATION.md, limitations)");
+    // Delayed states / controls (reference ePSOPT.cpp:231-248).  ePSOPT hands them to IPOPT through PSOPT like any other dependency of
+    // the node functions.  Here the delayed values become variables of their node for the duration of the solve ("lifted"), tied to their
+    // sources by linear coupling rows with the interpolation operators W(i dt) of the mesh: node functions, Jacobian entries and Hessian
+    // blocks stay node-local (the device kernels on the extended node variables, unchanged), W appears as constant rows of the KKT matrix.
+    // The Newton step of such a problem runs on the dense host backend (the structured device step has no place for a second operator
+    // beside D yet), so the mesh is bounded; mesh sequencing and refinement are off (the ODE-error estimate evaluates between the nodes,
+    // where the delayed values of a points-only mesh are not defined).
+    struct Lift {
+        eMI355X* self;
+        bool on;
+        ~Lift() {
+            if (!on) return;
+            self->_problem.lifted = false;
+            self->configureDevice(self->_dev.get());          // evaluate() forms the delayed values on the device again
+        }
+    } lift{this, P.ndelayed > 0};
+    if (lift.on) {
+        const size_t rows = (2 * P.nstates + P.ncontrols + 2 * P.ndelayed) * P.nodes;
+        if (rows > 4000)
+            die("solve(): a problem with delayed states / controls is solved with the dense host backend, which takes up to 4000 KKT rows; "
+                "this one has " + std::to_string(rows) + " ((2 nstates + ncontrols + 2 ndelayed) x nodes): use fewer nodes");
+        P.lifted = true;
+        configureDevice(_dev.get());
+    }
     const size_t ns = P.nstates, nc = P.ncontrols;
 
     mi355x::NlpOptions opt;
@@ -723,8 +788,8 @@ void eMI355X::solve() {
         mi355x::NlpProblem nlp = mi355x::make_nlp(P, _dev.get());
         // Newton-step linear algebra: small KKT systems on the host, the rest on the device
         const size_t kkt_rows = (2 * ns + nc) * P.nodes;
-        const bool dev_kkt = _algorithm.linear_solver == "device" ||
-                             (_algorithm.linear_solver == "auto" && kkt_rows > 400);
+        const bool dev_kkt = !P.lifted && (_algorithm.linear_solver == "device" ||
+                                           (_algorithm.linear_solver == "auto" && kkt_rows > 400));
         nlp.kkt = dev_kkt ? static_cast<mi355x::KktBackend*>(_dev.get()) : nullptr;
         if (_algorithm.scaling == "automatic") nlp.vscale = mi355x::bound_scales(P);
         else if (_algorithm.scaling != "none") die("Alg::scaling must be \"automatic\" or \"none\"");
@@ -835,7 +900,7 @@ void eMI355X::solve() {
     std::vector<size_t> ladder;
     const std::vector<double> true_records = P.path_records;
     double span = 0;
-    if (_algorithm.mesh_sequencing && P.nodes > 80 && P.guess_states.empty()) {
+    if (_algorithm.mesh_sequencing && P.nodes > 80 && P.guess_states.empty() && !P.lifted) {
         for (size_t m = 33; m < target; m = 2 * m - 1) ladder.push_back(m);
         // Constraints hold at the nodes only, so a coarse mesh can step over a thin keep-out ("tunnelling") and leave
         // the finer meshes a start on the wrong side of it.  On the ladder the keep-outs of the record table are
@@ -923,7 +988,7 @@ void eMI355X::solve() {
 
     // PSOPT's mesh refinement ("automatic", ePSOPT.cpp:69-71): solve, estimate the ODE error,
     // add nodes and re-solve from the interpolated solution until the tolerance is met.
-    const bool refine = _algorithm.mesh_refinement == "automatic";
+    const bool refine = _algorithm.mesh_refinement == "automatic" && !P.lifted;
     mi355x::NlpResult r_good;           // last converged solution and its mesh
     size_t M_good = 0;
     for (int mr = 0;; ++mr) {
@@ -998,7 +1063,7 @@ void eMI355X::solve() {
     _solution.ncontrols = nc;
     _solution.nodes = M;
     _solution.states.assign(r.z.begin(), r.z.begin() + ns * M);
-    _solution.controls.assign(r.z.begin() + ns * M, r.z.end());
+    _solution.controls.assign(r.z.begin() + ns * M, r.z.begin() + (ns + nc) * M);      // (a lifted solve carries the delayed values behind them)
     _solution.time.resize(M);
     for (size_t k = 0; k < M; ++k) _solution.time[k] = P.t0 + (P.tf - P.t0) / 2.0 * (P.tau[k] + 1.0);
     setScore(isMaximized() ? -_solution.cost : _solution.cost);

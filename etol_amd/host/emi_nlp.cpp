@@ -174,6 +174,7 @@ struct Iterate {
 
 struct Eval {
     std::vector<double> RES, VALS, H;
+    std::vector<double> LNK;          // residuals of the coupling rows (NlpProblem::links), [link][M]
     double cost = 0;
 };
 
@@ -289,7 +290,7 @@ class DenseHostKkt : public KktBackend {
  public:
     explicit DenseHostKkt(const NlpProblem& P) : _P(P) {}
     int factor(const double* Qblk, const double* Jblk, const unsigned char* fx, double dc) override {
-        const int M = _P.M, ns = _P.ns, nv = ns + _P.nc, nz = nv * M, N = nz + ns * M;
+        const int M = _P.M, ns = _P.ns, nv = ns + _P.nc, nz = nv * M, md = ns * M, N = nz + md + (int)_P.links.size() * M;
         _F.n = N;
         _r = 0;
         _F.a.assign((size_t)N * N, 0.0);
@@ -310,6 +311,17 @@ class DenseHostKkt : public KktBackend {
                     if (!_fixed[v * M + k]) row[v * M + k] = Jblk[(size_t)(i * nv + v) * M + k];
                 row[nz + i * M + k] = -dc;
             }
+        // coupling rows  z[dst][k] - sum_j W[k][j] z[src][j] = 0  (delayed values): constant entries, regularised like the defects
+        for (size_t l = 0; l < _P.links.size(); ++l) {
+            const NlpLink& L = _P.links[l];
+            for (int k = 0; k < M; ++k) {
+                double* row = a + (size_t)(nz + md + (int)l * M + k) * N;
+                for (int j = 0; j < M; ++j)
+                    if (!_fixed[L.src * M + j]) row[L.src * M + j] = -L.W[(size_t)k * M + j];
+                if (!_fixed[L.dst * M + k]) row[L.dst * M + k] += 1.0;
+                row[nz + md + (int)l * M + k] = -dc;
+            }
+        }
         _ok = ldlt_factor(_F) && _F.nzero == 0;
         return _ok ? 0 : 1;
     }
@@ -488,6 +500,13 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     NlpResult R;
     const int ns = P.ns, nc = P.nc, np = P.np, M = P.M, nv = ns + nc;
     const int nz = nv * M, md = ns * M, mc = np * M, nh = nv * (nv + 1) / 2;
+    const int nl = (int)P.links.size(), ml = nl * M, me = md + ml;      // coupling rows behind the defects: me equality multipliers
+    for (const NlpLink& L : P.links)
+        if (L.dst < 0 || L.dst >= nv || L.src < 0 || L.src >= nv || L.dst == L.src || (int)L.W.size() != M * M) {
+            R.msg = "solve_nlp: a coupling row names variables outside the problem or has no M x M operator";
+            return R;
+        }
+    if (nl > 0 && P.kkt) { R.msg = "solve_nlp: coupling rows (delayed values) are solved with the dense host backend only"; return R; }
     // (variable, VALS entry) pairs of every path row
     std::vector<std::vector<std::pair<int, int>>> rv = P.row_vars;
     if (rv.empty())
@@ -503,6 +522,8 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         }
         for (double sv : P.vscale)
             if (!(sv > 0) || !std::isfinite(sv)) { R.msg = "solve_nlp: vscale must be positive"; return R; }
+        for (const NlpLink& L : P.links)        // (d - W z) / s keeps W only if both ends carry the same scale
+            if (P.vscale[L.dst] != P.vscale[L.src]) { R.msg = "solve_nlp: a coupled variable must be scaled like its source"; return R; }
         NlpProblem Q = P;
         Q.vscale.clear();
         Q.row_vars = rv;
@@ -587,6 +608,17 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         const int est = P.ev->eval(z.data(), z.data() + (size_t)ns * M, e.RES.data(), jac ? e.VALS.data() : nullptr, &e.cost, jac);
         R.t_eval += secs(te, now());
         if (est != 0) return false;
+        e.LNK.resize(ml);
+        for (int l = 0; l < nl; ++l) {
+            const NlpLink& L = P.links[l];
+            const double* src = &z[(size_t)L.src * M];
+            for (int k = 0; k < M; ++k) {
+                const double* Wk = &L.W[(size_t)k * M];
+                double acc = 0;
+                for (int j = 0; j < M; ++j) acc += Wk[j] * src[j];
+                e.LNK[(size_t)l * M + k] = z[(size_t)L.dst * M + k] - acc;
+            }
+        }
         for (int j = 0; j < np; ++j) {
             if (sig[j] == 1.0) continue;
             for (int k = 0; k < M; ++k) {
@@ -619,9 +651,10 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         it.e1[r] = std::max(gap, 0.0) + ee;     // residual c - s - e1 + e2 starts at exactly 0
         it.e2[r] = std::max(-gap, 0.0) + ee;
     }
-    it.lam.assign(md, 0.0);
+    it.lam.assign(me, 0.0);
     it.y.assign(mc, 0.0);
-    if ((int)P.lamF0.size() == md) it.lam = P.lamF0;
+    if ((int)P.lamF0.size() == md) std::copy(P.lamF0.begin(), P.lamF0.end(), it.lam.begin());
+    auto eqr = [&](const Eval& e, int r) { return r < md ? e.RES[r] : e.LNK[r - md]; };      // residual of equality row r
     if ((int)P.lamC0.size() == mc)      // iterated on in scaled form; inside the penalty box
         for (int r = 0; r < mc; ++r) it.y[r] = std::min(std::max(P.lamC0[r] / sig[r / M], -0.9 * rho), 0.9 * rho);
     it.zL.assign(nz, 0.0); it.zU.assign(nz, 0.0);
@@ -660,6 +693,17 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 const double yy = I.y[j * M + k];
                 for (const auto& ve : rv[j]) jtl[ve.first * M + k] += V[(size_t)ve.second * M + k] * yy;
             }
+        for (int l = 0; l < nl; ++l) {          // coupling rows: + nu on the coupled variable, - W^T nu on its source
+            const NlpLink& L = P.links[l];
+            double* col = &jtl[(size_t)L.src * M];
+            for (int k = 0; k < M; ++k) {
+                const double nu_k = I.lam[md + l * M + k];
+                if (nu_k == 0.0) continue;
+                jtl[(size_t)L.dst * M + k] += nu_k;
+                const double* Wk = &L.W[(size_t)k * M];
+                for (int j = 0; j < M; ++j) col[j] -= Wk[j] * nu_k;
+            }
+        }
     };
     auto row_res = [&](const Eval& e, const std::vector<double>& s, const std::vector<double>& e1,
                        const std::vector<double>& e2, int r) { return e.RES[(size_t)md + r] - s[r] - e1[r] + e2[r]; };
@@ -672,9 +716,9 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             cntz += (I.vL[r] > 0) + (I.vU[r] > 0) + 2;
             summ += std::fabs(I.y[r]);
         }
-        for (int r = 0; r < md; ++r) summ += std::fabs(I.lam[r]);
+        for (int r = 0; r < me; ++r) summ += std::fabs(I.lam[r]);
         const double smax = 100.0;
-        const double sd = std::max(smax, (summ + sumz) / std::max(1, md + mc + cntz)) / smax;
+        const double sd = std::max(smax, (summ + sumz) / std::max(1, me + mc + cntz)) / smax;
         const double sc = std::max(smax, sumz / std::max(1, cntz)) / smax;
         double ed = 0, ep = 0, ec = 0, emax = 0;
         for (int q = 0; q < nz; ++q)
@@ -684,7 +728,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             ed = std::max(ed, std::fabs(rho - I.y[r] - I.w1[r]));
             ed = std::max(ed, std::fabs(rho + I.y[r] - I.w2[r]));
         }
-        for (int r = 0; r < md; ++r) ep = std::max(ep, std::fabs(E.RES[r]));
+        for (int r = 0; r < me; ++r) ep = std::max(ep, std::fabs(eqr(E, r)));
         for (int r = 0; r < mc; ++r) {
             ep = std::max(ep, std::fabs(row_res(E, I.s, I.e1, I.e2, r)));
             emax = std::max(emax, std::max(I.e1[r], I.e2[r]));
@@ -718,23 +762,23 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             phi += rho * (e1[r] + e2[r]) - mu_t * (std::log(e1[r]) + std::log(e2[r]));
             viol += std::fabs(row_res(e, s, e1, e2, r));
         }
-        for (int r = 0; r < md; ++r) viol += std::fabs(e.RES[r]);
+        for (int r = 0; r < me; ++r) viol += std::fabs(eqr(e, r));
         if (infeas) *infeas = viol;
         return phi + nu_t * viol;
     };
 
     // Newton-step linear algebra: the caller's backend (eMI355X: the device) or the dense host one
-    const size_t NN0 = (size_t)nz + md;
+    const size_t NN0 = (size_t)nz + me;
     DenseHostKkt host_kkt(P);
     KktBackend* kkt = P.kkt ? P.kkt : &host_kkt;
-    std::vector<double> Qblk((size_t)nh * M), rhs_full((size_t)nz + md);
+    std::vector<double> Qblk((size_t)nh * M), rhs_full((size_t)nz + me), eqres(me);
     std::vector<unsigned char> fixed_mask(nz);
     for (int q = 0; q < nz; ++q) fixed_mask[q] = fidx[q] < 0 ? 1 : 0;
     std::vector<BlockMod> mods;
     std::vector<double> Qexact, rhs_keep(NN0), resid(NN0), x_prev(NN0);
     bool exact_step = false;
     const int max_lowrank = 4096;        // more modified eigenpairs than this: take the modified step untested
-    std::vector<double> dz(nz), ds(mc), de1(mc), de2(mc), dlam(md), dy(mc), dzL(nz), dzU(nz), dvL(mc), dvU(mc),
+    std::vector<double> dz(nz), ds(mc), de1(mc), de2(mc), dlam(me), dy(mc), dzL(nz), dzU(nz), dvL(mc), dvU(mc),
         dw1(mc), dw2(mc);
     std::vector<double> sig_t(mc), r_t(mc), sig_s(mc), rhat_s(mc);
     Eval Et, Ekeep;
@@ -743,7 +787,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     std::vector<double> zt(nz), st(mc), e1t(mc), e2t(mc);
 
     // ---- pieces of one Newton step, shared by the regular step and the second-order correction ----
-    const size_t NN = (size_t)nz + md;
+    const size_t NN = (size_t)nz + me;
     int r_mod = 0;
     // r_t of the eliminated path rows for given row residuals  c - s - e1 + e2
     auto fill_rt = [&](const std::vector<double>& rowres) {
@@ -770,9 +814,9 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 for (const auto& ve : rv[j])
                     if (fidx[ve.first * M + k] >= 0) out[ve.first * M + k] -= V[(size_t)ve.second * M + k] * t;
             }
-        for (int r = 0; r < md; ++r) out[nz + r] = -defres[r];
+        for (int r = 0; r < me; ++r) out[nz + r] = -defres[r];
     };
-    std::vector<double> soc_def(md), soc_row(mc), soc_rhs(NN), lr_vec, lr_delta;
+    std::vector<double> soc_def(me), soc_row(mc), soc_rhs(NN), lr_vec, lr_delta;
     std::vector<int> lr_node;
     // y = [[Q, J^T], [J, -dc I]] x  with the node blocks Qb (fixed variables: identity rows/columns)
     std::vector<double> xfree;
@@ -816,6 +860,21 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                     y[v * M + k] += jv * xr;
                 }
                 y[R] = acc - dcv * xr;
+            }
+        }
+        for (int l = 0; l < nl; ++l) {          // coupling rows
+            const NlpLink& L = P.links[l];
+            const double* xs = &xfree[(size_t)L.src * M];
+            double* ys = &y[(size_t)L.src * M];
+            for (int k = 0; k < M; ++k) {
+                const int Rr = nz + md + l * M + k;
+                const double* Wk = &L.W[(size_t)k * M];
+                const double xr = x[Rr];
+                double acc = xfree[(size_t)L.dst * M + k];
+                for (int j = 0; j < M; ++j) acc -= Wk[j] * xs[j];
+                for (int j = 0; j < M; ++j) ys[j] -= Wk[j] * xr;
+                y[(size_t)L.dst * M + k] += xr;
+                y[Rr] = acc - dcv * xr;
             }
         }
         for (int q = 0; q < nz; ++q)
@@ -1054,7 +1113,8 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 continue;
             }
             if (exact_step && dw_shift > 0.0) dw_last_ok = dw_shift;
-            build_rhs(rhs_full.data(), E.RES.data());
+            for (int r = 0; r < me; ++r) eqres[r] = eqr(E, r);
+            build_rhs(rhs_full.data(), eqres.data());
             std::copy(rhs_full.begin(), rhs_full.begin() + NN, rhs_keep.begin());
             const auto ts0 = now();
             const int sst = kkt->solve(rhs_full.data(), 1);
@@ -1118,7 +1178,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
 
         // the step in the eliminated quantities
         for (int q = 0; q < nz; ++q) dz[q] = fidx[q] >= 0 ? rhs_full[q] : 0.0;
-        for (int r = 0; r < md; ++r) dlam[r] = rhs_full[nz + r];
+        for (int r = 0; r < me; ++r) dlam[r] = rhs_full[nz + r];
         expand_step();
         // fraction to the boundary
         double apr = 1.0, adu = 1.0;
@@ -1165,7 +1225,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         // far-from-feasible iterations are orders of magnitude above those near the solution, and a weight
         // frozen at that level rejects every step whose constraint curvature shows at all.
         double mmax = 0;
-        for (int r = 0; r < md; ++r) mmax = std::max(mmax, std::fabs(it.lam[r] + dlam[r]));
+        for (int r = 0; r < me; ++r) mmax = std::max(mmax, std::fabs(it.lam[r] + dlam[r]));
         for (int r = 0; r < mc; ++r) mmax = std::max(mmax, std::fabs(it.y[r] + dy[r]));
         double nu_want = std::max(1.0, std::min(1.1 * mmax, 1e8));
         if (infeas0 > 0) nu_want = std::max(nu_want, dphi / (0.9 * infeas0) + 1.0);
@@ -1194,7 +1254,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             it.e1 = e1t;
             it.e2 = e2t;
             auto clampm = [&](double m, double g) { return std::max(std::min(m, kappa_sigma * mu / g), mu / (kappa_sigma * g)); };
-            for (int r = 0; r < md; ++r) it.lam[r] += a_pr * dlam[r];
+            for (int r = 0; r < me; ++r) it.lam[r] += a_pr * dlam[r];
             for (int r = 0; r < mc; ++r) {
                 it.y[r] += a_pr * dy[r];
                 it.vL[r] += a_du * dvL[r];
@@ -1248,7 +1308,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                                               b_dzL = dzL, b_dzU = dzU, b_dvL = dvL, b_dvU = dvU, b_dw1 = dw1, b_dw2 = dw2,
                                               b_rt = r_t;
                     const double b_apr = apr, b_adu = adu;
-                    for (int r = 0; r < md; ++r) soc_def[r] = alpha * E.RES[r] + Et.RES[r];
+                    for (int r = 0; r < me; ++r) soc_def[r] = alpha * eqr(E, r) + eqr(Et, r);
                     for (int r = 0; r < mc; ++r)
                         soc_row[r] = alpha * row_res(E, it.s, it.e1, it.e2, r) + row_res(Et, st, e1t, e2t, r);
                     double infeas_old = infeas_t;
@@ -1260,7 +1320,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                         for (size_t r = 0; r < NN && fin; ++r) fin = std::isfinite(soc_rhs[r]);
                         if (!fin) break;
                         for (int q = 0; q < nz; ++q) dz[q] = fidx[q] >= 0 ? soc_rhs[q] : 0.0;
-                        for (int r = 0; r < md; ++r) dlam[r] = soc_rhs[nz + r];
+                        for (int r = 0; r < me; ++r) dlam[r] = soc_rhs[nz + r];
                         expand_step();
                         step_lengths();
                         const double asoc = apr;
@@ -1282,7 +1342,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                         }
                         if (!std::isfinite(infeas_s) || infeas_s > 0.99 * infeas_old) break;
                         infeas_old = infeas_s;
-                        for (int r = 0; r < md; ++r) soc_def[r] = asoc * soc_def[r] + Et.RES[r];
+                        for (int r = 0; r < me; ++r) soc_def[r] = asoc * soc_def[r] + eqr(Et, r);
                         for (int r = 0; r < mc; ++r) soc_row[r] = asoc * soc_row[r] + row_res(Et, st, e1t, e2t, r);
                     }
                     if (accepted) break;
@@ -1301,7 +1361,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 const double err_mu = kkt_error(it, mu, nullptr, nullptr);
                 const Iterate it_keep = it;
                 const std::vector<double> gradf_keep = gradf, jtl_keep = jtl;
-                Ekeep.RES = E.RES; Ekeep.VALS = E.VALS; Ekeep.cost = E.cost;
+                Ekeep.RES = E.RES; Ekeep.VALS = E.VALS; Ekeep.LNK = E.LNK; Ekeep.cost = E.cost;
                 for (int q = 0; q < nz; ++q) zt[q] = it.z[q] + apr * dz[q];
                 for (int r = 0; r < mc; ++r) {
                     st[r] = it.s[r] + apr * ds[r];
@@ -1318,7 +1378,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                 it = it_keep;
                 gradf = gradf_keep;
                 jtl = jtl_keep;
-                E.RES = Ekeep.RES; E.VALS = Ekeep.VALS; E.cost = Ekeep.cost;
+                E.RES = Ekeep.RES; E.VALS = Ekeep.VALS; E.LNK = Ekeep.LNK; E.cost = Ekeep.cost;
             }
             alpha *= 0.5;
         }
@@ -1361,7 +1421,8 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
                " (of the host part: J^T lambda %.2f, refinement matvecs %.2f, node blocks %.2f; Hessian calls %.2f)\n",
                R.t_total, R.t_eval, R.t_factor, R.n_factor, R.t_solve, R.n_solve, R.t_lowrank, R.t_jt, R.t_matvec, R.t_blocks, R.t_hess);
     R.z = it.z;
-    R.lamF = it.lam;
+    R.lamF.assign(it.lam.begin(), it.lam.begin() + md);
+    R.lamL.assign(it.lam.begin() + md, it.lam.end());
     R.lamC.resize(mc);
     for (int r = 0; r < mc; ++r) R.lamC[r] = sig[r / M] * it.y[r];
     return R;

@@ -56,6 +56,17 @@ class KktBackend {
     virtual std::string last_error() const { return std::string(); }
 };
 
+// A linear equality that couples a node variable to the whole trajectory of another one:
+//     z[dst][k] - sum_j W[k][j] z[src][j] = 0     for every node k.
+// This is how delayed states / controls (reference src/ePSOPT/ePSOPT.cpp:231-248: get_delayed_state / get_delayed_control
+// values appended to the callbacks' x and u) enter the NLP: the delayed value is a variable of its node -- the node functions,
+// their Jacobian entries and the packed Hessian blocks stay node-local, exactly what the device kernels produce on the extended
+// node variables -- and W (the interpolation operator of the delay on the mesh, emi_delay_matrix) ties it to its source.
+struct NlpLink {
+    int dst = 0, src = 0;               // variable indices (states 0 .. ns-1, controls ns .. ns+nc-1)
+    std::vector<double> W;              // M*M, row-major
+};
+
 struct NlpProblem {
     int ns = 0, nc = 0, np = 0, M = 0;
     int px = 0, py = 1;                 // states the path rows depend on when row_vars is empty (two partials per row)
@@ -69,6 +80,7 @@ struct NlpProblem {
     std::vector<double> vscale;         // ns+nc positive variable scales: the iteration runs on z_v / vscale[v], defect rows of state i
                                         // on defect_i / vscale[i] (PSOPT's scaling = "automatic" with state-based defect scaling); empty = none
     std::vector<double> lamF0, lamC0;   // optional warm start of the defect / path-row multipliers (ns*M, np*M)
+    std::vector<NlpLink> links;         // linear coupling rows (delayed values); the dense host backend only (kkt must be null)
     NlpEvaluator* ev = nullptr;
     KktBackend* kkt = nullptr;          // null: dense LDL^T on the host (with inertia); else e.g. the device LU
 };
@@ -102,6 +114,7 @@ struct NlpResult {
     double cost = 0, kkt_error = 0, constr_viol = 0;
     std::vector<double> z;              // (ns+nc)*M solution
     std::vector<double> lamF, lamC;     // multipliers of the defect and path rows
+    std::vector<double> lamL;           // multipliers of the coupling rows (NlpProblem::links), links.size() * M
     double t_eval = 0, t_factor = 0, t_solve = 0, t_lowrank = 0, t_total = 0;   // seconds: evaluator, KKT factor, KKT solves, host low-rank algebra
     int n_factor = 0, n_solve = 0;      // factorisations (inertia-search trials included) and solve calls
     double t_jt = 0, t_matvec = 0, t_blocks = 0, t_hess = 0;   // host: J^T lambda, refinement matvecs, node-block assembly + eigen-decompositions; Hessian calls

@@ -83,6 +83,10 @@ struct Prob {
     // delay i * delay_dt; the device model sees them as ndelayed extra inputs behind the ncontrols controls
     size_t xhorizon = 0, uhorizon = 0, ndelayed = 0;
     double delay_dt = 0;
+    bool lifted = false;                           // while solve() runs on a delayed problem: the ndelayed values are NLP variables of their
+                                                   // node (controls ncontrols .. ncontrols + ndelayed - 1, unbounded), tied to their sources by
+                                                   // linear coupling rows with the interpolation operators (mi355x::NlpLink); the device then
+                                                   // evaluates the node functions on given delayed values instead of forming them itself
     std::vector<size_t> row_order;                 // evaluation-order row q is row row_order[q] of the callbacks
     std::vector<double> traced_scale;              // normalisation of the traced rows inside the NLP iteration
     size_t npath_traced = 0;                       // of npath: rows traced from constraint callbacks (they follow the table rows)

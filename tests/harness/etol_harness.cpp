@@ -250,6 +250,45 @@ extern "C" int harness_solve_example1_oracle(const char* xml, const char* oracle
     return 0;
 }
 
+// ---- the delayed problem of harness_delay_demo, lifted (delayed values as node variables + coupling rows) and solved on the CPU
+// oracle: model 3 of oracle/emi_oracle.c takes [u | x(t-dt) | x(t-2dt) | u(t-dt)] as its 8 controls, which is the lifted node
+// variable list.  Solver-logic test of mi355x::NlpLink / make_nlp / solve_nlp without a GPU.  Z out: [X (2 x M) | U (2 x M) | delayed (6 x M)].
+extern "C" int harness_solve_delay_demo_oracle(const char* oracle_so, int nsteps, double dt, double disc_r, double tol, int print_level,
+                                               int scaling, double* cost, double* Z, int* iters) {
+    void* h = dlopen(oracle_so, RTLD_NOW);
+    if (!h) { g_out = dlerror(); return 3; }
+    OracleEval oe;
+    oe.ev = (orc_eval_t)dlsym(h, "orc_eval");
+    oe.hs = (orc_hess_t)dlsym(h, "orc_hess");
+    mx::Prob P;
+    P.nstates = 2; P.ncontrols = 2; P.xhorizon = 3; P.uhorizon = 1; P.ndelayed = 6; P.delay_dt = dt; P.lifted = true;
+    P.nodes = nsteps + 1; P.t0 = 0; P.tf = nsteps * dt;
+    P.model = 3;
+    P.model_params = {0.7, 0.3};
+    P.tau.resize(P.nodes); P.w.resize(P.nodes); P.D.resize(P.nodes * P.nodes);
+    emi_lgl((int)P.nodes, P.tau.data(), P.w.data(), P.D.data());
+    if (disc_r > 0) P.path_records = {(double)EMI_PATH_DISC, 2.0, 1.5, disc_r * disc_r, 0, 0, 0, 0};
+    P.npath = P.path_records.size() / 8;
+    P.px = 0; P.py = 1;
+    P.state_lower = {-10, -10}; P.state_upper = {10, 10}; P.control_lower = {-5, -5}; P.control_upper = {5, 5};
+    P.event_lower = {1, 2, 3 - 0.01, 1 - 0.01}; P.event_upper = {1, 2, 3 + 0.01, 1 + 0.01};
+    P.path_lower.assign(P.npath, -1000.0); P.path_upper.assign(P.npath, 0.0);
+    oe.P = &P;
+    mx::NlpProblem nlp = mx::make_nlp(P, &oe);
+    if (nlp.links.size() != 6) { g_out = "make_nlp built " + std::to_string(nlp.links.size()) + " coupling rows, expected 6"; dlclose(h); return 4; }
+    if (scaling) nlp.vscale = mx::bound_scales(P);
+    mx::NlpOptions opt;
+    opt.tol = tol; opt.print_level = print_level; opt.max_iter = 400;
+    mx::NlpResult r = mx::solve_nlp(nlp, opt, mx::initial_guess(P));
+    *iters = r.iterations;
+    g_out = r.msg;
+    if (!r.ok) { dlclose(h); return 1; }
+    *cost = r.cost;
+    std::copy(r.z.begin(), r.z.end(), Z);
+    dlclose(h);
+    return 0;
+}
+
 // ---- traced models: the quadrotor written with mi355x::Var arithmetic, as a user would -----------
 namespace {
 // x = (px, pz, theta, vx, vz, omega), u = (T, tau); same equations as EMI_MODEL_QUADROTOR2D
@@ -271,10 +310,11 @@ mx::Var traced_quad_cost(const std::vector<mx::Var>& u) { return 1.0 * u[0] * u[
 // horizon of 1, set up through the public ETOL API; the callbacks compute with the handles as an ePSOPT user's compute with
 // adoubles, reading the delayed values from the tails of x and u exactly where ePSOPT::dae appends them.  Same functions as
 // model 3 of oracle/emi_oracle.c.  Returns the device's evaluation at z = [X (2 x M) | U (2 x M)].
-extern "C" int harness_delay_demo(int nsteps, double dt, int xh, int uh, int with_disc, const double* z, double* res, int res_cap,
-                                  double* vals, int vals_cap, double* cost, int* nres, int* nvals) {
-    ETOL::eMI355X solver;
-    ETOL::TrajectoryOptimizer* t = &solver;
+namespace {
+struct DelayDemo {           // owns the callbacks: the optimiser keeps raw f_t pointers (TrajectoryOptimizer.hpp:686-690)
+    ETOL::f_t obj, f0, f1, obs;
+};
+void configure_delay_demo(ETOL::TrajectoryOptimizer* t, DelayDemo& d, int nsteps, double dt, int xh, int uh, int with_disc, double disc_r = 0.5) {
     t->setNSteps(nsteps); t->setDt(dt); t->setNStates(2); t->setNControls(2);
     t->setXrhorizon(xh); t->setUrhorizon(uh);
     t->setX0({1, 2}); t->setXf({3, 1}); t->setXtol({0.01, 0.01});
@@ -283,20 +323,29 @@ extern "C" int harness_delay_demo(int nsteps, double dt, int xh, int uh, int wit
     const double p0 = 0.7, p1 = 0.3;
     auto V = [](const std::any& a) { return std::any_cast<mx::Var>(a); };
     // x = [x0 x1 | x(t-dt) | x(t-2dt)], u = [u0 u1 | u(t-dt)]  (ePSOPT.cpp:225-248)
-    ETOL::f_t obj = [=](F_ARGS) -> ETOL::scalar_t {
+    d.obj = [=](F_ARGS) -> ETOL::scalar_t {
         return V(u.at(0)) * V(u.at(0)) + V(u.at(1)) * V(u.at(1)) + p1 * V(x.at(2)) * V(x.at(4)) + 0.05 * V(u.at(2)) * V(u.at(2));
     };
-    ETOL::f_t f0 = [=](F_ARGS) -> ETOL::scalar_t { return -p0 * V(x.at(2)) + V(u.at(0)) + 0.1 * V(u.at(3)) * V(x.at(1)); };
-    ETOL::f_t f1 = [=](F_ARGS) -> ETOL::scalar_t { return V(x.at(0)) * V(x.at(5)) - mx::sin(V(x.at(3))) + V(u.at(1)) * V(u.at(2)); };
-    t->setObjective(&obj);
-    t->setGradient({&f0, &f1});
-    ETOL::f_t obs = [](F_ARGS) -> ETOL::scalar_t {
-        return mx::disc_rows({{2.0, 1.5, 0.5}}, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
+    d.f0 = [=](F_ARGS) -> ETOL::scalar_t { return -p0 * V(x.at(2)) + V(u.at(0)) + 0.1 * V(u.at(3)) * V(x.at(1)); };
+    d.f1 = [=](F_ARGS) -> ETOL::scalar_t { return V(x.at(0)) * V(x.at(5)) - mx::sin(V(x.at(3))) + V(u.at(1)) * V(u.at(2)); };
+    t->setObjective(&d.obj);
+    t->setGradient({&d.f0, &d.f1});
+    d.obs = [disc_r](F_ARGS) -> ETOL::scalar_t {
+        return mx::disc_rows({{2.0, 1.5, disc_r}}, std::any_cast<mx::Symbol>(x.at(0)), std::any_cast<mx::Symbol>(x.at(1)));
     };
     if (with_disc) {
         t->addParams({std::pair<PARAM_PAIR>("disc_0", {ETOL::var_t::CONTINUOUS, -1000., 0., 0., nsteps * dt})});
-        t->setConstraints({&obs});
+        t->setConstraints({&d.obs});
     }
+}
+}  // namespace
+
+extern "C" int harness_delay_demo(int nsteps, double dt, int xh, int uh, int with_disc, const double* z, double* res, int res_cap,
+                                  double* vals, int vals_cap, double* cost, int* nres, int* nvals) {
+    ETOL::eMI355X solver;
+    ETOL::TrajectoryOptimizer* t = &solver;
+    DelayDemo d;
+    configure_delay_demo(t, d, nsteps, dt, xh, uh, with_disc);
     t->setup();
     const size_t M = nsteps + 1;
     std::vector<double> zz(z, z + 4 * M), r, v;
@@ -307,6 +356,43 @@ extern "C" int harness_delay_demo(int nsteps, double dt, int xh, int uh, int wit
     std::copy(r.begin(), r.end(), res);
     std::copy(v.begin(), v.end(), vals);
     g_out = solver.getProblem()->model_source;
+    t->close();
+    return 0;
+}
+
+// The same problem SOLVED through the ETOL API (setup(), solve(), getXtraj()/getUtraj(), getScore()): X [2][M], U [2][M] at the LGL
+// nodes.  After the solve one more evaluate() at the solution (the device forms the delayed values itself again): its defect rows go
+// to defect_max -- the trajectory must satisfy the DELAYED dynamics, not the lifted problem's.
+extern "C" int harness_solve_delay_demo(int nsteps, double dt, int xh, int uh, double disc_r, double tol, int print_level, double* cost,
+                                        double* X, double* U, int* iters, double* defect_max) {
+    ETOL::eMI355X solver;
+    ETOL::TrajectoryOptimizer* t = &solver;
+    DelayDemo d;
+    configure_delay_demo(t, d, nsteps, dt, xh, uh, disc_r > 0, disc_r);
+    t->setup();
+    solver.getAlgorithm()->nlp_tolerance = tol;
+    solver.getAlgorithm()->nlp_iter_max = 400;
+    solver.getAlgorithm()->print_level = print_level;
+    t->solve();
+    g_out = solver.getSolution()->error_msg;
+    if (solver.getSolution()->error_flag) { t->close(); return 1; }
+    const size_t M = nsteps + 1;
+    if (t->getXtraj()->size() != M || t->getUtraj()->size() != M) { t->close(); return 2; }
+    std::vector<double> zz(4 * M);
+    for (size_t k = 0; k < M; ++k)
+        for (int i = 0; i < 2; ++i) {
+            X[i * M + k] = zz[i * M + k] = t->getXtraj()->at(k).second.at(i);
+            U[i * M + k] = zz[(2 + i) * M + k] = t->getUtraj()->at(k).second.at(i);
+        }
+    *cost = t->getScore();
+    *iters = solver.getSolution()->nlp_iterations;
+    std::vector<double> r, v;
+    double c2 = 0;
+    solver.evaluate(zz, &r, &v, &c2);
+    double dm = 0;
+    for (size_t q = 0; q < 2 * M; ++q) dm = std::max(dm, std::fabs(r[q]));
+    *defect_max = dm;
+    if (std::fabs(c2 - *cost) > 1e-9 * std::max(1.0, std::fabs(c2))) { g_out = "cost of the solve and of evaluate() at the solution differ"; t->close(); return 3; }
     t->close();
     return 0;
 }

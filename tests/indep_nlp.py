@@ -87,7 +87,7 @@ class Nlp:
         """dense Hessian of cost + lamF.defect + lamC.path (node-block diagonal)"""
         ns, nv, M = self.ns, self.nv, self.M
         X, U = self.split(z)
-        H = O.hessian(self.model, self.params, M, self.mesh, self.t0, self.tf, X, U, lamF.reshape(1, ns, M),
+        H = O.hessian(self.model, self.params, M, self.mesh, self.t0, self.tf, X, U, lamF[: ns * M].reshape(1, ns, M),
                       lamC.reshape(1, self.np_, M) if self.np_ else None, 1.0, self.recs if self.np_ else None, self.tracks,
                       px=self.px, py=self.py)[0]
         W = np.zeros((nv * M, nv * M))
@@ -98,6 +98,54 @@ class Nlp:
                 W[b * M + np.arange(M), a * M + np.arange(M)] = H[e]
                 e += 1
         return W
+
+
+class DelayedNlp(Nlp):
+    """The delayed problem of tests/harness/etol_harness.cpp (harness_delay_demo; oracle model 3) in LIFTED form: the delayed
+    values x(t - dt), x(t - 2 dt), u(t - dt) are the controls 2 .. 7 of their node and coupling rows  d - W(i dt) . source = 0
+    tie them to the trajectory (W from the oracle's own orc_delay_matrix: plain Lagrange product formula, times before t0
+    clamped to t0).  Reference: ePSOPT::dae appends get_delayed_state / get_delayed_control values at these places
+    (src/ePSOPT/ePSOPT.cpp:231-248).  `defect` / `jac_defect` return the defect rows followed by the coupling rows."""
+
+    def __init__(self, nsteps, dt, disc_r=0.5, xh=3, uh=1):
+        M = nsteps + 1
+        recs = np.array([[1.0, 2.0, 1.5, disc_r * disc_r, 0, 0, 0, 0]]) if disc_r > 0 else None
+        big = 1e20
+        super().__init__(3, [0.7, 0.3], M, 0.0, nsteps * dt, recs, None, x0=[1, 2], xf=[3, 1], xtol=[0.01, 0.01], xlo=[-10, -10],
+                         xup=[10, 10], ulo=[-5, -5] + [-big] * 6, uup=[5, 5] + [big] * 6)
+        ns, ncf = 2, 2
+        self.links = []
+        slot = ns + ncf
+        for i in range(1, xh):
+            for s_ in range(ns):
+                self.links.append((slot, s_, O.delay_matrix(M, self.tau, self.t0, self.tf, i * dt)))
+                slot += 1
+        for i in range(1, uh + 1):
+            for c in range(ncf):
+                self.links.append((slot, ns + c, O.delay_matrix(M, self.tau, self.t0, self.tf, i * dt)))
+                slot += 1
+        assert slot == self.nv
+        self.n_eq = (ns + len(self.links)) * M
+        self.JL = np.zeros((len(self.links) * M, self.n))
+        for l, (dst, src, W) in enumerate(self.links):
+            self.JL[l * M:(l + 1) * M, dst * M:(dst + 1) * M] = np.eye(M)
+            self.JL[l * M:(l + 1) * M, src * M:(src + 1) * M] -= W
+
+    def lift(self, X, U):
+        """z = [X | U | W . sources] from the free trajectory X (2 x M), U (2 x M)"""
+        M = self.M
+        z = np.zeros(self.n)
+        z[: 2 * M] = np.asarray(X).ravel()
+        z[2 * M:4 * M] = np.asarray(U).ravel()
+        for dst, src, W in self.links:
+            z[dst * M:(dst + 1) * M] = W @ z[src * M:(src + 1) * M]
+        return z
+
+    def defect(self, z):
+        return np.concatenate([super().defect(z), self.JL @ z])
+
+    def jac_defect(self, z):
+        return np.vstack([super().jac_defect(z), self.JL])
 
 
 def slsqp(P, z0):
@@ -127,7 +175,8 @@ def polish(P, z, iters=30):
     free = ~(fixed | act_lo | act_up)
     c = P.path(z) if P.np_ else np.zeros(0)
     act_c = c > -1e-7
-    lamF = np.zeros(ns * M)
+    me = getattr(P, "n_eq", ns * M)          # equality rows: defects (+ coupling rows of a DelayedNlp)
+    lamF = np.zeros(me)
     lamA = np.zeros(int(act_c.sum()))
     for it in range(iters):
         g, Jd = P.grad(z), P.jac_defect(z)
@@ -135,7 +184,7 @@ def polish(P, z, iters=30):
         if it == 0:   # least-squares multipliers to start from
             A = np.vstack([Jd, Jp])[:, free]
             lam = np.linalg.lstsq(A.T, -g[free], rcond=None)[0]
-            lamF, lamA = lam[: ns * M], lam[ns * M:]
+            lamF, lamA = lam[:me], lam[me:]
         lamC = np.zeros(P.np_ * M)
         lamC[act_c] = lamA
         W = P.hess(z, lamF, lamC)
@@ -149,8 +198,8 @@ def polish(P, z, iters=30):
         K = np.block([[W[np.ix_(free, free)], A.T], [A, np.zeros((m, m))]])
         d = np.linalg.solve(K, -np.concatenate([r1, r2]))
         z[free] += d[:nf]
-        lamF += d[nf:nf + ns * M]
-        lamA += d[nf + ns * M:]
+        lamF += d[nf:nf + me]
+        lamA += d[nf + me:]
     # full KKT check at the polished point
     g, Jd = P.grad(z), P.jac_defect(z)
     c = P.path(z) if P.np_ else np.zeros(0)

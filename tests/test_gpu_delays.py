@@ -210,3 +210,36 @@ def test_mesh_change_after_set_delays_rebuilds_the_interpolation_matrices(built)
         ref = O.evaluate(3, P3, M, (ev.tau, ev.w, ev.D), t0, tf, X, _extended(X, U, ev.tau, t0, tf, dt), DISC)
         _check(*ev.eval_host(X, U), ref, X, ev.D)
     ev.close()
+
+
+@pytest.mark.parametrize("nsteps,disc_r", [(24, 0.9), (32, 0.5), (40, 0.0)])
+def test_delayed_problem_is_solved_through_the_etol_api(built, nsteps, disc_r):
+    """solve() on a problem with setXrhorizon(3) / setUrhorizon(1) (reference src/ePSOPT/ePSOPT.cpp:231-248, where ePSOPT hands
+    delayed values to the callbacks and the whole NLP to IPOPT): ETOL::eMI355X iterates on the delayed values as node variables
+    tied to their sources by coupling rows with the mesh's interpolation operators; functions, Jacobian entries and Hessian
+    blocks come from the DEVICE kernels on the extended node variables.  The trajectory returned must (a) satisfy the delayed
+    dynamics as the device itself evaluates them (delays formed on the device again), and (b) be, after lifting, a KKT point of
+    the independent restatement tests/indep_nlp.py::DelayedNlp (oracle functions + the oracle's own delay matrices): the
+    Newton polish from it converges to a verified KKT point within 1e-6 relative (north_star's tolerance)."""
+    import indep_nlp as N
+    h = _harness()
+    D = C.POINTER(C.c_double)
+    h.harness_solve_delay_demo.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, D, D, D,
+                                           C.POINTER(C.c_int), D]
+    M, dt = nsteps + 1, 0.25
+    X, U = np.zeros((2, M)), np.zeros((2, M))
+    cost, iters, dmax = C.c_double(), C.c_int(), C.c_double()
+    rc = h.harness_solve_delay_demo(nsteps, dt, 3, 1, disc_r, 1e-10, 0, C.byref(cost), X.ctypes.data_as(D), U.ctypes.data_as(D),
+                                    C.byref(iters), C.byref(dmax))
+    assert rc == 0, h.harness_last_message().decode()
+    assert dmax.value < 1e-8                              # (a): evaluate() at the solution, delays formed by the device
+    P = N.DelayedNlp(nsteps, dt, disc_r=disc_r)
+    Z = P.lift(X, U)
+    assert np.abs(P.defect(Z)).max() < 1e-8 and abs(P.cost(Z) - cost.value) < 1e-9 * max(1.0, abs(cost.value))
+    zp, lamF, lamC, k = N.polish(P, Z)
+    assert N.kkt_ok(k), k
+    rel = np.abs(zp - Z).max() / np.abs(zp).max()
+    print(f"delayed solve on the device evaluator: {M} nodes, {iters.value} iterations, cost {cost.value:.10f}, rel dist to the KKT point {rel:.2e}")
+    assert rel < 1e-6
+    if disc_r >= 0.9:
+        assert k["active_path_rows"] > 0

@@ -280,3 +280,40 @@ def test_host_sources_compile_against_the_reference_headers():
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I/root/reference/include", "-Iinclude", "-Ietol_amd/host", src],
                            cwd=root, capture_output=True, text=True)
         assert r.returncode == 0, src + "\n" + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("disc_r,scaling", [(0.9, 0), (0.9, 1), (0.5, 1), (0.0, 0)])
+def test_delayed_problem_is_solved_through_coupling_rows(H, disc_r, scaling):
+    """Delayed states / controls (reference src/ePSOPT/ePSOPT.cpp:231-248) in solve(): the delayed values are node variables
+    tied to their sources by coupling rows with the interpolation operators (mi355x::NlpLink, make_nlp of a lifted Prob).
+    Here on the CPU: the 2-state demo problem (state horizon 3, control horizon 1) with the oracle's model 3 as evaluator and
+    the dense host LDL^T; the result must be a KKT point of the same NLP restated in tests/indep_nlp.py (DelayedNlp: the
+    oracle's functions and the oracle's own delay matrices), which an independent Newton polish confirms within 1e-6."""
+    import indep_nlp as N
+    nsteps, dt = 24, 0.25
+    M = nsteps + 1
+    D = C.POINTER(C.c_double)
+    H.harness_solve_delay_demo_oracle.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, D, D,
+                                                  C.POINTER(C.c_int)]
+    H.harness_last_message.restype = C.c_char_p
+    Z = np.zeros(10 * M)
+    cost, iters = C.c_double(), C.c_int()
+    rc = H.harness_solve_delay_demo_oracle(os.path.join(ROOT, "oracle", "liboracle.so").encode(), nsteps, dt, disc_r, 1e-10, 0, scaling, C.byref(cost),
+                                           Z.ctypes.data_as(D), C.byref(iters))
+    assert rc == 0, H.harness_last_message().decode()
+    P = N.DelayedNlp(nsteps, dt, disc_r=disc_r)
+    # the iteration's answer satisfies the delayed dynamics and the coupling rows
+    assert np.abs(P.defect(Z)).max() < 1e-8
+    assert abs(P.cost(Z) - cost.value) < 1e-9 * max(1.0, abs(cost.value))
+    zp, lamF, lamC, k = N.polish(P, Z)
+    assert N.kkt_ok(k), k
+    rel = np.abs(zp - Z).max() / np.abs(zp).max()
+    print(f"delayed solve: {iters.value} iterations, cost {cost.value:.10f}, polished {P.cost(zp):.10f}, rel dist {rel:.2e}, KKT {k}")
+    assert rel < 1e-6
+    if disc_r >= 0.9:
+        assert k["active_path_rows"] > 0          # the keep-out binds at this size
+    # the delays matter: the same trajectory is not feasible for the problem without them (history = present)
+    Zn = Z.copy()
+    for dst, src, W in P.links:
+        Zn[dst * M:(dst + 1) * M] = Z[src * M:(src + 1) * M]
+    assert np.abs(N.Nlp.defect(P, Zn)).max() > 1e-3
