@@ -35,6 +35,12 @@ class Layout(C.Structure):
                 ("t0", C.c_double), ("tf", C.c_double)]
 
 
+class PassPlan(C.Structure):
+    """emi_pass_plan_t: what the default dispatch does with a batch (include/emi355x.h, emi_plan_pass)"""
+    _fields_ = [(n, C.c_int) for n in ("one_launch", "sw", "ksplit", "ring_stages", "cpart", "cx", "mfma_workgroups", "store_mode",
+                                       "block_order", "tiles16", "piece", "tail")]
+
+
 _P = C.c_void_p
 _D = C.POINTER(C.c_double)
 _I = C.POINTER(C.c_int)
@@ -82,6 +88,7 @@ SYMBOLS = {
     "emi_profile_read": (C.c_int, [_P, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _I]),
     "emi_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "emi_last_path": (C.c_int, [_P, _I]),
+    "emi_plan_pass": (C.c_int, [_P, C.c_int, C.POINTER(PassPlan)]),
     "emi_last_defect_kernel": (C.c_char_p, [_P]),
     "emi_debug_pass_roles": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "emi_debug_tile_order": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -205,6 +205,102 @@ int ready(emi_ctx_t c) {
     return EMI_OK;
 }
 
+// Result-store flavour of the node role for a launch of B instances ("node_store" forces it).  Non-temporal once a pass writes
+// about what the Infinity Cache holds (256 MB; RES + VALS above 230 MiB): measured on the one-launch pass, M = 1024
+// (profiles/r03_mid_sweep.json): 256 instances (244 MiB) 0.0581 ms against 0.0720 with plain stores, 320: 0.0749 / 0.0973,
+// 384: 0.0879 / 0.1050; 224 instances (214 MiB): plain 0.0557 / nt 0.0606, 128: 0.0338 / 0.0354.  (Round 2 switched at 300 MB of
+// VALS, i.e. above 384 instances: the 256 .. 384 band ran 20 % slow.)
+int store_mode_for(emi_ctx_t c, int B) {
+    if (c->node_store >= 0) return c->node_store;
+    return (size_t)B * (nvals_of(c) + nres_of(c)) * c->M * (c->f32 ? 4 : 8) > ((size_t)230 << 20) ? 2 : 0;
+}
+
+// Everything the default dispatch decides about ONE launch of the evaluation pass as emi_pass_f64_kernel, in one place:
+// plan_pass() is what eval_dev_slice launches by and what emi_plan_pass reports (tests and tools read the policy from the
+// library instead of restating it).
+struct PassPlan {
+    bool one_launch = false;    // the pass goes out as ONE launch (MFMA-role + node-role workgroups)
+    emi::SymPlan sym;           // MFMA role: states per workgroup, K slices per tile, ring stages, tile order
+    int tiles16 = 0;            // 16-instance x 128-node tiles of the launch (what the thresholds below are written in)
+    int store_mode = 0;         // node role: 0 plain, 1 sc1, 2 non-temporal, 3 nt sc1
+    int mfma_first = 0;         // block order (pass_role_of): 1 MFMA workgroups first, 0 evenly interleaved, >= 100: at that % of the even density
+};
+
+// The pass as ONE launch: MFMA-role and node-role workgroups in one grid, COST finished in-kernel -- since round 3 at EVERY
+// batch size (round 2: two streams between 384 and 767 instances, which ran 20 - 25 % under the rest).  One box, interleaved
+// rounds, M = 1024, ms per pass, best one-launch form against the round-2 choice (profiles/r03_mid_sweep.json): 256: 0.0581 /
+// 0.0731, 320: 0.0749 / 0.0927, 384: 0.0879 / 0.1177 (two streams), 448: 0.1035 / 0.1038, 512: 0.1188 / 0.1162, 576: 0.1332 /
+// 0.1777, 640: 0.146 / 0.155, 704: 0.160 / 0.181.
+//   * SW (states per MFMA workgroup): 1 below 128 sixteen-instance x 128-node tiles (more workgroups than CUs), else 2;
+//   * K slices per tile ("sym_ksplit"; partial sums combined in-kernel by ticket, in slice order).  By itself only where the MFMA
+//     role has fewer workgroups than the chip has places for them, i.e. where a pass waits for one 64-tile dependency chain per
+//     workgroup: 4 slices while that keeps the role within 256 workgroups, 2 within 512.  One box, M = 1024, ms per pass
+//     unsplit / 2 / 4 slices (tools/mid_sweep.py, profiles/r03_notes.md section 7): B = 8: 0.0204 / 0.0148 / 0.0140,
+//     16: 0.0235 / 0.0179 / 0.0155, 32: 0.0242 / 0.0190 / 0.0192, 64: 0.0257 / 0.0218 / 0.0261, 80: 0.0263 / 0.0249 / 0.0312,
+//     96: 0.0288 / 0.0290 / 0.0407, 128: 0.0333 / 0.0387 / 0.0496 (from ~500 workgroups the split loses: three and more MFMA
+//     waves per SIMD share the matrix pipe and the node role starts behind them);
+//   * block order (pass_role_of): MFMA workgroups first below 208 tiles (their 64-tile dependency chains start at once, the
+//     streaming workgroups fill in behind), at 1.25 x the even density up to 384 tiles, at 1.1 x up to 768, evenly interleaved
+//     from there (B >= 768, where "first" would hold the node role back: 0.288 against 0.222 at 1024).  (Round 2 measured
+//     "first" against "interleaved" WITH PLAIN STORES at 256 instances and found interleaved ahead, 0.0727 / 0.0748; with
+//     non-temporal stores "first" wins up to 448 instances: 256: 0.0581 against 0.0756 interleaved.  End of round 3, one box,
+//     e9 node-evals/s at first / 1.25 x / 1.5 x / even: 448 instances 4.21 / 4.41 / 4.22 / 4.31, 512: 3.60 / 4.32 / 4.38 / 4.22,
+//     640: 3.76 / 4.48 / 4.37 / 4.37, 704: 3.89 / 4.63 / 4.45 / 4.50; ms per pass at even / 1.1 x / 1.25 x: 768: 0.1747 /
+//     0.1696 / 0.1760, 896: 0.1964 / 0.1959 / 0.2022, 1024: 0.2230 / 0.2200 / 0.2304, 1536: 0.3215 / 0.3219 / 0.3411,
+//     2048: 0.4239 / 0.4227 / 0.4415);
+//   * tile order: grouped (an XCD's MFMA tiles and node workgroups walk the same instance groups together) for launches of more
+//     than 2048 instances in whole super-blocks, else column partitions by mesh size (plan_symdefect);
+//   * stores: store_mode_for (non-temporal from about 256 instances).
+// Every choice can be forced through emi_set_option (sym_ct, sym_ksplit, sym_cpart, sym_gblk, sym_cx, sym_nst, pass_order,
+// node_store); a run-time compiled model holds two instantiations of the pass kernel -- SW = 1 with plain stores (small batches)
+// and SW = 2 (1 for an odd number of states) with non-temporal stores (large ones) -- and is planned within those.
+PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
+    PassPlan p;
+    p.tiles16 = ((B + 15) / 16) * (c->M / 128);
+    p.store_mode = store_mode_for(c, B);
+    const bool auto_mode = c->overlap_mode == 0;
+    if (!((c->overlap_mode == 3 || auto_mode) && jac) || c->M % 128 != 0) return p;
+    const bool auto_ct = auto_mode && (c->sym_ct == 0 || c->sym_ct == 4);
+    const int gblk = (c->sym_gblk == 0 && c->sym_cpart == 0 && B > 2048 && B % 256 == 0) ? 2 : c->sym_gblk;
+    const int gblk_first = (auto_ct || c->rtc) ? gblk : c->sym_gblk;
+    int ct = c->sym_ct;                                  // 5 / 6 / 7 / 8 = SW NS / 2 / 1 / 3 (plan_symdefect)
+    if (c->rtc) ct = (p.store_mode == 2 && emi::rtc_pass_sw_large(c->rtc) == 2) ? 6 : 7;
+    else if (auto_ct) ct = p.tiles16 < 128 ? 7 : 6;
+    emi::SymPlan plan = emi::plan_symdefect(c->ns, B, c->M, ct, 1, c->sym_cpart, gblk_first, c->sym_cx);
+    if (plan.ring1) plan = emi::plan_symdefect(c->ns, B, c->M, 5, 1, c->sym_cpart, c->sym_gblk, c->sym_cx);
+    int ks_want = c->sym_ksplit;
+    if (ks_want == 0 && auto_ct) ks_want = plan.tiles * 4 <= 256 ? 4 : (plan.tiles * 2 <= 512 ? 2 : 1);
+    if (ks_want > 1) {
+        const int ct_now = plan.sw == c->ns ? 5 : (plan.sw == 2 ? 6 : (plan.sw == 3 ? 8 : 7));
+        plan = emi::plan_symdefect(c->ns, B, c->M, ct_now, ks_want, c->sym_cpart, c->rtc ? gblk : c->sym_gblk, c->sym_cx);
+    } else {
+        plan.ks = 1;
+    }
+    plan.nst = c->rtc ? 3 : c->sym_nst;
+    p.sym = plan;
+    p.mfma_first = c->pass_order >= 0 ? c->pass_order
+                                      : (p.tiles16 < 208 ? 1 : (p.tiles16 < 384 ? 125 : (p.tiles16 < 768 ? 110 : 0)));
+    p.one_launch = c->rtc ? emi::rtc_pass_supported(c->rtc, B, c->M, plan.sw, plan.ks, p.store_mode)
+                          : emi::pass_supported(c->model, c->ns, B, c->M, plan);
+    return p;
+}
+
+// Large batches: the instances one launch of emi_eval_dev's default dispatch takes (0: the whole batch in one).  Round 2 cut
+// everything above 2048 instances into 1024-instance launches (the two-stream form drifted apart on long launches); with the pass
+// as ONE launch that buys nothing, and inputs of more than ~256 MB no longer stay in the Infinity Cache from one pass to the next,
+// which is what really slows a large batch (B = 16384: 3.47e9 node-evals/s sliced or not, profiles/r03_notes.md).  Now: one launch
+// over the whole batch in the GROUPED tile order: 4.10e9 /s at 16384 instances, 4.13e9 at 4096.  Pieces remain only where
+// something forces them: the "slice" option (> 0: pieces of that many instances once B > 2 slice), the 32-bit operand offsets of
+// the MFMA role (X of a launch below 4 GB), and a remainder that is not a multiple of 256 instances (the grouped order wants whole
+// super-blocks on every XCD) as a second launch.
+int plan_piece(emi_ctx_t c) {
+    const long long cap = ((0xFFFFFFFFLL / ((long long)c->ns * c->M * 8)) / 256) * 256;     // instances whose X stays below 4 GB
+    int piece = 0;
+    if (c->slice > 0) { if (c->B > 2 * c->slice) piece = c->slice; }
+    else if (c->B > 2048) piece = (int)std::min<long long>(cap > 0 ? cap : 256, c->B - c->B % 256);
+    return piece >= c->B ? 0 : piece;
+}
+
 template <typename T>
 void fill_node_args(emi_ctx_t c, emi::NodeArgs<T>& a, const void* dX, const void* dU, void* dRES,
                     void* dVALS, void* dCOST) {
@@ -231,12 +327,7 @@ void fill_node_args(emi_ctx_t c, emi::NodeArgs<T>& a, const void* dX, const void
     a.ntracks = c->ntracks;
     a.px = c->px;
     a.py = c->py;
-    // Non-temporal result stores once a pass writes about what the Infinity Cache holds (256 MB; RES + VALS above 230 MiB):
-    // measured on the one-launch pass, M = 1024 (profiles/r03_mid_sweep.json): 256 instances (244 MiB) 0.0581 ms against
-    // 0.0720 with plain stores, 320: 0.0749 / 0.0973, 384: 0.0879 / 0.1050; 224 instances (214 MiB): plain 0.0557 / nt 0.0606,
-    // 128: 0.0338 / 0.0354.  (Round 2 switched at 300 MB of VALS, i.e. above 384 instances: the 256 .. 384 band ran 20 % slow.)
-    a.store_mode = c->node_store >= 0 ? c->node_store
-                                      : ((size_t)c->B * (nvals_of(c) + nres_of(c)) * c->M * (c->f32 ? 4 : 8) > ((size_t)230 << 20) ? 2 : 0);
+    a.store_mode = store_mode_for(c, c->B);
     a.h = (T)((c->tf - c->t0) / 2.0);
     a.sgn = c->maximize ? T(-1) : T(1);
     for (int i = 0; i < EMI_MAX_PARAMS; ++i) a.P.p[i] = (T)c->params[i];
@@ -752,22 +843,11 @@ int emi_eval_dev(emi_ctx_t c, const void* dX, const void* dU, void* dRES, void* 
     int st = ready(c);
     if (st) return st;
     if (c->nch > 0 && dX && dU && (st = extend_controls(c, dX, dU, &dU))) return st;     // delayed values appended to the controls
-    // Large batches.  Round 2 cut everything above 2048 instances into 1024-instance launches (the two-stream form drifted apart
-    // on long launches); with the pass as ONE launch that buys nothing, and inputs of more than ~256 MB no longer stay in the
-    // Infinity Cache from one pass to the next, which is what really slows a large batch (B = 16384: 3.47e9 node-evals/s sliced or
-    // not, profiles/r03_notes.md).  Now: one launch over the whole batch, in the GROUPED tile order (plan_symdefect: an XCD's
-    // MFMA tiles and node workgroups walk the same instances together): 4.10e9 /s at 16384 instances, 4.13e9 at 4096.  Pieces
-    // remain only where something forces them: the "slice" option (> 0: pieces of that many instances once B > 2 slice), the
-    // 32-bit operand offsets of the MFMA role (X of a launch below 4 GB), and a remainder that is not a multiple of 256
-    // instances (the grouped order wants whole super-blocks on every XCD) as a second launch.  Not while per-kernel profiling is on.
+    // large batches go out in pieces only where something forces them (plan_piece); not while per-kernel profiling is on
     int piece = 0;
     if (!c->profile && !c->f32 && (flags & EMI_EVAL_ALL) == EMI_EVAL_ALL && overlapped_path(c) && dX && dU && dRES && dCOST &&
-        (dVALS || (flags & EMI_EVAL_NOJAC))) {
-        const long long cap = ((0xFFFFFFFFLL / ((long long)c->ns * c->M * 8)) / 256) * 256;     // instances whose X stays below 4 GB
-        if (c->slice > 0) { if (c->B > 2 * c->slice) piece = c->slice; }
-        else if (c->B > 2048) piece = (int)std::min<long long>(cap > 0 ? cap : 256, c->B - c->B % 256);
-        if (piece >= c->B) piece = 0;
-    }
+        (dVALS || (flags & EMI_EVAL_NOJAC)))
+        piece = plan_piece(c);
     if (piece > 0) {
         const int SL = piece;
         const int Btot = c->B;
@@ -826,89 +906,58 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         // The MFMA kernel goes first and takes one workgroup per CU (LDS-shaped); the streaming
         // kernel's waves fill the rest of every CU.
         emi::SymDefectArgs sa;
-        sa.X = (const double*)dX; sa.U = (const double*)dU; sa.RES = (double*)dRES;
-        sa.node_t = (const double*)c->d_t.p; sa.De = (const double*)c->d_De.p; sa.Do = (const double*)c->d_Do.p;
-        sa.M = c->M; sa.B = c->B; sa.nres = nres_of(c); sa.h = (c->tf - c->t0) / 2.0; sa.order = c->sym_order; sa.ablate = c->sym_ablate; sa.ksplit = 1; sa.slab = nullptr; sa.tile_ticket = nullptr; sa.cpart = sa.cx = 0; sa.mfma_first = 0;
+        sa.X = (const double*)dX;
+        sa.U = (const double*)dU;
+        sa.RES = (double*)dRES;
+        sa.node_t = (const double*)c->d_t.p;
+        sa.De = (const double*)c->d_De.p;
+        sa.Do = (const double*)c->d_Do.p;
+        sa.M = c->M;
+        sa.B = c->B;
+        sa.nres = nres_of(c);
+        sa.h = (c->tf - c->t0) / 2.0;
+        sa.order = c->sym_order;
+        sa.ablate = c->sym_ablate;
+        sa.ksplit = 1;
+        sa.slab = nullptr;
+        sa.tile_ticket = nullptr;
+        sa.cpart = sa.cx = 0;
+        sa.mfma_first = 0;
         for (int i = 0; i < EMI_MAX_PARAMS; ++i) sa.P.p[i] = c->params[i];
         emi::NodeArgs<double> na;
         fill_node_args(c, na, dX, dU, dRES, dVALS, dCOST);
-        const int tiles16 = ((c->B + 15) / 16) * (c->M / 128);
-        const bool auto_mode = c->overlap_mode == 0;
-        if ((c->overlap_mode == 3 || auto_mode) && jac) {
-            // The pass as ONE launch: MFMA-role and node-role workgroups in one grid, COST finished in-kernel -- since round 3
-            // at EVERY batch size (round 2: two streams between 384 and 767 instances, which ran 20 - 25 % under the rest).
-            // One box, interleaved rounds, M = 1024, ms per pass, best one-launch form against the round-2 choice
-            // (profiles/r03_mid_sweep.json): 256: 0.0581 / 0.0731, 320: 0.0749 / 0.0927, 384: 0.0879 / 0.1177 (two streams),
-            // 448: 0.1035 / 0.1038, 512: 0.1188 / 0.1162, 576: 0.1332 / 0.1777, 640: 0.146 / 0.155, 704: 0.160 / 0.181.
-            //   * SW (states per MFMA workgroup): 1 below 128 sixteen-instance x 128-node tiles (more workgroups than CUs), else 2;
-            //   * block order (pass_role_of): MFMA workgroups first below 208 tiles (their 64-tile dependency chains start at
-            //     once, the streaming workgroups fill in behind), at 1.25 x the even density up to 384 tiles, at 1.1 x up to 768, evenly
-            //     interleaved from there (B >= 768, where "first" would hold the node role back: 0.288 against 0.222 at 1024);
-            //   * stores: fill_node_args (non-temporal from about 256 instances).
-            emi::SymPlan plan = emi::plan_symdefect(c->ns, c->B, c->M, c->sym_ct, 1, c->sym_cpart, c->sym_gblk, c->sym_cx);
-            const int gblk_auto = (c->sym_gblk == 0 && c->sym_cpart == 0 && c->B > 2048 && c->B % 256 == 0) ? 2 : c->sym_gblk;   // grouped order for large batches (emi_eval_dev)
-            if (auto_mode && (c->sym_ct == 0 || c->sym_ct == 4))
-                plan = emi::plan_symdefect(c->ns, c->B, c->M, tiles16 < 128 ? 7 : 6, 1, c->sym_cpart, gblk_auto, c->sym_cx);        // SW = 1 / 2
-            else if (plan.ring1) plan = emi::plan_symdefect(c->ns, c->B, c->M, 5, 1, c->sym_cpart, c->sym_gblk, c->sym_cx);
-            plan.nst = c->sym_nst;
-            // K slices per tile ("sym_ksplit"; partial sums combined in-kernel by ticket, bitwise the unsplit sum order per slice).
-            // By itself (0, and only in the default dispatch: no variant forced) only where the MFMA role has fewer workgroups than the chip has places for them, i.e. where a pass waits
-            // for one 64-tile dependency chain per workgroup: 4 slices while that keeps the role within 256 workgroups, 2 within 512.
-            // One box, M = 1024, ms per pass unsplit / 2 / 4 slices (tools/mid_sweep.py, profiles/r03_notes.md section 7):
-            // B = 8: 0.0204 / 0.0148 / 0.0140, 16: 0.0235 / 0.0179 / 0.0155, 32: 0.0242 / 0.0190 / 0.0192, 64: 0.0257 / 0.0218 / 0.0261,
-            // 80: 0.0263 / 0.0249 / 0.0312, 96: 0.0288 / 0.0290 / 0.0407, 128: 0.0333 / 0.0387 / 0.0496 (from ~500 workgroups the
-            // split loses: three and more MFMA waves per SIMD share the matrix pipe and the node role starts behind them).
-            if (c->rtc) {
-                // a run-time compiled model holds two instantiations of the pass kernel: SW = 1 with plain stores (small
-                // batches) and SW = 2 (1 for an odd number of states) with non-temporal stores (large ones)
-                const int swl = emi::rtc_pass_sw_large(c->rtc);
-                plan = emi::plan_symdefect(c->ns, c->B, c->M, (na.store_mode == 2 && swl == 2) ? 6 : 7, 1, c->sym_cpart, gblk_auto, c->sym_cx);
-            }
-            int ks_want = c->sym_ksplit;
-            if (ks_want == 0 && auto_mode && (c->sym_ct == 0 || c->sym_ct == 4)) ks_want = plan.tiles * 4 <= 256 ? 4 : (plan.tiles * 2 <= 512 ? 2 : 1);
-            if (ks_want > 1) {
-                const int ct_now = plan.sw == c->ns ? 5 : (plan.sw == 2 ? 6 : (plan.sw == 3 ? 8 : 7));
-                plan = emi::plan_symdefect(c->ns, c->B, c->M, ct_now, ks_want, c->sym_cpart, c->rtc ? gblk_auto : c->sym_gblk, c->sym_cx);
-            } else {
-                plan.ks = 1;
-            }
-            plan.nst = c->rtc ? 3 : c->sym_nst;
-            // (round 2 measured "first" against "interleaved" WITH PLAIN STORES at 256 instances and found interleaved ahead,
-            // 0.0727 / 0.0748; with non-temporal stores "first" wins up to 448 instances: 256: 0.0581 against 0.0756 interleaved)
-            // (end of round 3, one box, e9 node-evals/s at first / 1.25 x / 1.5 x / even: 448 instances 4.21 / 4.41 / 4.22 / 4.31, 512: 3.60 / 4.32 / 4.38 / 4.22,
-            // 640: 3.76 / 4.48 / 4.37 / 4.37, 704: 3.89 / 4.63 / 4.45 / 4.50; ms per pass at even / 1.1 x / 1.25 x: 768: 0.1747 / 0.1696 / 0.1760,
-            // 896: 0.1964 / 0.1959 / 0.2022, 1024: 0.2230 / 0.2200 / 0.2304, 1536: 0.3215 / 0.3219 / 0.3411, 2048: 0.4239 / 0.4227 / 0.4415)
-            sa.mfma_first = c->pass_order >= 0 ? c->pass_order : (tiles16 < 208 ? 1 : (tiles16 < 384 ? 125 : (tiles16 < 768 ? 110 : 0)));
-            if (c->rtc ? emi::rtc_pass_supported(c->rtc, c->B, c->M, plan.sw, plan.ks, na.store_mode)
-                       : emi::pass_supported(c->model, c->ns, c->B, c->M, plan)) {
-                sa.cpart = plan.cpart; sa.cx = plan.cx;
-                if (plan.ks > 1) {
-                    int est = ensure(c, c->d_slab, plan.slab_bytes);
+        const PassPlan pp = plan_pass(c, c->B, jac);
+        if (pp.one_launch) {
+            const emi::SymPlan& plan = pp.sym;
+            sa.mfma_first = pp.mfma_first;
+            sa.cpart = plan.cpart;
+            sa.cx = plan.cx;
+            if (plan.ks > 1) {
+                int est = ensure(c, c->d_slab, plan.slab_bytes);
+                if (est) return est;
+                if (c->d_tile_ticket.bytes < (size_t)plan.tiles * 4) {
+                    est = ensure(c, c->d_tile_ticket, (size_t)plan.tiles * 4);
                     if (est) return est;
-                    if (c->d_tile_ticket.bytes < (size_t)plan.tiles * 4) {
-                        est = ensure(c, c->d_tile_ticket, (size_t)plan.tiles * 4);
-                        if (est) return est;
-                        HIP_TRY(c, hipMemsetAsync(c->d_tile_ticket.p, 0, c->d_tile_ticket.bytes, c->stream));
-                    }
-                    sa.ksplit = plan.ks;
-                    sa.slab = (double*)c->d_slab.p;
-                    sa.tile_ticket = (unsigned*)c->d_tile_ticket.p;
+                    HIP_TRY(c, hipMemsetAsync(c->d_tile_ticket.p, 0, c->d_tile_ticket.bytes, c->stream));
                 }
-                if (c->d_ticket.bytes < (size_t)c->B * 4) {
-                    int est = ensure(c, c->d_ticket, (size_t)c->B * 4);
-                    if (est) return est;
-                    HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, (size_t)c->B * 4, c->stream));
-                }
-                na.cost_ticket = (unsigned*)c->d_ticket.p;
-                if (plv) HIP_TRY(c, hipEventRecord(pe->k[0], c->stream));
-                if (c->rtc) HIP_TRY(c, emi::rtc_launch_pass(c->rtc, sa, na, plan.sw, c->stream));
-                else HIP_TRY(c, emi::launch_pass(c->model, sa, na, c->stream, plan));
-                if (plv) HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
-                if (pe) pe->level = -1;                 // one bracket: the pass kernel
-                c->last_defect_kernel = "emi_pass_f64_kernel<SW=" + std::to_string(plan.sw) + "> (MFMA + node roles, one launch" +
-                                        (plan.ks > 1 ? ", " + std::to_string(plan.ks) + " K slices per tile" : "") + ")";
-                return EMI_OK;
+                sa.ksplit = plan.ks;
+                sa.slab = (double*)c->d_slab.p;
+                sa.tile_ticket = (unsigned*)c->d_tile_ticket.p;
             }
+            if (c->d_ticket.bytes < (size_t)c->B * 4) {
+                int est = ensure(c, c->d_ticket, (size_t)c->B * 4);
+                if (est) return est;
+                HIP_TRY(c, hipMemsetAsync(c->d_ticket.p, 0, (size_t)c->B * 4, c->stream));
+            }
+            na.cost_ticket = (unsigned*)c->d_ticket.p;
+            if (plv) HIP_TRY(c, hipEventRecord(pe->k[0], c->stream));
+            if (c->rtc) HIP_TRY(c, emi::rtc_launch_pass(c->rtc, sa, na, plan.sw, c->stream));
+            else HIP_TRY(c, emi::launch_pass(c->model, sa, na, c->stream, plan));
+            if (plv) HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
+            if (pe) pe->level = -1;                 // one bracket: the pass kernel
+            c->last_defect_kernel = "emi_pass_f64_kernel<SW=" + std::to_string(plan.sw) + "> (MFMA + node roles, one launch" +
+                                    (plan.ks > 1 ? ", " + std::to_string(plan.ks) + " K slices per tile" : "") + ")";
+            return EMI_OK;
         }
         const bool two = c->overlap_mode != 1;
         const bool split = two && c->cu_split > 0;
@@ -1356,6 +1405,33 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         return EMI_OK;
     }
     return fail(c, EMI_ERR_ARG, "unknown option '%s'", name);
+}
+
+int emi_plan_pass(emi_ctx_t c, int B, emi_pass_plan_t* out) {
+    if (!c || !out || B < 1) return EMI_ERR_ARG;
+    if (c->M <= 0 || c->model < 0) return fail(c, EMI_ERR_STATE, "emi_plan_pass: mesh and model must be set");
+    memset(out, 0, sizeof *out);
+    const int Bkeep = c->B;
+    c->B = B;                                   // the policy reads the batch from the context (piece sizes, per-instance tables)
+    const int piece = (!c->f32 && overlapped_path(c)) ? plan_piece(c) : 0;
+    const int first = piece > 0 ? piece : B;    // instances of the first launch
+    out->piece = piece;
+    out->tail = piece > 0 ? B % piece : 0;
+    if (!c->f32 && overlapped_path(c)) {
+        const PassPlan p = plan_pass(c, first, true);
+        out->one_launch = p.one_launch ? 1 : 0;
+        out->sw = p.sym.sw;
+        out->ksplit = p.sym.ks;
+        out->ring_stages = p.sym.nst;
+        out->cpart = p.sym.cpart;
+        out->cx = p.sym.cx;
+        out->mfma_workgroups = p.sym.tiles * p.sym.ks;
+        out->store_mode = p.store_mode;
+        out->block_order = p.mfma_first;
+        out->tiles16 = p.tiles16;
+    }
+    c->B = Bkeep;
+    return EMI_OK;
 }
 
 int emi_last_path(emi_ctx_t c, int* fused) {

@@ -265,6 +265,12 @@ class Evaluator:
     def set_option(self, name, value):
         self._ck(self.lib.emi_set_option(self.ctx, name.encode(), int(value)), "emi_set_option")
 
+    def plan(self, B=None):
+        """What the default dispatch does with a batch of B instances (default: the batch set): dict of emi_pass_plan_t."""
+        p = L.PassPlan()
+        self._ck(self.lib.emi_plan_pass(self.ctx, int(B if B is not None else self.layout.B), C.byref(p)), "emi_plan_pass")
+        return {n: getattr(p, n) for n, _ in L.PassPlan._fields_}
+
     @property
     def last_defect_kernel(self):
         return self.lib.emi_last_defect_kernel(self.ctx).decode()

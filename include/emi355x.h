@@ -249,6 +249,23 @@ int emi_kkt_last_regularisation(emi_ctx_t ctx, double* dc, double* dw);
  * may be called repeatedly after one factor.                               */
 int emi_kkt_solve(emi_ctx_t ctx, double* rhs, int nrhs);
 
+/* What emi_eval_dev's default dispatch would do with a batch of B instances on this
+ * context (mesh, model, options as set): the one definition of the launch policy,
+ * for reports, tools and tests (csrc/emi_api.hip: plan_pass, plan_piece).           */
+typedef struct emi_pass_plan {
+  int one_launch;      /* 1: the pass goes out as ONE launch (emi_pass_f64_kernel: MFMA-role + node-role workgroups) */
+  int sw;              /* states per MFMA workgroup */
+  int ksplit;          /* K slices per tile (> 1: combined in-kernel by ticket, in slice order) */
+  int ring_stages;     /* operand ring stages of the MFMA role */
+  int cpart, cx;       /* tile order: 0 plain, > 0 column partitions, < 0 grouped (-G instance groups per super-block); column tiles per block */
+  int mfma_workgroups; /* workgroups of the MFMA role (tiles x K slices) */
+  int store_mode;      /* node-role result stores: 0 plain, 1 sc1, 2 non-temporal, 3 nt sc1 */
+  int block_order;     /* 1 MFMA workgroups first, 0 evenly interleaved, >= 100: MFMA workgroups at that % of the even density */
+  int tiles16;         /* 16-instance x 128-node tiles of the (first) launch */
+  int piece, tail;     /* > 0: the batch goes out in launches of `piece` instances and a last one of `tail` (0: none) */
+} emi_pass_plan_t;
+int emi_plan_pass(emi_ctx_t ctx, int B, emi_pass_plan_t* out);
+
 /* COO pattern of VALS in per-instance NLP numbering:
  * rows/cols have nvals*M entries ordered like VALS; cost-gradient entries
  * carry row = -1.                                                          */

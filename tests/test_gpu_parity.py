@@ -774,20 +774,22 @@ def test_mfma_defect_kernel_variants_for_the_two_state_model(built, sym_ct):
     ev.close()
 
 
-def _expected_default_form(B, M=1024):
-    """What emi_eval_dev's policy picks for the 6-state model by itself (csrc/emi_api.hip): the pass as one launch at every
-    size, SW = 1 below 128 sixteen-instance x 128-node tiles and 2 from there; batches above 2048 instances as one launch over
-    the multiple of 256 instances (grouped tile order) plus a second launch for the remainder."""
-    last = B if (B <= 2048 or B % 256 == 0) else B % 256
-    tiles16 = ((last + 15) // 16) * (M // 128)
-    if tiles16 >= 128:
-        return "emi_pass_f64_kernel<SW=2>"
-    wgs = tiles16 * 6                                  # MFMA workgroups unsplit: 4 K slices within 256 of them, 2 within 512
-    ks = 4 if wgs * 4 <= 256 else (2 if wgs * 2 <= 512 else 1)
-    return "emi_pass_f64_kernel<SW=1> (MFMA + node roles, one launch" + (f", {ks} K slices" if ks > 1 else ")")
+def _expected_default_form(ev, B):
+    """The name emi_eval_dev reports for the LAST launch of a batch of B instances, from the library's own statement of its
+    launch policy (emi_plan_pass: csrc/emi_api.hip plan_pass / plan_piece are the one definition; nothing is restated here)."""
+    p = ev.plan(B)
+    last = p["tail"] if p["tail"] else (p["piece"] if p["piece"] else B)
+    q = ev.plan(last)
+    assert q["one_launch"] == 1 and q["piece"] == 0
+    return (f"emi_pass_f64_kernel<SW={q['sw']}> (MFMA + node roles, one launch" + (f", {q['ksplit']} K slices" if q["ksplit"] > 1 else ")")), p
 
 
-@pytest.mark.parametrize("B", [1, 3, 5, 16, 64, 128, 256, 512, 1024, 2064, 2560])
+# the shapes the benchmark lines and the profiles quote, pinned: a policy change has to be made here as well as in plan_pass
+PINNED_PLANS = {128: dict(sw=1, ksplit=1, store_mode=0, block_order=1, piece=0), 1024: dict(sw=2, ksplit=1, store_mode=2, piece=0),
+                16: dict(sw=1, ksplit=4), 64: dict(sw=1, ksplit=2), 4096: dict(sw=2, store_mode=2, piece=0)}
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 16, 64, 128, 256, 512, 1024, 2064, 2560, 4096])
 def test_default_dispatch_at_the_benchmarked_shapes_matches_the_oracle(built, B):
     """The shapes bench.py and config 4 actually run -- M = 1024, 20 PER-INSTANCE keep-outs, B = 1 / 3 / 5 (role counts that are no
     multiple of 8: the grid is padded with workgroups that return at once), 16 / 64 (SW = 1 with 4 / 2 K slices per tile, combined
@@ -815,10 +817,13 @@ def test_default_dispatch_at_the_benchmarked_shapes_matches_the_oracle(built, B)
         ev.eval_dev(dX, dU, *outs)
     ev.synchronize()
     torch.cuda.synchronize()
-    assert _expected_default_form(B) in ev.last_defect_kernel, ev.last_defect_kernel
+    expected, plan = _expected_default_form(ev, B)
+    assert expected in ev.last_defect_kernel, (ev.last_defect_kernel, plan)
+    for k, v in PINNED_PLANS.get(B, {}).items():
+        assert plan[k] == v, (B, k, plan)
     for t in outs:
         assert not torch.isnan(t).any().item()          # every row of every instance was written
-    sample = [0, 15, 16, 17, B // 2 - 1, B // 2, B - 16, B - 1, 1023, 1024, 2047, 2048, 2063, 2303, 2304]
+    sample = [0, 15, 16, 17, B // 2 - 1, B // 2, B - 16, B - 1, 1023, 1024, 2047, 2048, 2063, 2303, 2304, 4080]
     e = O.sampled_errors(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, cases.W.TF, X, U, recs, outs, sample)
     print(f"B={B}: {ev.last_defect_kernel}: {e}")
     assert e["defect"] < TOL_DEFECT and e["path"] < TOL_NODE and e["vals"] < TOL_NODE and e["cost"] < 1e-13, e
