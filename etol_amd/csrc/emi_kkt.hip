@@ -1305,10 +1305,17 @@ static int solve_dev(KktWorkspace* w, hipStream_t stream, int nz, double* X, int
         dim3 gk((M + 127) / 128, nrhs), bk(128);
         // t = P a
         hipLaunchKernelGGL(emi_kkt_apply_p_kernel, gk, bk, 0, stream, w->Pinv, X, (size_t)N, w->T, (size_t)nz, M, nv);
-        // Cb = Doff t_states            (Doff = Dc^T in column-major terms), one M x ns panel per right-hand side
-        KKT_RB(rocblas_dgemm_strided_batched(w->handle, rocblas_operation_transpose, rocblas_operation_none, M, ns, M, &one,
-                                             w->Doff, M, 0, w->T, M, (rocblas_stride)nz, &zero, w->Cb, M, (rocblas_stride)md,
-                                             nrhs));
+        // Cb = Doff t_states            (Doff = Dc^T in column-major terms).  One right-hand side: an M x ns panel.  Many (the r columns of
+        // the low-rank correction, r ~ 800 at 1024 nodes): batched over the STATES instead -- state i of every right-hand side is the
+        // M x nrhs matrix at T + i M with leading dimension nz, so the product is ns large GEMMs (M x nrhs x M) rather than nrhs GEMMs
+        // with ns columns each (which ran at a few percent of the matrix pipe)
+        if (nrhs >= 8)
+            KKT_RB(rocblas_dgemm_strided_batched(w->handle, rocblas_operation_transpose, rocblas_operation_none, M, nrhs, M, &one,
+                                                 w->Doff, M, 0, w->T, nz, (rocblas_stride)M, &zero, w->Cb, md, (rocblas_stride)M, ns));
+        else
+            KKT_RB(rocblas_dgemm_strided_batched(w->handle, rocblas_operation_transpose, rocblas_operation_none, M, ns, M, &one,
+                                                 w->Doff, M, 0, w->T, M, (rocblas_stride)nz, &zero, w->Cb, M, (rocblas_stride)md,
+                                                 nrhs));
         // Cb += J_node t - b
         hipLaunchKernelGGL(emi_kkt_jnode_minus_b_kernel, gk, bk, 0, stream, w->J, w->T, (size_t)nz, X + nz, (size_t)N, w->Cb,
                            (size_t)md, M, ns, nv);
@@ -1317,8 +1324,12 @@ static int solve_dev(KktWorkspace* w, hipStream_t stream, int nz, double* X, int
         if (nrhs == 1 && w->linv_n == md) { if (int st = blk_potrs(w, stream, md, w->S, w->Cb, err)) return st; }
         else KKT_RB(rocsolver_dpotrs(w->handle, rocblas_fill_lower, md, nrhs, w->S, md, w->Cb, md));
         // y = a - J^T lambda  (in place in the primal part of X), then x = P y
-        KKT_RB(rocblas_dgemm_strided_batched(w->handle, rocblas_operation_none, rocblas_operation_none, M, ns, M, &mone, w->Doff,
-                                             M, 0, w->Cb, M, (rocblas_stride)md, &one, X, M, (rocblas_stride)N, nrhs));
+        if (nrhs >= 8)
+            KKT_RB(rocblas_dgemm_strided_batched(w->handle, rocblas_operation_none, rocblas_operation_none, M, nrhs, M, &mone, w->Doff,
+                                                 M, 0, w->Cb, md, (rocblas_stride)M, &one, X, N, (rocblas_stride)M, ns));
+        else
+            KKT_RB(rocblas_dgemm_strided_batched(w->handle, rocblas_operation_none, rocblas_operation_none, M, ns, M, &mone, w->Doff,
+                                                 M, 0, w->Cb, M, (rocblas_stride)md, &one, X, M, (rocblas_stride)N, nrhs));
         hipLaunchKernelGGL(emi_kkt_jnode_t_kernel, gk, bk, 0, stream, w->J, w->Cb, (size_t)md, X, (size_t)N, M, ns, nv);
         hipLaunchKernelGGL(emi_kkt_apply_p_kernel, gk, bk, 0, stream, w->Pinv, X, (size_t)N, w->T, (size_t)nz, M, nv);
         KKT_HIP(hipGetLastError());
