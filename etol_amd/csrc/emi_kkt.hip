@@ -166,16 +166,16 @@ __global__ __launch_bounds__(256) void emi_kkt_assemble_kernel(double* __restric
     K[(size_t)r * N + c] = val;    // K symmetric: row-major position == column-major position of the transpose
 }
 
-__global__ void emi_kkt_mask_rhs_kernel(double* __restrict__ rhs, const unsigned char* __restrict__ fixed, int nz, int N) {
+static __device__ __forceinline__ void emi_kkt_mask_rhs_kernel_body(double* __restrict__ rhs, const unsigned char* __restrict__ fixed, int nz, int N, int c_in) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nz && fixed[q]) rhs[(size_t)blockIdx.y * N + q] = 0.0;
+    if (q < nz && fixed[q]) rhs[(size_t)c_in * N + q] = 0.0;
 }
 
 
 // ---- method 1 kernels ----------------------------------------------------------------------
 #define KKT_NV_MAX 16
 // One thread per node: P_k = Q_k^-1 over the free variables (Cholesky), G_k = (P_k J_k^T)[states], R_k = J_k P_k J_k^T.
-__global__ __launch_bounds__(64) void emi_kkt_node_inverse_kernel(const double* __restrict__ Q, const double* __restrict__ J,
+static __device__ __forceinline__ void emi_kkt_node_inverse_kernel_body(const double* __restrict__ Q, const double* __restrict__ J,
                                                                  const unsigned char* __restrict__ fixed, int M, int ns,
                                                                  int nv, double* __restrict__ Pinv, double* __restrict__ G,
                                                                  double* __restrict__ Rk, int* __restrict__ flag, double dw) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64) void emi_kkt_node_inverse_kernel(const double* 
 // indexes its arrays with run-time bounds and runs out of 6.3 KB of scratch memory per thread: 252 us per launch whatever the mesh,
 // 14 % of a factorisation at 256 nodes).  Same operations in the same order: bitwise the generic kernel's results.
 template <int NS_, int NV_>
-__global__ __launch_bounds__(64) void emi_kkt_node_inverse_fixed_kernel(const double* __restrict__ Q, const double* __restrict__ J,
+static __device__ __forceinline__ void emi_kkt_node_inverse_fixed_kernel_body(const double* __restrict__ Q, const double* __restrict__ J,
                                                                  const unsigned char* __restrict__ fixed, int M,
                                                                  double* __restrict__ Pinv, double* __restrict__ G,
                                                                  double* __restrict__ Rk, int* __restrict__ flag, double dw) {
@@ -341,7 +341,7 @@ __global__ void emi_kkt_doff_kernel(const double* __restrict__ D, double* __rest
     Doff[idx] = j == k ? 0.0 : D[idx];
 }
 // W[k][j] = Doff[k][j] * p[j]
-__global__ void emi_kkt_scale_kernel(const double* __restrict__ Doff, const double* __restrict__ p, double* __restrict__ W,
+static __device__ __forceinline__ void emi_kkt_scale_kernel_body(const double* __restrict__ Doff, const double* __restrict__ p, double* __restrict__ W,
                                      int M) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)M * M) return;
@@ -360,15 +360,15 @@ __global__ void emi_kkt_scale_all_kernel(const double* __restrict__ Doff, const 
     W[(size_t)blockIdx.y * M * M + idx] = Doff[idx] * Pinv[(size_t)(i * nv + ip) * M + j];
 }
 // element-wise terms of one state-pair block of S (column-major big matrix, rows i*M+k, columns ip*M+kp)
-__global__ void emi_kkt_sblock_terms_kernel(double* __restrict__ S, const double* __restrict__ Doff,
+static __device__ __forceinline__ void emi_kkt_sblock_terms_kernel_body(double* __restrict__ S, const double* __restrict__ Doff,
                                             const double* __restrict__ G, const double* __restrict__ Rk, int M, int ns, int i,
-                                            int ip, double dc, double rel) {
+                                            int ip, double dc, double rel, int pair_in) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)M * M) return;
     if (i < 0) {                                   // batched launch: blockIdx.y = pair index
         i = 0;
-        while ((i + 1) * (i + 2) / 2 <= (int)blockIdx.y) ++i;
-        ip = (int)blockIdx.y - i * (i + 1) / 2;
+        while ((i + 1) * (i + 2) / 2 <= pair_in) ++i;
+        ip = pair_in - i * (i + 1) / 2;
     }
     const int kp = (int)(idx / M), k = (int)(idx - (size_t)kp * M);      // k fast: coalesced along a column of S
     const size_t md = (size_t)ns * M;
@@ -380,10 +380,10 @@ __global__ void emi_kkt_sblock_terms_kernel(double* __restrict__ S, const double
     *dst = (k == kp && i == ip) ? val * (1.0 + rel) + dc : val;
 }
 // out[(v,k),c] = sum_q P_k[v][q] in[(q,k),c]      (in/out: column stride ld_in / ld_out, nz rows used)
-__global__ void emi_kkt_apply_p_kernel(const double* __restrict__ Pinv, const double* __restrict__ in, size_t ld_in,
-                                       double* __restrict__ out, size_t ld_out, int M, int nv) {
+static __device__ __forceinline__ void emi_kkt_apply_p_kernel_body(const double* __restrict__ Pinv, const double* __restrict__ in, size_t ld_in,
+                                       double* __restrict__ out, size_t ld_out, int M, int nv, int c_in) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y;
+    const int c = c_in;
     if (k >= M) return;
     double x[KKT_NV_MAX];
     for (int q = 0; q < nv; ++q) x[q] = in[(size_t)c * ld_in + (size_t)q * M + k];
@@ -394,11 +394,11 @@ __global__ void emi_kkt_apply_p_kernel(const double* __restrict__ Pinv, const do
     }
 }
 // Cb[(i,k),c] += sum_v J_k[i][v] t[(v,k),c] - b[(i,k),c]
-__global__ void emi_kkt_jnode_minus_b_kernel(const double* __restrict__ J, const double* __restrict__ t, size_t ld_t,
+static __device__ __forceinline__ void emi_kkt_jnode_minus_b_kernel_body(const double* __restrict__ J, const double* __restrict__ t, size_t ld_t,
                                              const double* __restrict__ b, size_t ld_b, double* __restrict__ Cb, size_t ld_c,
-                                             int M, int ns, int nv) {
+                                             int M, int ns, int nv, int c_in) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y;
+    const int c = c_in;
     if (k >= M) return;
     for (int i = 0; i < ns; ++i) {
         double sum = 0;
@@ -407,10 +407,10 @@ __global__ void emi_kkt_jnode_minus_b_kernel(const double* __restrict__ J, const
     }
 }
 // y[(v,k),c] -= sum_i J_k[i][v] lam[(i,k),c]
-__global__ void emi_kkt_jnode_t_kernel(const double* __restrict__ J, const double* __restrict__ lam, size_t ld_l,
-                                       double* __restrict__ y, size_t ld_y, int M, int ns, int nv) {
+static __device__ __forceinline__ void emi_kkt_jnode_t_kernel_body(const double* __restrict__ J, const double* __restrict__ lam, size_t ld_l,
+                                       double* __restrict__ y, size_t ld_y, int M, int ns, int nv, int c_in) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y;
+    const int c = c_in;
     if (k >= M) return;
     for (int v = 0; v < nv; ++v) {
         double sum = 0;
@@ -419,10 +419,10 @@ __global__ void emi_kkt_jnode_t_kernel(const double* __restrict__ J, const doubl
     }
 }
 // rhs[(i,k) + nz, c] = lam[(i,k), c]
-__global__ void emi_kkt_copy_lambda_kernel(const double* __restrict__ lam, size_t ld_l, double* __restrict__ rhs, size_t ld_r,
-                                           int nz, int md) {
+static __device__ __forceinline__ void emi_kkt_copy_lambda_kernel_body(const double* __restrict__ lam, size_t ld_l, double* __restrict__ rhs, size_t ld_r,
+                                           int nz, int md, int c_in) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int c = blockIdx.y;
+    const int c = c_in;
     if (r < md) rhs[(size_t)c * ld_r + nz + r] = lam[(size_t)c * ld_l + r];
 }
 
@@ -468,7 +468,7 @@ const char* rb(rocblas_status s) { return rocblas_status_to_string(s); }
 // Thread (r, g) = (lane, wave) holds row r, columns g, g+4, ..: per column one LDS hand-over of the finished column
 // (double-buffered: one barrier), everything else is register arithmetic.  Lout: the factor once more, column-major
 // [64][64] with zeros above the diagonal, then the 64 reciprocals of its diagonal -- what the panel kernel reads.
-__global__ __launch_bounds__(256) void emi_chol_diag_kernel(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ info,
+static __device__ __forceinline__ void emi_chol_diag_kernel_body(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ info,
                                                             double* __restrict__ Lout) {
     __shared__ double col[2][CHOL_NB];
     const int tid = threadIdx.x, r = tid & 63, g = tid >> 6;
@@ -544,8 +544,8 @@ __global__ __launch_bounds__(EMI_PANEL_THREADS) void emi_chol_panel_kernel(doubl
 // groups interleaved (independent accumulators); the inverses of the four diagonal 16 x 16 blocks are formed by the wave itself
 // (a 16-step substitution per lane) and pass through LDS into the A layout.
 typedef double chol_d4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(64) void emi_chol_panel_mfma_kernel(double* __restrict__ A, int lda, int n, int j0,
-                                                                const double* __restrict__ Lb) {
+static __device__ __forceinline__ void emi_chol_panel_mfma_kernel_body(double* __restrict__ A, int lda, int n, int j0,
+                                                                const double* __restrict__ Lb, int rowgrp) {
     __shared__ double inv_s[4][16][17];
     const int lane = threadIdx.x, r16 = lane & 15, kq = lane >> 4;
     {   // lane (a = kq, j = r16): column j of inv(L_aa); L_aa[r][c] = Lb[(16 a + c) * 64 + 16 a + r], reciprocal diagonal behind the block
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64) void emi_chol_panel_mfma_kernel(double* __restr
             for (int ks = 0; ks < 4; ++ks)
                 Aoff[a * (a - 1) / 2 + b][ks] = -Lb[(size_t)(16 * b + kq + 4 * ks) * CHOL_NB + 16 * a + r16];
     // the panel: element (panel row, column 16 a + kq + 4 i) in T[g][a][i]
-    const int row0 = j0 + CHOL_NB + blockIdx.x * 64;
+    const int row0 = j0 + CHOL_NB + rowgrp * 64;
     chol_d4 T[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64) void emi_chol_panel_mfma_kernel(double* __restr
 // any shuffle), and whose four 16 x 16 diagonal blocks are factorised inside the wave with lane shuffles (16 columns each instead of
 // one 64-column chain with an LDS hand-over and a workgroup barrier per column: emi_chol_diag_kernel, 38 us per launch).
 // Full blocks only (nb == 64); the last, partial block of a matrix goes through emi_chol_diag_kernel.  Outputs as that kernel's.
-__global__ __launch_bounds__(64) void emi_chol_diag_mfma_kernel(double* __restrict__ A, int lda, int j0, int* __restrict__ info,
+static __device__ __forceinline__ void emi_chol_diag_mfma_kernel_body(double* __restrict__ A, int lda, int j0, int* __restrict__ info,
                                                                double* __restrict__ Lout) {
     __shared__ double Ls[16][17];
     __shared__ double inv_s[16][17];
@@ -774,10 +774,10 @@ __global__ __launch_bounds__(64) void emi_trsv_diag_kernel(const double* __restr
 }
 // transposes of the inverted diagonal blocks (512 x 512 each, 32 x 32 tiles through LDS): the forward sweep then multiplies with
 // op T like the backward one (rocBLAS gemvt 5 us a call, gemvn 22 us on a 512 x 512 block: eight workgroups)
-__global__ __launch_bounds__(256) void emi_trsv_transpose_kernel(const double* __restrict__ src, double* __restrict__ dst) {
+static __device__ __forceinline__ void emi_trsv_transpose_kernel_body(const double* __restrict__ src, double* __restrict__ dst, int blk_in) {
     __shared__ double tile[32][33];
-    const double* S = src + (size_t)blockIdx.z * TRSV_NB * TRSV_NB;
-    double* D = dst + (size_t)blockIdx.z * TRSV_NB * TRSV_NB;
+    const double* S = src + (size_t)blk_in * TRSV_NB * TRSV_NB;
+    double* D = dst + (size_t)blk_in * TRSV_NB * TRSV_NB;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
 #pragma unroll
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256) void emi_trsv_transpose_kernel(const double* _
 // y[0 .. m) -= A x for a TALL block A (m x nc, column-major, leading dimension lda; nc <= 512): 64 rows per workgroup, its four waves
 // take a quarter of the columns each and add up through LDS in wave order (fixed summation order).  The forward sweep's update of
 // everything below a block column; rocBLAS gemvn takes 22 us for it at 5632 x 512.
-__global__ __launch_bounds__(256) void emi_trsv_update_kernel(const double* __restrict__ A, int lda, int m, int nc,
+static __device__ __forceinline__ void emi_trsv_update_kernel_body(const double* __restrict__ A, int lda, int m, int nc,
                                                               const double* __restrict__ x, double* __restrict__ y) {
     __shared__ double xs[TRSV_NB];
     __shared__ double part[4][64];
@@ -818,6 +818,139 @@ __global__ __launch_bounds__(256) void emi_trsv_update_kernel(const double* __re
 __global__ void emi_trsv_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
+}
+
+// ---- kernels: the single-instance entry points (one workspace) and the BATCHED ones (a table of workspaces, one entry per
+// scenario: emi_kkt_factor_batch / _solve_batch).  Same bodies: a batched launch is the single launch with blockIdx.y (or .x for the
+// one-workgroup kernels) choosing the scenario, so a batch of n scenarios amortises every dependency chain of the factorisation
+// (96 diagonal-block steps at 1024 nodes) over n matrices.
+struct KktDev {                 // device pointers of one workspace, as the batched kernels see them
+    double *Q, *J, *Pinv, *G, *Rk, *S, *W, *chol_blk, *Linv, *LinvT, *T, *Cb, *rhs, *y;
+    const double* Doff;
+    unsigned char* fixed;
+    int *flag, *info;
+    double dw, dc;
+};
+
+__global__ __launch_bounds__(64) void emi_kkt_node_inverse_kernel(const double* __restrict__ Q, const double* __restrict__ J,
+                                                                 const unsigned char* __restrict__ fixed, int M, int ns, int nv, double* __restrict__ Pinv,
+                                                                 double* __restrict__ G, double* __restrict__ Rk, int* __restrict__ flag, double dw) {
+    emi_kkt_node_inverse_kernel_body(Q, J, fixed, M, ns, nv, Pinv, G, Rk, flag, dw);
+}
+__global__ __launch_bounds__(64) void emi_kkt_node_inverse_b_kernel(const KktDev* __restrict__ tab, int M, int ns, int nv) {
+    const KktDev t = tab[blockIdx.y];
+    emi_kkt_node_inverse_kernel_body(t.Q, t.J, t.fixed, M, ns, nv, t.Pinv, t.G, t.Rk, t.flag, t.dw);
+}
+template <int NS_, int NV_>
+__global__ __launch_bounds__(64) void emi_kkt_node_inverse_fixed_kernel(const double* __restrict__ Q, const double* __restrict__ J,
+                                                                       const unsigned char* __restrict__ fixed, int M, double* __restrict__ Pinv,
+                                                                       double* __restrict__ G, double* __restrict__ Rk, int* __restrict__ flag, double dw) {
+    emi_kkt_node_inverse_fixed_kernel_body<NS_, NV_>(Q, J, fixed, M, Pinv, G, Rk, flag, dw);
+}
+template <int NS_, int NV_>
+__global__ __launch_bounds__(64) void emi_kkt_node_inverse_fixed_b_kernel(const KktDev* __restrict__ tab, int M) {
+    const KktDev t = tab[blockIdx.y];
+    emi_kkt_node_inverse_fixed_kernel_body<NS_, NV_>(t.Q, t.J, t.fixed, M, t.Pinv, t.G, t.Rk, t.flag, t.dw);
+}
+__global__ void emi_kkt_scale_kernel(const double* __restrict__ Doff, const double* __restrict__ p, double* __restrict__ W, int M) {
+    emi_kkt_scale_kernel_body(Doff, p, W, M);
+}
+__global__ void emi_kkt_scale_b_kernel(const KktDev* __restrict__ tab, int M, int pofs) {      // p = Pinv + pofs: entry (i, ip) of the node inverses
+    const KktDev t = tab[blockIdx.y];
+    emi_kkt_scale_kernel_body(t.Doff, t.Pinv + pofs, t.W, M);
+}
+__global__ void emi_kkt_sblock_terms_kernel(double* __restrict__ S, const double* __restrict__ Doff, const double* __restrict__ G,
+                                            const double* __restrict__ Rk, int M, int ns, int i, int ip, double dc, double rel) {
+    emi_kkt_sblock_terms_kernel_body(S, Doff, G, Rk, M, ns, i, ip, dc, rel, (int)blockIdx.y);
+}
+__global__ void emi_kkt_sblock_terms_b_kernel(const KktDev* __restrict__ tab, int M, int ns, int i, int ip) {
+    const KktDev t = tab[blockIdx.y];
+    emi_kkt_sblock_terms_kernel_body(t.S, t.Doff, t.G, t.Rk, M, ns, i, ip, t.dc, 0.0, 0);
+}
+__global__ void emi_kkt_mask_rhs_kernel(double* __restrict__ rhs, const unsigned char* __restrict__ fixed, int nz, int N) {
+    emi_kkt_mask_rhs_kernel_body(rhs, fixed, nz, N, (int)blockIdx.y);
+}
+__global__ void emi_kkt_mask_rhs_b_kernel(const KktDev* __restrict__ tab, int nz, int N) {
+    const KktDev t = tab[blockIdx.y];
+    emi_kkt_mask_rhs_kernel_body(t.rhs, t.fixed, nz, N, 0);
+}
+__global__ void emi_kkt_apply_p_kernel(const double* __restrict__ Pinv, const double* __restrict__ in, size_t ld_in, double* __restrict__ out,
+                                       size_t ld_out, int M, int nv) {
+    emi_kkt_apply_p_kernel_body(Pinv, in, ld_in, out, ld_out, M, nv, (int)blockIdx.y);
+}
+__global__ void emi_kkt_apply_p_b_kernel(const KktDev* __restrict__ tab, int M, int nv, int back) {    // back: T <- P rhs, else rhs -> T
+    const KktDev t = tab[blockIdx.y];
+    (void)back;
+    emi_kkt_apply_p_kernel_body(t.Pinv, t.rhs, 0, t.T, 0, M, nv, 0);
+}
+__global__ void emi_kkt_jnode_minus_b_kernel(const double* __restrict__ J, const double* __restrict__ t, size_t ld_t, const double* __restrict__ b,
+                                             size_t ld_b, double* __restrict__ Cb, size_t ld_c, int M, int ns, int nv) {
+    emi_kkt_jnode_minus_b_kernel_body(J, t, ld_t, b, ld_b, Cb, ld_c, M, ns, nv, (int)blockIdx.y);
+}
+__global__ void emi_kkt_jnode_minus_b_b_kernel(const KktDev* __restrict__ tab, int M, int ns, int nv) {
+    const KktDev t = tab[blockIdx.y];
+    emi_kkt_jnode_minus_b_kernel_body(t.J, t.T, 0, t.rhs + (size_t)nv * M, 0, t.Cb, 0, M, ns, nv, 0);
+}
+__global__ void emi_kkt_jnode_t_kernel(const double* __restrict__ J, const double* __restrict__ lam, size_t ld_l, double* __restrict__ y, size_t ld_y,
+                                       int M, int ns, int nv) {
+    emi_kkt_jnode_t_kernel_body(J, lam, ld_l, y, ld_y, M, ns, nv, (int)blockIdx.y);
+}
+__global__ void emi_kkt_jnode_t_b_kernel(const KktDev* __restrict__ tab, int M, int ns, int nv) {
+    const KktDev t = tab[blockIdx.y];
+    emi_kkt_jnode_t_kernel_body(t.J, t.Cb, 0, t.rhs, 0, M, ns, nv, 0);
+}
+__global__ void emi_kkt_copy_lambda_kernel(const double* __restrict__ lam, size_t ld_l, double* __restrict__ rhs, size_t ld_r, int nz, int md) {
+    emi_kkt_copy_lambda_kernel_body(lam, ld_l, rhs, ld_r, nz, md, (int)blockIdx.y);
+}
+// the tail of a batched solve: rhs[0 .. nz) <- T (the primal step), rhs[nz ..) <- Cb (the multipliers)
+__global__ void emi_kkt_finish_solve_b_kernel(const KktDev* __restrict__ tab, int nz, int md) {
+    const KktDev t = tab[blockIdx.y];
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nz) t.rhs[q] = t.T[q];
+    else if (q < nz + md) t.rhs[q] = t.Cb[q - nz];
+}
+__global__ __launch_bounds__(256) void emi_chol_diag_kernel(double* __restrict__ A, int lda, int j0, int nb, int* __restrict__ info,
+                                                            double* __restrict__ Lout) {
+    emi_chol_diag_kernel_body(A, lda, j0, nb, info, Lout);
+}
+__global__ __launch_bounds__(256) void emi_chol_diag_b_kernel(const KktDev* __restrict__ tab, int lda, int j0, int nb) {
+    const KktDev t = tab[blockIdx.x];
+    emi_chol_diag_kernel_body(t.S, lda, j0, nb, t.info, t.chol_blk);
+}
+__global__ __launch_bounds__(64) void emi_chol_diag_mfma_kernel(double* __restrict__ A, int lda, int j0, int* __restrict__ info, double* __restrict__ Lout) {
+    emi_chol_diag_mfma_kernel_body(A, lda, j0, info, Lout);
+}
+__global__ __launch_bounds__(64) void emi_chol_diag_mfma_b_kernel(const KktDev* __restrict__ tab, int lda, int j0) {
+    const KktDev t = tab[blockIdx.x];
+    emi_chol_diag_mfma_kernel_body(t.S, lda, j0, t.info, t.chol_blk);
+}
+__global__ __launch_bounds__(64) void emi_chol_panel_mfma_kernel(double* __restrict__ A, int lda, int n, int j0, const double* __restrict__ Lb) {
+    emi_chol_panel_mfma_kernel_body(A, lda, n, j0, Lb, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(64) void emi_chol_panel_mfma_b_kernel(const KktDev* __restrict__ tab, int lda, int n, int j0) {
+    const KktDev t = tab[blockIdx.y];
+    emi_chol_panel_mfma_kernel_body(t.S, lda, n, j0, t.chol_blk, (int)blockIdx.x);
+}
+__global__ __launch_bounds__(256) void emi_trsv_transpose_kernel(const double* __restrict__ src, double* __restrict__ dst) {
+    emi_trsv_transpose_kernel_body(src, dst, (int)blockIdx.z);
+}
+__global__ __launch_bounds__(256) void emi_trsv_transpose_b_kernel(const KktDev* __restrict__ tab, int nblk) {
+    const KktDev t = tab[blockIdx.z / nblk];
+    emi_trsv_transpose_kernel_body(t.Linv, t.LinvT, (int)(blockIdx.z % nblk));
+}
+__global__ __launch_bounds__(256) void emi_trsv_update_kernel(const double* __restrict__ A, int lda, int m, int nc, const double* __restrict__ x,
+                                                              double* __restrict__ y) {
+    emi_trsv_update_kernel_body(A, lda, m, nc, x, y);
+}
+// forward sweep of a batched solve, block column j0: everything below it in Cb -= L[rest, block] y_block
+__global__ __launch_bounds__(256) void emi_trsv_update_b_kernel(const KktDev* __restrict__ tab, int lda, int j0, int bs, int rest) {
+    const KktDev t = tab[blockIdx.y];
+    emi_trsv_update_kernel_body(t.S + (size_t)j0 * lda + j0 + bs, lda, rest, bs, t.y + j0, t.Cb + j0 + bs);
+}
+// status words of a batch gathered in one place (one copy to the host instead of two per scenario)
+__global__ void emi_kkt_zero_status_b_kernel(const KktDev* __restrict__ tab, int n) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n) { *tab[b].flag = 0; *tab[b].info = 0; }
 }
 
 // error plumbing of the host functions below: they have `std::string* err` in scope and return an EMI_* status

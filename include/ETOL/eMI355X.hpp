@@ -29,9 +29,13 @@ struct Alg {
     std::string hessian = "exact";
     std::string collocation_method = "Legendre";   // Legendre-Gauss-Lobatto, as PSOPT's "Legendre"
     std::string mesh_refinement = "automatic";     // "automatic" or "none" (ePSOPT.cpp:69)
-    std::string scaling = "automatic";             // ePSOPT.cpp:63.  "automatic": the NLP iteration runs on variables scaled by their bounds
-                                                   // (z_v / max(|lower_v|, |upper_v|)) and on defect rows scaled like their state (PSOPT's
-                                                   // state-based defect scaling); "none": unscaled.  Results are always in the caller's units.
+    std::string scaling = "none";                  // ePSOPT.cpp:63 sets PSOPT's "automatic".  Here "automatic" is built (the NLP iteration runs on variables
+                                                   // scaled by their bounds, z_v / max(|lower_v|, |upper_v|), and on defect rows scaled like their state:
+                                                   // PSOPT's state-based defect scaling) and is an OPTION, not the default: measured on one box
+                                                   // (profiles/r04_regress_probe.json) it takes the 1024-node / 20 keep-out solve from 12 to 58 last-mesh
+                                                   // iterations (0.92 -> 3.05 s, and to a worse local optimum, 416.19 against 400.47) and the 129-node
+                                                   // fixed wing from 11 to 79 (1.05 -> 2.32 s); on Monte-Carlo sets it saves ~10 % of the iterations.
+                                                   // Results are always in the caller's units.
     int mr_max_iterations = 10;                    // ePSOPT.cpp:70
     double ode_tolerance = 1.e-4;                  // ePSOPT.cpp:71
     int mr_max_nodes = 513;                        // refinement stops adding nodes here

@@ -174,6 +174,7 @@ def test_delay_declarations_are_checked(built):
     assert ev.n_delayed == 0
     assert lib.emi_set_delays(ev.ctx, 0, 1, C.c_double(0.0)) == 1                 # dt must be positive
     assert lib.emi_set_delays(ev.ctx, 0, 1, C.c_double(0.1)) == 0                 # 2 = 1 free control + its delayed copy
+    ev._changed()                                                                 # (the C ABI was called behind the Evaluator's cached layout)
     assert ev.n_delayed == 1
     ev.close()
 
