@@ -529,6 +529,7 @@ int emi_set_mesh(emi_ctx_t c, int M, const double* tau, const double* w, const d
         c->symmetric = false;
         c->points_only = true;
         c->delay_dirty = true;
+        emi::kkt_mesh_changed(c->kkt);
         c->h_tau.assign(tau, tau + M);
         c->h_w.assign(w, w + M);
         c->M = M; c->t0 = t0; c->tf = tf;
@@ -599,6 +600,7 @@ int emi_set_mesh(emi_ctx_t c, int M, const double* tau, const double* w, const d
     c->t0 = t0;
     c->tf = tf;
     c->delay_dirty = true;      // W(delay) is built for one mesh: [nd][M][M] on these nodes and this horizon
+    emi::kkt_mesh_changed(c->kkt);
     // tables sized by M are stale now
     c->ntracks = 0;
     c->track_sets = 0;
@@ -1220,6 +1222,73 @@ int emi_kkt_lowrank(emi_ctx_t c, int r, const int* node, const double* vec, cons
     std::string err;
     const int st = emi::kkt_lowrank(c->kkt, c->stream, (c->ns + c->nc) * c->M, r, node, vec, delta, exact, &err);
     if (st) c->err = err;
+    return st;
+}
+
+// ---- batched Newton steps: n contexts (one scenario each) on the same mesh and model ---------------------------------------
+static int batch_compatible(int n, const emi_ctx_t* ctxs, const char* what) {
+    if (n < 1 || !ctxs || !ctxs[0]) return EMI_ERR_ARG;
+    emi_ctx_t c0 = ctxs[0];
+    for (int b = 0; b < n; ++b) {
+        emi_ctx_t c = ctxs[b];
+        if (!c) return EMI_ERR_ARG;
+        if (c->M <= 0 || c->model < 0 || c->f32 || c->points_only || c->kkt_method != 1)
+            return fail(c0, EMI_ERR_STATE, "%s: context %d is not an f64 context with a collocation mesh, a model and the Schur method", what, b);
+        if (c->device != c0->device || c->M != c0->M || c->ns != c0->ns || c->nc != c0->nc)
+            return fail(c0, EMI_ERR_ARG, "%s: context %d differs from context 0 in device, mesh size or model dimensions", what, b);
+        for (int a = 0; a < b; ++a)
+            if (ctxs[a] == c) return fail(c0, EMI_ERR_ARG, "%s: context %d appears twice", what, b);
+    }
+    return EMI_OK;
+}
+
+int emi_kkt_factor_batch(int n, const emi_ctx_t* ctxs, const double* const* Qblk, const double* const* Jblk,
+                         const unsigned char* const* fixed, const double* dc, int* info) {
+    int st = batch_compatible(n, ctxs, "emi_kkt_factor_batch");
+    if (st) return st;
+    emi_ctx_t c0 = ctxs[0];
+    if (!Qblk || !Jblk || !fixed || !dc || !info) return fail(c0, EMI_ERR_ARG, "emi_kkt_factor_batch: null argument");
+    for (int b = 0; b < n; ++b)
+        if (!Qblk[b] || !Jblk[b] || !fixed[b] || !(dc[b] >= 0.0)) return fail(c0, EMI_ERR_ARG, "emi_kkt_factor_batch: bad argument for scenario %d", b);
+    HIP_TRY(c0, hipSetDevice(c0->device));
+    std::vector<emi::KktWorkspace**> pws(n);
+    std::vector<const double*> dD(n);
+    for (int b = 0; b < n; ++b) {
+        HIP_TRY(c0, hipStreamSynchronize(ctxs[b]->stream));     // whatever the scenario's own stream still holds (its last evaluation)
+        pws[b] = &ctxs[b]->kkt;
+        dD[b] = (const double*)ctxs[b]->d_D.p;
+    }
+    std::string err;
+    st = emi::kkt_factor_batch(n, pws.data(), c0->stream, dD.data(), c0->M, c0->ns, c0->ns + c0->nc, Qblk, Jblk, fixed, dc, info, &err);
+    if (st) { c0->err = err; return st; }
+    // scenarios the batch could not take (a node block not positive definite, the ladder exhausted): the single path with its LU
+    for (int b = 0; b < n; ++b)
+        if (info[b] < 0) {
+            const int s1 = emi_kkt_factor(ctxs[b], Qblk[b], Jblk[b], fixed[b], dc[b], &info[b]);
+            if (s1) { c0->err = ctxs[b]->err; return s1; }
+        }
+    return EMI_OK;
+}
+
+int emi_kkt_solve_batch(int n, const emi_ctx_t* ctxs, double* const* rhs) {
+    int st = batch_compatible(n, ctxs, "emi_kkt_solve_batch");
+    if (st) return st;
+    emi_ctx_t c0 = ctxs[0];
+    if (!rhs) return fail(c0, EMI_ERR_ARG, "emi_kkt_solve_batch: null argument");
+    HIP_TRY(c0, hipSetDevice(c0->device));
+    // scenarios whose factorisation is the LU fallback (or none) go through the single entry point; the rest as one batch
+    std::vector<emi::KktWorkspace*> ws;
+    std::vector<double*> rb;
+    for (int b = 0; b < n; ++b) {
+        if (!rhs[b]) return fail(c0, EMI_ERR_ARG, "emi_kkt_solve_batch: null right-hand side %d", b);
+        HIP_TRY(c0, hipStreamSynchronize(ctxs[b]->stream));
+        if (emi::kkt_is_schur(ctxs[b]->kkt)) { ws.push_back(ctxs[b]->kkt); rb.push_back(rhs[b]); }
+        else if ((st = emi_kkt_solve(ctxs[b], rhs[b], 1))) { c0->err = ctxs[b]->err; return st; }
+    }
+    if (ws.empty()) return EMI_OK;
+    std::string err;
+    st = emi::kkt_solve_batch((int)ws.size(), ws.data(), c0->stream, (c0->ns + c0->nc) * c0->M, rb.data(), &err);
+    if (st) c0->err = err;
     return st;
 }
 

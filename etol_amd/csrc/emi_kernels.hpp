@@ -75,5 +75,12 @@ int kkt_lowrank(KktWorkspace* w, hipStream_t stream, int nz, int r, const int* n
                 int* exact, std::string* err);
 void kkt_destroy(KktWorkspace* w);
 void kkt_last_regularisation(const KktWorkspace* w, double* dc, double* dw);
+void kkt_mesh_changed(KktWorkspace* w);
+bool kkt_is_schur(const KktWorkspace* w);            // holds a factorisation of the Schur path (what the batched solve takes)
+// the Newton steps of n scenarios on one mesh at once (emi_kkt.hip, "Batched entry points")
+int kkt_factor_batch(int n, KktWorkspace** const* pws, hipStream_t stream, const double* const* dD, int M, int ns, int nv,
+                     const double* const* Qblk, const double* const* Jblk, const unsigned char* const* fixed, const double* dc, int* info,
+                     std::string* err);
+int kkt_solve_batch(int n, KktWorkspace* const* ws, hipStream_t stream, int nz, double* const* rhs, std::string* err);
 
 }  // namespace emi

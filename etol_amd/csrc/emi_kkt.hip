@@ -130,6 +130,15 @@ struct KktWorkspace {
     int* lr_node = nullptr;
     double* lr_vec = nullptr;   // [r][nv]
     double* lr_delta = nullptr;
+    // Doff is a function of the mesh only: rebuilt when the mesh changes (kkt_mesh_changed), not at every factorisation
+    const double* doff_src = nullptr;
+    int doff_M = 0;
+    // batched entry points (kkt_factor_batch / kkt_solve_batch): scratch of the workspace that LEADS a batch
+    void* b_tab = nullptr;      // device: KktDev[n]
+    double** b_ptrs = nullptr;  // device: pointer arrays of the batched rocBLAS calls
+    int* b_stat = nullptr;      // device: [2 n] info words, then block flags
+    char* b_pin = nullptr;      // pinned host staging of all three
+    size_t cap_b_tab = 0, cap_b_ptrs = 0, cap_b_stat = 0, cap_b_pin = 0;
 };
 
 namespace {
@@ -1200,7 +1209,19 @@ void kkt_destroy(KktWorkspace* w) {
                     w->Cb, w->flag, w->chol_blk, w->chol_copy, w->Linv, w->LinvT, w->trsv_tmp, w->trsv_y, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (w->b_tab) (void)hipFree(w->b_tab);
+    if (w->b_ptrs) (void)hipFree(w->b_ptrs);
+    if (w->b_stat) (void)hipFree(w->b_stat);
+    if (w->b_pin) (void)hipHostFree(w->b_pin);
     delete w;
+}
+
+bool kkt_is_schur(const KktWorkspace* w) { return w && w->factored && w->method_used == 1; }
+
+void kkt_mesh_changed(KktWorkspace* w) {
+    if (!w) return;
+    w->doff_M = 0;
+    w->doff_src = nullptr;
 }
 
 // Returns an EMI_* status; *info = 0 factorised, > 0 exactly singular (zero pivot at that position).
@@ -1243,6 +1264,7 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         KKT_ENSURE(w->Pinv, w->cap_Pinv, (size_t)nv * nv * M * sizeof(double));
         KKT_ENSURE(w->G, w->cap_G, (size_t)ns * ns * M * sizeof(double));
         KKT_ENSURE(w->Rk, w->cap_Rk, (size_t)ns * ns * M * sizeof(double));
+        if (w->cap_Doff < (size_t)M * M * sizeof(double)) w->doff_M = 0;
         KKT_ENSURE(w->Doff, w->cap_Doff, (size_t)M * M * sizeof(double));
         // one batched GEMM for all state pairs where the build is launch-bound (measured: +5-10 % Monte-Carlo throughput
         // at 65 nodes, +3 % at 129; no gain per factorisation at 1024 nodes, where the unbatched form is kept)
@@ -1257,7 +1279,11 @@ int kkt_factor(KktWorkspace** pw, hipStream_t stream, const double* dD, int M, i
         // works against the matrix with the nominal dc.
         KKT_HIP(hipMemsetAsync(w->flag, 0, sizeof(int), stream));
         const unsigned nb2 = (unsigned)(((size_t)M * M + 255) / 256);
-        hipLaunchKernelGGL(emi_kkt_doff_kernel, dim3(nb2), dim3(256), 0, stream, dD, w->Doff, M);
+        if (w->doff_M != M || w->doff_src != dD) {
+            hipLaunchKernelGGL(emi_kkt_doff_kernel, dim3(nb2), dim3(256), 0, stream, dD, w->Doff, M);
+            w->doff_M = M;
+            w->doff_src = dD;
+        }
         // Doff is stored [k][j] row-major, i.e. as the column-major matrix Dc = Doff^T:  Doff diag(p) Doff^T = Dc^T (diag(p) Dc)
         const double one = 1.0, zero = 0.0;
         rocblas_int hinfo = 0;
@@ -1559,6 +1585,441 @@ int kkt_solve(KktWorkspace* w, hipStream_t stream, int nz, double* rhs, int nrhs
                              &one, w->rhs, N));
     }
     KKT_HIP(hipMemcpyAsync(rhs, w->rhs, elems * sizeof(double), hipMemcpyDeviceToHost, stream));
+    KKT_HIP(hipStreamSynchronize(stream));
+    return EMI_OK;
+}
+
+// ==================================================================================================================================
+// Batched entry points: the Newton steps of n scenarios on ONE mesh at once.
+//
+// A Monte-Carlo run solves hundreds of independent scenarios of the same transcription (BASELINE configs[3]).
+// Factorised one by one -- each from its own host thread -- their ~50 000 small launches per solve take turns on the device: the
+// chain of 96 one-workgroup diagonal-block kernels of a 1024-node factorisation keeps one CU of 256 busy, and eight host threads
+// reached 2.3 x the throughput of one (profiles/r03_notes.md section 7).  Here every launch of the factorisation carries the whole
+// batch: the diagonal-block kernel runs n workgroups, the panel kernel n x rest / 64, every GEMM is a batched GEMM, so the dependency
+// chain of ONE factorisation is paid once per batch.  The scenarios keep their own workspaces (factors, node inverses, low-rank
+// correction); the batch is a table of their device pointers (KktDev) plus pointer arrays for rocBLAS' *_batched calls, built on the
+// host in pinned memory and uploaded once per attempt.
+//
+// Restrictions (the caller falls back to the single entry points otherwise): Schur method, one common (M, ns, nv), every scenario's
+// context holding the same differentiation matrix (all of them come from emi_lgl for the same node count).
+// ==================================================================================================================================
+namespace {
+
+int batch_scratch(KktWorkspace* L, size_t tab_bytes, size_t ptr_bytes, size_t stat_bytes, std::string* err) {
+    KKT_ENSURE(L->b_tab, L->cap_b_tab, tab_bytes);
+    KKT_ENSURE(L->b_ptrs, L->cap_b_ptrs, ptr_bytes);
+    KKT_ENSURE(L->b_stat, L->cap_b_stat, stat_bytes);
+    const size_t pin = tab_bytes + ptr_bytes + stat_bytes;
+    if (L->cap_b_pin < pin) {
+        if (L->b_pin) KKT_HIP(hipHostFree(L->b_pin));
+        L->b_pin = nullptr;
+        L->cap_b_pin = 0;
+        KKT_HIP(hipHostMalloc((void**)&L->b_pin, pin + pin / 2, hipHostMallocDefault));
+        L->cap_b_pin = pin + pin / 2;
+    }
+    return EMI_OK;
+}
+
+// handle + every buffer a Schur factorisation of (M, ns, nv) needs, Doff for the mesh
+int ws_prepare(KktWorkspace* w, hipStream_t stream, const double* dD, int M, int ns, int nv, std::string* err) {
+    const int nh = nv * (nv + 1) / 2, N = (nv + ns) * M, nz = nv * M;
+    const size_t md = (size_t)ns * M;
+    if (!w->handle) {
+        KKT_RB(rocblas_create_handle(&w->handle));
+        KKT_RB(rocblas_set_atomics_mode(w->handle, rocblas_atomics_not_allowed));
+    }
+    if (!w->info) KKT_HIP(hipMalloc(&w->info, sizeof(rocblas_int)));
+    if (!w->flag) KKT_HIP(hipMalloc(&w->flag, sizeof(int)));
+    if (!w->chol_blk) KKT_HIP(hipMalloc((void**)&w->chol_blk, (CHOL_NB * CHOL_NB + CHOL_NB) * sizeof(double)));
+    KKT_ENSURE(w->ipiv, w->cap_ipiv, (size_t)N * sizeof(rocblas_int));
+    KKT_ENSURE(w->Q, w->cap_Q, (size_t)nh * M * sizeof(double));
+    KKT_ENSURE(w->J, w->cap_J, (size_t)ns * nv * M * sizeof(double));
+    KKT_ENSURE(w->fixed, w->cap_fixed, (size_t)nz);
+    if (w->S_elems < md * md) {
+        if (w->S) KKT_HIP(hipFree(w->S));
+        w->S = nullptr;
+        w->S_elems = 0;
+        KKT_HIP(hipMalloc(&w->S, md * md * sizeof(double)));
+        w->S_elems = md * md;
+    }
+    KKT_ENSURE(w->Pinv, w->cap_Pinv, (size_t)nv * nv * M * sizeof(double));
+    KKT_ENSURE(w->G, w->cap_G, (size_t)ns * ns * M * sizeof(double));
+    KKT_ENSURE(w->Rk, w->cap_Rk, (size_t)ns * ns * M * sizeof(double));
+    if (w->cap_Doff < (size_t)M * M * sizeof(double)) w->doff_M = 0;
+    KKT_ENSURE(w->Doff, w->cap_Doff, (size_t)M * M * sizeof(double));
+    KKT_ENSURE(w->W, w->cap_W, (size_t)M * M * sizeof(double));
+    if (w->doff_M != M || w->doff_src != dD) {
+        hipLaunchKernelGGL(emi_kkt_doff_kernel, dim3((unsigned)(((size_t)M * M + 255) / 256)), dim3(256), 0, stream, dD, w->Doff, M);
+        KKT_HIP(hipGetLastError());
+        w->doff_M = M;
+        w->doff_src = dD;
+    }
+    w->N = N; w->M = M; w->ns = ns; w->nv = nv;
+    return EMI_OK;
+}
+
+// Blocked Cholesky of na matrices at once (two-level form of chol_blocked2; lower, column-major, lda = n): per 64-column step one
+// diagonal-block launch of na workgroups, one panel launch, one batched dgemm for the rest of the outer panel; per outer panel one
+// batched dsyrk.  ptrs: device pointer arrays laid out by the caller as  [step][0 = panel, 1 = trailing][na]  for the steps, then
+// [outer][0 = panel, 1 = trailing][na]  for the outer updates (host copy hp: the same layout, filled here).
+int chol_batched(KktWorkspace* L, hipStream_t stream, const KktDev* d_tab, int na, double* const* Sptr, int n, double** hp, double** dp,
+                 size_t* used, std::string* err) {
+    const int NB2 = std::max(128, (g_tune.chol_outer.load() / CHOL_NB) * CHOL_NB);
+    const double one = 1.0, mone = -1.0;
+    size_t q = 0;
+    // pass 1: every pointer array on the host (the launches below read them from dp, which the caller uploads AFTER this function
+    // has filled hp?  No: the arrays must be on the device before the first launch that uses them, so they are filled first ...)
+    struct Step { int j0, nb, rest, wc; size_t at; };
+    struct Outer { int J0, Jend, rest2; size_t at; };
+    std::vector<Step> steps;
+    std::vector<Outer> outers;
+    for (int J0 = 0; J0 < n; J0 += NB2) {
+        const int Jend = std::min(n, J0 + NB2);
+        for (int j0 = J0; j0 < Jend; j0 += CHOL_NB) {
+            const int nb = std::min(CHOL_NB, n - j0), rest = n - j0 - nb, wc = Jend - (j0 + nb);
+            Step st{j0, nb, rest, wc, q};
+            if (rest > 0 && wc > 0) {
+                for (int a = 0; a < na; ++a) hp[q + a] = Sptr[a] + (size_t)j0 * n + j0 + nb;                 // panel below the diagonal block
+                for (int a = 0; a < na; ++a) hp[q + na + a] = Sptr[a] + (size_t)(j0 + nb) * n + j0 + nb;     // rest of the outer panel
+                q += 2 * (size_t)na;
+            }
+            steps.push_back(st);
+        }
+        const int rest2 = n - Jend;
+        Outer o{J0, Jend, rest2, q};
+        if (rest2 > 0) {
+            for (int a = 0; a < na; ++a) hp[q + a] = Sptr[a] + (size_t)J0 * n + Jend;
+            for (int a = 0; a < na; ++a) hp[q + na + a] = Sptr[a] + (size_t)Jend * n + Jend;
+            q += 2 * (size_t)na;
+        }
+        outers.push_back(o);
+    }
+    *used = q;
+    KKT_HIP(hipMemcpyAsync(dp, hp, q * sizeof(double*), hipMemcpyHostToDevice, stream));
+    // ... then the launches
+    size_t si = 0;
+    for (const Outer& o : outers) {
+        for (; si < steps.size() && steps[si].j0 < o.Jend; ++si) {
+            const Step& st = steps[si];
+            if (st.nb == CHOL_NB)
+                hipLaunchKernelGGL(emi_chol_diag_mfma_b_kernel, dim3(na), dim3(64), 0, stream, d_tab, n, st.j0);
+            else
+                hipLaunchKernelGGL(emi_chol_diag_b_kernel, dim3(na), dim3(256), 0, stream, d_tab, n, st.j0, st.nb);
+            if (st.rest <= 0) continue;
+            hipLaunchKernelGGL(emi_chol_panel_mfma_b_kernel, dim3((st.rest + 63) / 64, na), dim3(64), 0, stream, d_tab, n, n, st.j0);
+            if (st.wc > 0)
+                KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_none, rocblas_operation_transpose, st.rest, st.wc, st.nb, &mone,
+                                             (const double* const*)(dp + st.at), n, (const double* const*)(dp + st.at), n, &one,
+                                             dp + st.at + na, n, na));
+        }
+        if (o.rest2 > 0)
+            KKT_RB(rocblas_dsyrk_batched(L->handle, rocblas_fill_lower, rocblas_operation_none, o.rest2, o.Jend - o.J0, &mone,
+                                         (const double* const*)(dp + o.at), n, &one, dp + o.at + na, n, na));
+    }
+    KKT_HIP(hipGetLastError());
+    return EMI_OK;
+}
+
+}  // namespace
+
+// n scenarios, one mesh.  pws[b]: the scenario's workspace slot (created here if empty); dD[b]: its context's differentiation matrix
+// on the device; Qblk / Jblk / fixed / dc as kkt_factor, per scenario (host pointers).  info[b]: 0 factorised (Schur path), > 0 singular,
+// -1: this scenario needs the single entry point (a node block not positive definite, or the regularisation ladder exhausted: the LU).
+int kkt_factor_batch(int n, KktWorkspace** const* pws, hipStream_t stream, const double* const* dD, int M, int ns, int nv,
+                     const double* const* Qblk, const double* const* Jblk, const unsigned char* const* fixed, const double* dc, int* info,
+                     std::string* err) {
+    if (n < 1 || nv > KKT_NV_MAX) { *err = "emi_kkt_factor_batch: bad batch"; return EMI_ERR_ARG; }
+    const int nh = nv * (nv + 1) / 2, nz = nv * M, md = ns * M, npairs = ns * (ns + 1) / 2;
+    std::vector<KktWorkspace*> W(n);
+    for (int b = 0; b < n; ++b) {
+        if (!*pws[b]) *pws[b] = new KktWorkspace();
+        KktWorkspace* w = W[b] = *pws[b];
+        w->factored = false;
+        w->lr_active = false;
+        w->linv_n = 0;
+        w->reg_dc_applied = dc[b];
+        w->reg_dw_applied = 0.0;
+        if (int st = ws_prepare(w, stream, dD[b], M, ns, nv, err)) return st;
+        KKT_HIP(hipMemcpyAsync(w->Q, Qblk[b], (size_t)nh * M * sizeof(double), hipMemcpyHostToDevice, stream));
+        KKT_HIP(hipMemcpyAsync(w->J, Jblk[b], (size_t)ns * nv * M * sizeof(double), hipMemcpyHostToDevice, stream));
+        KKT_HIP(hipMemcpyAsync(w->fixed, fixed[b], (size_t)nz, hipMemcpyHostToDevice, stream));
+        info[b] = -1;
+    }
+    KktWorkspace* L = W[0];
+    KKT_RB(rocblas_set_stream(L->handle, stream));
+    // scratch: table, pointer arrays (S build: A, B, one C array per state pair; Cholesky: two arrays per step and per outer panel;
+    // block inverses: two arrays per diagonal block), status words
+    const int nsteps = (md + CHOL_NB - 1) / CHOL_NB, nblk = (md + TRSV_NB - 1) / TRSV_NB;
+    const size_t ptr_count = (size_t)n * (2 + npairs + 2 * (nsteps + nsteps / 2 + 2) + 2 * nblk + 8);
+    const size_t tab_bytes = (size_t)n * sizeof(KktDev), ptr_bytes = ptr_count * sizeof(double*), stat_bytes = (size_t)2 * n * sizeof(int);
+    if (int st = batch_scratch(L, tab_bytes, ptr_bytes, stat_bytes, err)) return st;
+    KktDev* h_tab = reinterpret_cast<KktDev*>(L->b_pin);
+    double** h_ptr = reinterpret_cast<double**>(L->b_pin + tab_bytes);
+    int* h_stat = reinterpret_cast<int*>(L->b_pin + tab_bytes + ptr_bytes);
+    KktDev* d_tab = reinterpret_cast<KktDev*>(L->b_tab);
+
+    static const double LV_DC[5] = {1.0, 1e3, 1e3, 1e3, 1e6}, LV_DW[5] = {0.0, 0.0, 1e-7, 1e-5, 1e-3};       // the ladder of kkt_factor
+    constexpr int NLV = 5;
+    const int max_lv = g_tune.primal_levels.load() ? NLV : 2;
+    std::vector<int> level(n), first(n);
+    std::vector<char> done(n, 0);
+    for (int b = 0; b < n; ++b) {
+        KktWorkspace* w = W[b];
+        if (w->reg_M != M || w->reg_ns != ns || w->reg_nv != nv || !g_tune.sticky_reg.load()) {
+            w->reg_level = w->reg_hits = 0;
+            w->reg_M = M; w->reg_ns = ns; w->reg_nv = nv;
+        } else if (w->reg_level > 0 && w->reg_hits >= 4) {
+            --w->reg_level;
+            w->reg_hits = 0;
+        }
+        level[b] = first[b] = std::min(w->reg_level, max_lv - 1);
+    }
+    const unsigned nb2 = (unsigned)(((size_t)M * M + 255) / 256);
+    const double one = 1.0, zero = 0.0;
+    std::vector<int> act;
+    std::vector<double*> Sptr(n);
+    for (int round = 0; round < NLV + 1; ++round) {
+        act.clear();
+        for (int b = 0; b < n; ++b)
+            if (!done[b]) act.push_back(b);
+        const int na = (int)act.size();
+        if (na == 0) break;
+        for (int a = 0; a < na; ++a) {
+            KktWorkspace* w = W[act[a]];
+            const double dc_base = dc[act[a]] > 1e-9 ? dc[act[a]] : 1e-9;
+            KktDev t{};
+            t.Q = w->Q; t.J = w->J; t.Pinv = w->Pinv; t.G = w->G; t.Rk = w->Rk; t.S = w->S; t.W = w->W; t.chol_blk = w->chol_blk;
+            t.Doff = L->Doff;                       // one copy of the operand for the whole batch (same mesh: same matrix)
+            t.fixed = w->fixed;
+            t.info = L->b_stat + a;
+            t.flag = L->b_stat + na + a;
+            t.dw = LV_DW[level[act[a]]];
+            t.dc = dc_base * LV_DC[level[act[a]]];
+            h_tab[a] = t;
+            Sptr[a] = w->S;
+        }
+        // pointer arrays of the S build
+        size_t q = 0;
+        const size_t at_A = q;  for (int a = 0; a < na; ++a) h_ptr[q++] = L->Doff;
+        const size_t at_B = q;  for (int a = 0; a < na; ++a) h_ptr[q++] = W[act[a]]->W;
+        const size_t at_C = q;
+        for (int i = 0; i < ns; ++i)
+            for (int ip = 0; ip <= i; ++ip)
+                for (int a = 0; a < na; ++a) h_ptr[q++] = W[act[a]]->S + ((size_t)ip * M) * md + (size_t)i * M;
+        KKT_HIP(hipMemcpyAsync(d_tab, h_tab, (size_t)na * sizeof(KktDev), hipMemcpyHostToDevice, stream));
+        KKT_HIP(hipMemcpyAsync(L->b_ptrs, h_ptr, q * sizeof(double*), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(emi_kkt_zero_status_b_kernel, dim3((na + 63) / 64), dim3(64), 0, stream, (const KktDev*)d_tab, na);
+        if (ns == 6 && nv == 8)
+            hipLaunchKernelGGL((emi_kkt_node_inverse_fixed_b_kernel<6, 8>), dim3((M + 63) / 64, na), dim3(64), 0, stream, (const KktDev*)d_tab, M);
+        else if (ns == 2 && nv == 4)
+            hipLaunchKernelGGL((emi_kkt_node_inverse_fixed_b_kernel<2, 4>), dim3((M + 63) / 64, na), dim3(64), 0, stream, (const KktDev*)d_tab, M);
+        else
+            hipLaunchKernelGGL(emi_kkt_node_inverse_b_kernel, dim3((M + 63) / 64, na), dim3(64), 0, stream, (const KktDev*)d_tab, M, ns, nv);
+        KKT_HIP(hipGetLastError());
+        for (int i = 0, p = 0; i < ns; ++i)
+            for (int ip = 0; ip <= i; ++ip, ++p) {
+                hipLaunchKernelGGL(emi_kkt_scale_b_kernel, dim3(nb2, na), dim3(256), 0, stream, (const KktDev*)d_tab, M, (i * nv + ip) * M);
+                KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &one,
+                                             (const double* const*)(L->b_ptrs + at_A), M, (const double* const*)(L->b_ptrs + at_B), M, &zero,
+                                             L->b_ptrs + at_C + (size_t)p * na, (rocblas_int)md, na));
+                hipLaunchKernelGGL(emi_kkt_sblock_terms_b_kernel, dim3(nb2, na), dim3(256), 0, stream, (const KktDev*)d_tab, M, ns, i, ip);
+            }
+        KKT_HIP(hipGetLastError());
+        size_t used = 0;
+        if (int st = chol_batched(L, stream, d_tab, na, Sptr.data(), md, h_ptr + q, L->b_ptrs + q, &used, err)) return st;
+        KKT_HIP(hipMemcpyAsync(h_stat, L->b_stat, (size_t)2 * na * sizeof(int), hipMemcpyDeviceToHost, stream));
+        KKT_HIP(hipStreamSynchronize(stream));
+        for (int a = 0; a < na; ++a) {
+            const int b = act[a], hinfo = h_stat[a], hflag = h_stat[na + a];
+            KktWorkspace* w = W[b];
+            if (hinfo == 0 && hflag == 0) {
+                done[b] = 1;
+                info[b] = 0;
+                if (level[b] == first[b]) ++w->reg_hits; else { w->reg_level = level[b]; w->reg_hits = 0; }
+                w->reg_dc_applied = h_tab[a].dc;
+                w->reg_dw_applied = h_tab[a].dw;
+                w->factored = true;
+                w->method_used = 1;
+            } else if (hflag != 0 || level[b] + 1 >= max_lv) {
+                done[b] = 1;                        // not the quasi-definite case, or no level helps: the single path (and its LU) decides
+                info[b] = -1;
+                if (hflag == 0) { w->reg_level = max_lv - 1; w->reg_hits = 0; }
+                if (g_tune.debug.load())
+                    fprintf(stderr, "emi_kkt_factor_batch: scenario %d of %d leaves the batch (block flag %d, potrf info %d, M %d)\n", b, n, hflag, hinfo, M);
+            } else {
+                if (g_tune.debug.load())
+                    fprintf(stderr, "emi_kkt_factor_batch: S not positive definite at %d (scenario %d, dual regularisation %.1e, primal %.1e, M %d), retrying\n",
+                            hinfo, b, h_tab[a].dc, h_tab[a].dw, M);
+                ++level[b];
+            }
+        }
+    }
+    // block inverses for the single-right-hand-side solves of everything that was factorised
+    if (g_tune.block_trsv.load() && md >= 2 * TRSV_NB) {
+        act.clear();
+        for (int b = 0; b < n; ++b)
+            if (info[b] == 0) act.push_back(b);
+        const int na = (int)act.size();
+        if (na > 0) {
+            const int full = md / TRSV_NB, tail = md - full * TRSV_NB;
+            size_t q = 0;
+            for (int a = 0; a < na; ++a) {
+                KktWorkspace* w = W[act[a]];
+                KKT_ENSURE(w->Linv, w->cap_Linv, (size_t)nblk * TRSV_NB * TRSV_NB * sizeof(double));
+                KKT_ENSURE(w->LinvT, w->cap_LinvT, (size_t)nblk * TRSV_NB * TRSV_NB * sizeof(double));
+                KKT_HIP(hipMemsetAsync(w->Linv, 0, (size_t)nblk * TRSV_NB * TRSV_NB * sizeof(double), stream));
+                KktDev t{};
+                t.Linv = w->Linv;
+                t.LinvT = w->LinvT;
+                h_tab[a] = t;
+            }
+            const size_t at_LA = q;
+            for (int j = 0; j < full; ++j)
+                for (int a = 0; a < na; ++a) h_ptr[q++] = W[act[a]]->S + (size_t)j * TRSV_NB * ((size_t)md + 1);
+            const size_t at_LI = q;
+            for (int j = 0; j < full; ++j)
+                for (int a = 0; a < na; ++a) h_ptr[q++] = W[act[a]]->Linv + (size_t)j * TRSV_NB * TRSV_NB;
+            const size_t at_TA = q;
+            for (int a = 0; a < na; ++a) h_ptr[q++] = W[act[a]]->S + (size_t)full * TRSV_NB * ((size_t)md + 1);
+            const size_t at_TI = q;
+            for (int a = 0; a < na; ++a) h_ptr[q++] = W[act[a]]->Linv + (size_t)full * TRSV_NB * TRSV_NB;
+            KKT_HIP(hipMemcpyAsync(d_tab, h_tab, (size_t)na * sizeof(KktDev), hipMemcpyHostToDevice, stream));
+            KKT_HIP(hipMemcpyAsync(L->b_ptrs, h_ptr, q * sizeof(double*), hipMemcpyHostToDevice, stream));
+            if (full > 0)
+                KKT_RB(rocblas_dtrtri_batched(L->handle, rocblas_fill_lower, rocblas_diagonal_non_unit, TRSV_NB,
+                                              (const double* const*)(L->b_ptrs + at_LA), md, L->b_ptrs + at_LI, TRSV_NB, full * na));
+            if (tail > 0)
+                KKT_RB(rocblas_dtrtri_batched(L->handle, rocblas_fill_lower, rocblas_diagonal_non_unit, tail,
+                                              (const double* const*)(L->b_ptrs + at_TA), md, L->b_ptrs + at_TI, TRSV_NB, na));
+            hipLaunchKernelGGL(emi_trsv_transpose_b_kernel, dim3(TRSV_NB / 32, TRSV_NB / 32, nblk * na), dim3(256), 0, stream, (const KktDev*)d_tab, nblk);
+            KKT_HIP(hipGetLastError());
+            KKT_HIP(hipStreamSynchronize(stream));          // (the pinned table is reused by the next call)
+            for (int a = 0; a < na; ++a) W[act[a]]->linv_n = md;
+        }
+    }
+    return EMI_OK;
+}
+
+// One right-hand side per scenario, all factorised on the same mesh (Schur path): rhs[b] [N] host, in place.  Scenarios with an active
+// low-rank correction get their Woodbury term after the common part.
+int kkt_solve_batch(int n, KktWorkspace* const* ws, hipStream_t stream, int nz, double* const* rhs, std::string* err) {
+    if (n < 1) { *err = "emi_kkt_solve_batch: empty batch"; return EMI_ERR_ARG; }
+    KktWorkspace* L = ws[0];
+    const int M = L->M, ns = L->ns, nv = L->nv, N = L->N, md = ns * M;
+    for (int b = 0; b < n; ++b) {
+        KktWorkspace* w = ws[b];
+        if (!w || !w->factored || w->method_used != 1 || w->M != M || w->ns != ns || w->nv != nv || w->N != N) {
+            *err = "emi_kkt_solve_batch: every scenario must hold a Schur factorisation on the same mesh";
+            return EMI_ERR_STATE;
+        }
+        if (w->rhs_elems < (size_t)N) {
+            if (w->rhs) KKT_HIP(hipFree(w->rhs));
+            w->rhs = nullptr; w->rhs_elems = 0;
+            KKT_HIP(hipMalloc(&w->rhs, (size_t)N * sizeof(double)));
+            w->rhs_elems = (size_t)N;
+        }
+        if (w->T_elems < (size_t)nz) {
+            if (w->T) KKT_HIP(hipFree(w->T));
+            w->T = nullptr; w->T_elems = 0;
+            KKT_HIP(hipMalloc(&w->T, (size_t)nz * sizeof(double)));
+            w->T_elems = (size_t)nz;
+        }
+        if (w->Cb_elems < (size_t)md) {
+            if (w->Cb) KKT_HIP(hipFree(w->Cb));
+            w->Cb = nullptr; w->Cb_elems = 0;
+            KKT_HIP(hipMalloc(&w->Cb, (size_t)md * sizeof(double)));
+            w->Cb_elems = (size_t)md;
+        }
+        KKT_ENSURE(w->trsv_y, w->cap_trsv_y, (size_t)md * sizeof(double));
+        KKT_HIP(hipMemcpyAsync(w->rhs, rhs[b], (size_t)N * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
+    KKT_RB(rocblas_set_stream(L->handle, stream));
+    bool blk = true;
+    for (int b = 0; b < n; ++b) blk = blk && ws[b]->linv_n == md;
+    const int nblk = (md + TRSV_NB - 1) / TRSV_NB;
+    const size_t ptr_count = (size_t)n * (6 + (blk ? 6 * nblk : 0));
+    const size_t tab_bytes = (size_t)n * sizeof(KktDev), ptr_bytes = ptr_count * sizeof(double*), stat_bytes = (size_t)2 * n * sizeof(int);
+    if (int st = batch_scratch(L, tab_bytes, ptr_bytes, stat_bytes, err)) return st;
+    KktDev* h_tab = reinterpret_cast<KktDev*>(L->b_pin);
+    double** h_ptr = reinterpret_cast<double**>(L->b_pin + tab_bytes);
+    KktDev* d_tab = reinterpret_cast<KktDev*>(L->b_tab);
+    for (int b = 0; b < n; ++b) {
+        KktWorkspace* w = ws[b];
+        KktDev t{};
+        t.J = w->J; t.Pinv = w->Pinv; t.S = w->S; t.Linv = w->Linv; t.LinvT = w->LinvT; t.T = w->T; t.Cb = w->Cb; t.rhs = w->rhs; t.y = w->trsv_y;
+        t.fixed = w->fixed;
+        t.Doff = L->Doff;
+        h_tab[b] = t;
+    }
+    size_t q = 0;
+    auto arr = [&](auto f) { const size_t at = q; for (int b = 0; b < n; ++b) h_ptr[q++] = f(ws[b]); return at; };
+    const size_t at_D = arr([&](KktWorkspace*) { return L->Doff; });
+    const size_t at_T = arr([](KktWorkspace* w) { return w->T; });
+    const size_t at_Cb = arr([](KktWorkspace* w) { return w->Cb; });
+    const size_t at_X = arr([](KktWorkspace* w) { return w->rhs; });
+    const size_t at_S = arr([](KktWorkspace* w) { return w->S; });
+    const size_t at_Y = arr([](KktWorkspace* w) { return w->trsv_y; });
+    std::vector<size_t> at_LT(nblk), at_LI(nblk), at_xj(nblk), at_yj(nblk), at_Sr(nblk);
+    if (blk)
+        for (int j = 0; j < nblk; ++j) {
+            const size_t j0 = (size_t)j * TRSV_NB;
+            at_LT[j] = arr([&](KktWorkspace* w) { return w->LinvT + (size_t)j * TRSV_NB * TRSV_NB; });
+            at_LI[j] = arr([&](KktWorkspace* w) { return w->Linv + (size_t)j * TRSV_NB * TRSV_NB; });
+            at_xj[j] = arr([&](KktWorkspace* w) { return w->Cb + j0; });
+            at_yj[j] = arr([&](KktWorkspace* w) { return w->trsv_y + j0; });
+            at_Sr[j] = arr([&](KktWorkspace* w) { return w->S + j0; });
+        }
+    KKT_HIP(hipMemcpyAsync(d_tab, h_tab, (size_t)n * sizeof(KktDev), hipMemcpyHostToDevice, stream));
+    KKT_HIP(hipMemcpyAsync(L->b_ptrs, h_ptr, q * sizeof(double*), hipMemcpyHostToDevice, stream));
+    double** P = L->b_ptrs;
+    const double one = 1.0, zero = 0.0, mone = -1.0;
+    dim3 gk((M + 127) / 128, n), bk(128);
+    hipLaunchKernelGGL(emi_kkt_mask_rhs_b_kernel, dim3((nz + 255) / 256, n), dim3(256), 0, stream, (const KktDev*)d_tab, nz, N);
+    hipLaunchKernelGGL(emi_kkt_apply_p_b_kernel, gk, bk, 0, stream, (const KktDev*)d_tab, M, nv, 0);           // t = P a
+    KKT_HIP(hipGetLastError());
+    KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_transpose, rocblas_operation_none, M, ns, M, &one, (const double* const*)(P + at_D), M,
+                                 (const double* const*)(P + at_T), M, &zero, P + at_Cb, M, n));                 // Cb = Doff t_states
+    hipLaunchKernelGGL(emi_kkt_jnode_minus_b_b_kernel, gk, bk, 0, stream, (const KktDev*)d_tab, M, ns, nv);    // Cb += J_node t - b
+    KKT_HIP(hipGetLastError());
+    if (blk) {                                          // lambda = S^-1 Cb through the block inverses (blk_potrs, gemv form)
+        for (int j = 0; j < nblk; ++j) {
+            const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, md - j0), rest = md - j0 - bs;
+            KKT_RB(rocblas_dgemv_batched(L->handle, rocblas_operation_transpose, bs, bs, &one, (const double* const*)(P + at_LT[j]), TRSV_NB,
+                                         (const double* const*)(P + at_xj[j]), 1, &zero, P + at_yj[j], 1, n));
+            if (rest > 0)
+                hipLaunchKernelGGL(emi_trsv_update_b_kernel, dim3((rest + 63) / 64, n), dim3(256), 0, stream, (const KktDev*)d_tab, md, j0, bs, rest);
+        }
+        for (int j = nblk - 1; j >= 0; --j) {
+            const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, md - j0);
+            KKT_RB(rocblas_dgemv_batched(L->handle, rocblas_operation_transpose, bs, bs, &one, (const double* const*)(P + at_LI[j]), TRSV_NB,
+                                         (const double* const*)(P + at_yj[j]), 1, &zero, P + at_xj[j], 1, n));
+            if (j0 > 0)
+                KKT_RB(rocblas_dgemv_batched(L->handle, rocblas_operation_transpose, bs, j0, &mone, (const double* const*)(P + at_Sr[j]), md,
+                                             (const double* const*)(P + at_xj[j]), 1, &one, P + at_Y, 1, n));
+        }
+        KKT_HIP(hipGetLastError());
+    } else {
+        KKT_RB(rocsolver_dpotrs_batched(L->handle, rocblas_fill_lower, md, 1, P + at_S, md, P + at_Cb, md, n));
+    }
+    KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_none, rocblas_operation_none, M, ns, M, &mone, (const double* const*)(P + at_D), M,
+                                 (const double* const*)(P + at_Cb), M, &one, P + at_X, M, n));                  // y = a - J^T lambda ...
+    hipLaunchKernelGGL(emi_kkt_jnode_t_b_kernel, gk, bk, 0, stream, (const KktDev*)d_tab, M, ns, nv);
+    hipLaunchKernelGGL(emi_kkt_apply_p_b_kernel, gk, bk, 0, stream, (const KktDev*)d_tab, M, nv, 1);           // ... x = P y
+    hipLaunchKernelGGL(emi_kkt_finish_solve_b_kernel, dim3((N + 255) / 256, n), dim3(256), 0, stream, (const KktDev*)d_tab, nz, md);
+    KKT_HIP(hipGetLastError());
+    for (int b = 0; b < n; ++b) {
+        KktWorkspace* w = ws[b];
+        if (w->lr_active) {             // x <- x + Y C^-1 (U^T x), with the scenario's own handle on this stream
+            const int r = w->lr_r;
+            KKT_RB(rocblas_set_stream(w->handle, stream));
+            hipLaunchKernelGGL(emi_kkt_lr_utx_kernel, dim3((r + 63) / 64, 1), dim3(64), 0, stream, w->lrT, w->rhs, w->lr_node, w->lr_vec, r, N, M, nv);
+            KKT_HIP(hipGetLastError());
+            KKT_RB(rocsolver_dpotrs(w->handle, rocblas_fill_lower, r, 1, w->lrC, r, w->lrT, r));
+            KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_none, N, r, &one, w->lrY, N, w->lrT, 1, &one, w->rhs, 1));
+        }
+        KKT_HIP(hipMemcpyAsync(rhs[b], w->rhs, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, stream));
+    }
     KKT_HIP(hipStreamSynchronize(stream));
     return EMI_OK;
 #undef KKT_ENSURE

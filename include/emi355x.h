@@ -237,6 +237,24 @@ int emi_kkt_factor(emi_ctx_t ctx, const double* Qblk, const double* Jblk,
  * solutions of K (Woodbury), else of K~.  r = 0 clears the correction.       */
 int emi_kkt_lowrank(emi_ctx_t ctx, int r, const int* node, const double* vec,
                     const double* delta, int* exact);
+/* The Newton steps of n scenarios at once: ctxs[b] are n DIFFERENT contexts on one
+ * device with the same mesh size and model dimensions (one scenario of a
+ * Monte-Carlo batch each, BASELINE configs[3]); arguments per scenario as the
+ * single entry points take them (host pointers).  Every launch of the
+ * factorisation then carries the whole batch -- the 96-step dependency chain of a
+ * 1024-node Cholesky is paid once per batch instead of once per scenario -- on
+ * ctxs[0]'s stream; each context keeps its own factors, so emi_kkt_lowrank /
+ * emi_kkt_solve / emi_kkt_solve_batch may follow in any grouping.  A scenario
+ * the batch cannot take (a node block that is not positive definite, or one
+ * whose regularisation ladder is exhausted) is factorised through
+ * emi_kkt_factor inside the call.  info[b] as emi_kkt_factor's.  What IPOPT does
+ * once per scenario behind ePSOPT (reference src/ePSOPT/ePSOPT.cpp:62-66, 84).     */
+int emi_kkt_factor_batch(int n, const emi_ctx_t* ctxs, const double* const* Qblk,
+                         const double* const* Jblk, const unsigned char* const* fixed,
+                         const double* dc, int* info);
+/* one right-hand side [N] per scenario, in place (host pointers); low-rank
+ * corrections of the scenarios that hold one are applied                          */
+int emi_kkt_solve_batch(int n, const emi_ctx_t* ctxs, double* const* rhs);
 /* What the last emi_kkt_factor really factorised: [[Q + dw I_x, J^T], [J, -dc I]]
  * with dw on the diagonal of the free STATE variables.  dc >= the caller's and
  * dw >= 0; they exceed the nominal (dc, 0) when the Schur path had to climb its

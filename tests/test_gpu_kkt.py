@@ -341,3 +341,100 @@ def test_concurrent_contexts_give_reproducible_factorisations(built):
     assert not bad, bad[:5]
     for tid in range(1, nthreads):           # and the threads agree with each other
         assert firsts[tid][0] == firsts[0][0] and np.array_equal(firsts[tid][1], firsts[0][1])
+
+
+def _random_kkt(ev, M, ns, nv, rng, weak_nodes=0):
+    nh = nv * (nv + 1) // 2
+    Qblk = np.zeros((nh, M))
+    for k in range(M):
+        A = rng.standard_normal((nv, nv))
+        Qk = A @ A.T + nv * np.eye(nv)
+        for v in range(nv):
+            for q in range(v + 1):
+                Qblk[v * (v + 1) // 2 + q, k] = Qk[v, q]
+    Jblk = rng.standard_normal((ns * nv, M))
+    for i in range(ns):
+        Jblk[i * nv + i] += np.diag(ev.D)
+    fixed = np.zeros(nv * M, dtype=np.uint8)
+    fixed[np.arange(ns) * M] = 1
+    return Qblk, Jblk, fixed
+
+
+@pytest.mark.parametrize("M,model,n", [(33, 1, 5), (65, 1, 3), (171, 1, 4), (256, 1, 6), (9, 0, 2), (1024, 1, 3)])
+def test_batched_factor_and_solve_match_numpy_and_the_single_path(built, M, model, n):
+    """emi_kkt_factor_batch / emi_kkt_solve_batch: n scenarios (n contexts) on one mesh, every launch of the factorisation carrying
+    the whole batch (pointer-table kernels + rocBLAS *_batched).  Each scenario's solution must solve ITS matrix (numpy, backward
+    error) and agree with what the single entry points return for the same matrix; low-rank corrections of individual scenarios
+    survive the batched solve; a scenario with an indefinite node block leaves the batch through the single path (LU) inside the
+    call.  Meshes: one-level sizes with a partial last Cholesky block (33, 65, 171 nodes), block-inverse solves with a partial last
+    block (171, 256), the 1024-node shape of config 4 (96 full steps, 8 outer panels, 12 diagonal blocks)."""
+    import ctypes as C
+    import etol_amd as E
+    from etol_amd import _lib as L
+    from etol_amd import workloads as W
+    lib = L.load()
+    ns, nc, _ = E.model_dims(model)
+    nv, N = ns + nc, (2 * ns + nc) * M
+    rng = np.random.default_rng(7000 + M + n)
+    evs = []
+    for b in range(n):
+        ev = E.Evaluator(0)
+        ev.set_mesh(M, 0.0, 4.0)
+        ev.set_model(model, W.QUAD_PARAMS if model == 1 else [])
+        ev.set_batch(1)
+        evs.append(ev)
+    probs = [_random_kkt(evs[0], M, ns, nv, rng) for _ in range(n)]
+    bad = n - 1 if n >= 4 else -1                  # one scenario whose node block 3 is indefinite: not the quasi-definite case
+    if bad >= 0:
+        Q = probs[bad][0]
+        Q[0, min(3, M - 1)] = -5.0
+    dc = np.full(n, 1e-9)
+    D = C.POINTER(C.c_double)
+    dp = lambda a: a.ctypes.data_as(D)
+    ctxs = (C.c_void_p * n)(*[ev.ctx for ev in evs])
+    Qp = (D * n)(*[dp(p[0]) for p in probs])
+    Jp = (D * n)(*[dp(p[1]) for p in probs])
+    Fp = (C.POINTER(C.c_ubyte) * n)(*[p[2].ctypes.data_as(C.POINTER(C.c_ubyte)) for p in probs])
+    info = np.full(n, -7, dtype=np.int32)
+    st = lib.emi_kkt_factor_batch(n, ctxs, Qp, Jp, Fp, dp(dc), info.ctypes.data_as(C.POINTER(C.c_int)))
+    assert st == 0, lib.emi_last_error(evs[0].ctx)
+    assert np.all(info == 0), info
+    Ks = [dense_kkt(evs[0].D, p[0], p[1], p[2], 1e-9, M, ns, nv) for p in probs] if M <= 256 else None
+    # a low-rank correction on scenario 1 (as the interior-point iteration adds after reflecting a node block): K = K~ - d u u^T
+    lr = None
+    if M <= 256 and n >= 3:
+        node, vec, delta = np.array([M // 2], dtype=np.int32), rng.standard_normal((1, nv)) * 0.3, np.array([0.7])
+        lr = (node, vec, delta, evs[1].kkt_lowrank(node, vec, delta))
+    for rep in range(2):                          # one factorisation, several batched solves
+        rhs = [rng.standard_normal(N) for _ in range(n)]
+        work = [r.copy() for r in rhs]
+        Rp = (D * n)(*[dp(w) for w in work])
+        assert lib.emi_kkt_solve_batch(n, ctxs, Rp) == 0, lib.emi_last_error(evs[0].ctx)
+        for b in range(n):
+            single = evs[b].kkt_solve(rhs[b])     # the same factors through the single entry point
+            scale = np.abs(single).max() + 1
+            assert np.abs(work[b] - single).max() < 1e-9 * scale, (b, np.abs(work[b] - single).max())
+            if Ks is not None:
+                K = Ks[b].copy()
+                if lr is not None and b == 1 and lr[3]:
+                    u = np.zeros(N)
+                    u[np.arange(nv) * M + lr[0][0]] = lr[1][0]
+                    u[np.nonzero(probs[b][2])[0]] = 0
+                    K -= lr[2][0] * np.outer(u, u)
+                ref = rhs[b].copy()
+                ref[np.nonzero(probs[b][2])[0]] = 0
+                assert np.abs(K @ work[b] - ref).max() < 1e-9 * (np.abs(K).max() * np.abs(work[b]).max() + 1), b
+    # the batch against factorisations made one by one (fresh contexts): same solutions to rounding
+    for b in range(min(n, 2)):
+        ev = E.Evaluator(0)
+        ev.set_mesh(M, 0.0, 4.0)
+        ev.set_model(model, W.QUAD_PARAMS if model == 1 else [])
+        ev.set_batch(1)
+        if b == 1 and lr is not None:
+            continue
+        assert ev.kkt_factor(probs[b][0], probs[b][1], probs[b][2], 1e-9) == 0
+        x1 = ev.kkt_solve(rhs[b])
+        assert np.abs(x1 - work[b]).max() < 1e-8 * (np.abs(x1).max() + 1)
+        ev.close()
+    for ev in evs:
+        ev.close()
