@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -139,7 +140,7 @@ void comm_file_done(int rank) {
     if (rank == 0 && !getenv("EMI_COMM_FILE_KEEP")) unlink(comm_file_path().c_str());
 }
 
-Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
+Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced, const std::shared_ptr<mx::KktBatcher>& batcher = nullptr) {
     Result R;
     R.scenario = s;
     const auto t0 = std::chrono::steady_clock::now();
@@ -194,6 +195,7 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced) {
     if (getenv("EMI_MC_MU_RESTART")) solver.getAlgorithm()->mu_restart = atof(getenv("EMI_MC_MU_RESTART"));
     if (getenv("EMI_MC_WARM_PUSH")) solver.getAlgorithm()->warm_bound_push = atof(getenv("EMI_MC_WARM_PUSH"));
     solver.getAlgorithm()->print_level = env_int("EMI_MC_PRINT_LEVEL", 0);
+    solver.getAlgorithm()->kkt_batcher = batcher;          // the Newton steps of every scenario in flight share their launches
     t->solve();
     const mx::Sol* sol = solver.getSolution();
     R.rc = sol->error_flag;
@@ -248,15 +250,31 @@ int main(int argc, char** argv) {
     }
     std::vector<Result> results(hi - lo);
     std::atomic<int> next(lo);
+    // EMI_MC_BATCH = g > 0: the worker threads form g groups, each sharing a KktBatcher -- the factorisations and solves of a
+    // group's scenarios go out as batched launches (emi_kkt_factor_batch); while one group's batch runs on the device the other
+    // groups do their host work.  0: every thread launches for itself (the round-3 form).
+    const int groups = std::max(0, std::min(env_int("EMI_MC_BATCH", 0), nthreads));
+    std::vector<std::shared_ptr<mx::KktBatcher>> batchers;
+    for (int g = 0; g < groups; ++g) {
+        batchers.push_back(std::make_shared<mx::KktBatcher>());
+        batchers.back()->flush_us = env_int("EMI_MC_FLUSH_US", 300);
+    }
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
     for (int th = 0; th < nthreads; ++th)
-        pool.emplace_back([&] {
-            for (int s = next++; s < hi; s = next++) results[s - lo] = solve_scenario(s, nsteps, ndiscs, device, traced);
+        pool.emplace_back([&, th] {
+            const std::shared_ptr<mx::KktBatcher> mine = groups > 0 ? batchers[th % groups] : nullptr;
+            {
+                mx::KktBatcher::Member member(mine);
+                for (int s = next++; s < hi; s = next++) results[s - lo] = solve_scenario(s, nsteps, ndiscs, device, traced, mine);
+            }
             ETOL::eMI355X::releaseDevices();     // this thread's idle device contexts
         });
     for (auto& th : pool) th.join();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (size_t g = 0; g < batchers.size(); ++g)
+        printf("batcher %zu: %ld factor calls carrying %ld factorisations, %ld solve calls carrying %ld solves, largest batch %d\n", g,
+               batchers[g]->factor_calls, batchers[g]->factor_items, batchers[g]->solve_calls, batchers[g]->solve_items, batchers[g]->largest_batch);
 
     int ok = 0;
     double iters = 0;
@@ -267,8 +285,8 @@ int main(int argc, char** argv) {
         iters += r.iterations;
     }
     printf("{\"rank\": %d, \"world\": %d, \"scenarios\": %d, \"solved\": %d, \"nodes\": %d, \"keepouts\": %d, \"threads\": %d, "
-           "\"model\": \"%s\", \"wall_s\": %.3f, \"solves_per_s\": %.3f, \"mean_iterations\": %.1f}\n",
-           rank, world, hi - lo, ok, nsteps + 1, ndiscs, nthreads, traced ? "traced" : "built-in", wall,
+           "\"model\": \"%s\", \"kkt_batch_groups\": %d, \"wall_s\": %.3f, \"solves_per_s\": %.3f, \"mean_iterations\": %.1f}\n",
+           rank, world, hi - lo, ok, nsteps + 1, ndiscs, nthreads, traced ? "traced" : "built-in", groups, wall,
            (hi - lo) / wall, results.empty() ? 0.0 : iters / results.size());
 
     // ---- the one collective: every rank's trajectories to rank 0 over RCCL ------------------------------

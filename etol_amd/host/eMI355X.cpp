@@ -8,10 +8,13 @@
 #include <ETOL/eMI355X.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <mutex>
 
 #include "emi_nlp.hpp"
 #include "emi_transcribe.hpp"
@@ -92,6 +95,7 @@ PathBlock track_rows(const std::list<track_t>& tracks, const Symbol& sx, const S
 struct eMI355X::Device : public mi355x::NlpEvaluator, public mi355x::KktBackend {
     emi_ctx_t ctx = nullptr;
     int device_id = -1;
+    int nodes = 0;                       // mesh size the context holds (configureDevice)
     std::string installed_source;        // text of the traced model whose code object is loaded in ctx ("" = none)
     bool installed_maximize = false;     // ... and the objective sign it was installed with
     ~Device() override {
@@ -119,6 +123,139 @@ struct eMI355X::Device : public mi355x::NlpEvaluator, public mi355x::KktBackend 
     int solve(double* rhs, int nrhs) override { return emi_kkt_solve(ctx, rhs, nrhs) == EMI_OK ? 0 : -1; }
     void applied_regularisation(double* dc, double* dw) override { (void)emi_kkt_last_regularisation(ctx, dc, dw); }
     std::string last_error() const override { return ctx ? emi_last_error(ctx) : "no device context"; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// KktBatcher: the rendezvous (see include/ETOL/eMI355X.hpp)
+// ---------------------------------------------------------------------------------------------
+namespace mi355x {
+
+struct KktBatcher::Impl {
+    struct Req {
+        int op = 0;                                 // 0 factor, 1 solve (one right-hand side)
+        emi_ctx_t ctx = nullptr;
+        int nodes = 0;
+        const double *Q = nullptr, *J = nullptr;
+        const unsigned char* fixed = nullptr;
+        double dc = 0;
+        double* rhs = nullptr;
+        int result = -1;
+        bool done = false;
+        std::chrono::steady_clock::time_point posted;
+    };
+    std::mutex m;
+    std::condition_variable cv;
+    int members = 0;
+    bool leading = false;
+    std::vector<Req*> pending;
+};
+
+KktBatcher::KktBatcher() : impl(new Impl()) {}
+KktBatcher::~KktBatcher() { delete impl; }
+KktBatcher::Member::Member(const std::shared_ptr<KktBatcher>& b) : batcher(b) {
+    if (!batcher) return;
+    std::lock_guard<std::mutex> lk(batcher->impl->m);
+    ++batcher->impl->members;
+}
+KktBatcher::Member::~Member() {
+    if (!batcher) return;
+    {
+        std::lock_guard<std::mutex> lk(batcher->impl->m);
+        --batcher->impl->members;
+    }
+    batcher->impl->cv.notify_all();                 // whoever waits for "everyone is here" counts again
+}
+
+// what has gathered, as batched calls: one per operation and mesh size
+static void run_batch(KktBatcher* B, std::vector<KktBatcher::Impl::Req*>& take) {
+    using Req = KktBatcher::Impl::Req;
+    std::sort(take.begin(), take.end(), [](const Req* a, const Req* b) { return a->op != b->op ? a->op < b->op : a->nodes < b->nodes; });
+    size_t i = 0;
+    while (i < take.size()) {
+        size_t j = i;
+        while (j < take.size() && take[j]->op == take[i]->op && take[j]->nodes == take[i]->nodes) ++j;
+        const int n = (int)(j - i);
+        std::vector<emi_ctx_t> ctxs(n);
+        for (int b = 0; b < n; ++b) ctxs[b] = take[i + b]->ctx;
+        if (take[i]->op == 0) {
+            std::vector<const double*> Q(n), J(n);
+            std::vector<const unsigned char*> fx(n);
+            std::vector<double> dc(n);
+            std::vector<int> info(n, -1);
+            for (int b = 0; b < n; ++b) { Q[b] = take[i + b]->Q; J[b] = take[i + b]->J; fx[b] = take[i + b]->fixed; dc[b] = take[i + b]->dc; }
+            const int st = n == 1 ? emi_kkt_factor(ctxs[0], Q[0], J[0], fx[0], dc[0], &info[0])
+                                  : emi_kkt_factor_batch(n, ctxs.data(), Q.data(), J.data(), fx.data(), dc.data(), info.data());
+            for (int b = 0; b < n; ++b) take[i + b]->result = st == EMI_OK ? info[b] : -1;
+            ++B->factor_calls;
+            B->factor_items += n;
+        } else {
+            std::vector<double*> rhs(n);
+            for (int b = 0; b < n; ++b) rhs[b] = take[i + b]->rhs;
+            const int st = n == 1 ? emi_kkt_solve(ctxs[0], rhs[0], 1) : emi_kkt_solve_batch(n, ctxs.data(), rhs.data());
+            for (int b = 0; b < n; ++b) take[i + b]->result = st == EMI_OK ? 0 : -1;
+            ++B->solve_calls;
+            B->solve_items += n;
+        }
+        B->largest_batch = std::max(B->largest_batch, n);
+        i = j;
+    }
+}
+
+static int submit(KktBatcher* B, KktBatcher::Impl::Req& r) {
+    KktBatcher::Impl* I = B->impl;
+    std::unique_lock<std::mutex> lk(I->m);
+    r.posted = std::chrono::steady_clock::now();
+    I->pending.push_back(&r);
+    I->cv.notify_all();
+    for (;;) {
+        if (r.done) return r.result;
+        if (!I->leading && !I->pending.empty()) {
+            const bool everyone = (int)I->pending.size() >= I->members;
+            const auto oldest = (*std::min_element(I->pending.begin(), I->pending.end(),
+                                                   [](const KktBatcher::Impl::Req* a, const KktBatcher::Impl::Req* b) { return a->posted < b->posted; }))->posted;
+            const bool stale = std::chrono::steady_clock::now() - oldest > std::chrono::microseconds(B->flush_us);
+            if (everyone || stale) {
+                I->leading = true;
+                std::vector<KktBatcher::Impl::Req*> take;
+                take.swap(I->pending);
+                lk.unlock();
+                run_batch(B, take);
+                lk.lock();
+                for (KktBatcher::Impl::Req* q : take) q->done = true;
+                I->leading = false;
+                I->cv.notify_all();
+                continue;
+            }
+        }
+        I->cv.wait_for(lk, std::chrono::microseconds(100));
+    }
+}
+}  // namespace mi355x
+
+// The device Newton step of a solver that shares a KktBatcher: factorisations and single-right-hand-side solves go to the
+// rendezvous, everything else (the low-rank correction with its many right-hand sides) straight to the solver's own context.
+struct BatchedKkt : public mi355x::KktBackend {
+    mi355x::KktBatcher* B;
+    mi355x::KktBackend* direct;          // the solver's own device adapter
+    emi_ctx_t ctx;
+    int nodes;
+    BatchedKkt(mi355x::KktBatcher* b, mi355x::KktBackend* d, emi_ctx_t c, int n) : B(b), direct(d), ctx(c), nodes(n) {}
+    int factor(const double* Qblk, const double* Jblk, const unsigned char* fixed, double dc) override {
+        mi355x::KktBatcher::Impl::Req r;
+        r.op = 0; r.ctx = ctx; r.nodes = nodes; r.Q = Qblk; r.J = Jblk; r.fixed = fixed; r.dc = dc;
+        return mi355x::submit(B, r);
+    }
+    int lowrank(int r, const int* node, const double* vec, const double* delta, bool* exact) override {
+        return direct->lowrank(r, node, vec, delta, exact);
+    }
+    int solve(double* rhs, int nrhs) override {
+        if (nrhs != 1) return direct->solve(rhs, nrhs);
+        mi355x::KktBatcher::Impl::Req r;
+        r.op = 1; r.ctx = ctx; r.nodes = nodes; r.rhs = rhs;
+        return mi355x::submit(B, r);
+    }
+    void applied_regularisation(double* dc, double* dw) override { direct->applied_regularisation(dc, dw); }
+    std::string last_error() const override { return direct->last_error(); }
 };
 
 namespace {
@@ -407,6 +544,7 @@ void eMI355X::configureDevice(Device* dev) {
     }
     emi_ctx_t c = dev->ctx;
     must(emi_set_mesh(c, (int)P.nodes, P.tau.data(), P.w.data(), P.D.data(), P.t0, P.tf), c, "emi_set_mesh");
+    dev->nodes = (int)P.nodes;
     if (P.model == EMI_MODEL_SOURCE) {
         // compiled for gfx950 once per context; meshes come and go.  The call also fixes the objective sign.
         if (dev->installed_source != P.model_source || dev->installed_maximize != isMaximized())
@@ -790,7 +928,9 @@ void eMI355X::solve() {
         const size_t kkt_rows = (2 * ns + nc) * P.nodes;
         const bool dev_kkt = !P.lifted && (_algorithm.linear_solver == "device" ||
                                            (_algorithm.linear_solver == "auto" && kkt_rows > 400));
-        nlp.kkt = dev_kkt ? static_cast<mi355x::KktBackend*>(_dev.get()) : nullptr;
+        BatchedKkt shared(_algorithm.kkt_batcher.get(), static_cast<mi355x::KktBackend*>(_dev.get()), _dev->ctx, _dev->nodes);
+        nlp.kkt = dev_kkt ? (_algorithm.kkt_batcher ? static_cast<mi355x::KktBackend*>(&shared) : static_cast<mi355x::KktBackend*>(_dev.get()))
+                          : nullptr;
         if (_algorithm.scaling == "automatic") nlp.vscale = mi355x::bound_scales(P);
         else if (_algorithm.scaling != "none") die("Alg::scaling must be \"automatic\" or \"none\"");
         _solution.linear_solver = dev_kkt ? "device: structured KKT factorisation (Schur complement + Cholesky), Woodbury-corrected" : "host LDL^T";

@@ -21,6 +21,29 @@ namespace ETOL {
 
 namespace mi355x {
 
+// Rendezvous of the Newton steps of CONCURRENT solves on one device (a Monte-Carlo batch: one host thread and one eMI355X per
+// scenario in flight, BASELINE configs[3]).  Solvers that share a batcher hand their factorisations and single-right-hand-side
+// solves to it instead of launching them themselves; whichever worker finds every member waiting (or has waited `flush_us`) runs
+// what has gathered as ONE batched call (emi_kkt_factor_batch / emi_kkt_solve_batch: every launch carries all scenarios of one mesh
+// size) and hands the answers back.  The iteration of each scenario is untouched -- same matrices, same steps, its own factors --
+// only the launches are shared.  A worker thread joins before its first solve() and leaves after its last (Member guard).
+class KktBatcher {
+ public:
+    KktBatcher();
+    ~KktBatcher();
+    struct Member {                                 // RAII membership of the calling thread
+        explicit Member(const std::shared_ptr<KktBatcher>& b);
+        ~Member();
+        std::shared_ptr<KktBatcher> batcher;
+    };
+    int flush_us = 300;                             // a request older than this is run with whatever has gathered
+    // totals, for reports: batched calls, scenarios they carried, largest batch
+    long factor_calls = 0, factor_items = 0, solve_calls = 0, solve_items = 0;
+    int largest_batch = 0;
+    struct Impl;
+    Impl* impl;                                     // (used by the device adapter in eMI355X.cpp)
+};
+
 // Algorithm knobs (the fields of PSOPT's Alg that ePSOPT::setup sets,
 // reference src/ePSOPT/ePSOPT.cpp:62-72, plus device selection).
 struct Alg {
@@ -60,6 +83,7 @@ struct Alg {
     double max_cpu_time = 1.e9;
     int print_level = 0;
     int device = 0;                                 // HIP device ordinal
+    std::shared_ptr<KktBatcher> kkt_batcher;        // set: the device Newton steps of this solver go through the shared rendezvous (above)
 };
 
 struct Sol {

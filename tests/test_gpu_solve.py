@@ -483,6 +483,35 @@ def test_montecarlo_example_shards_scenarios_over_ranks_and_threads(built):
     assert len(set(round(c, 3) for c in c_all.values())) > 1          # the scenarios really differ
 
 
+def test_montecarlo_with_shared_newton_steps_solves_the_same_scenarios(built):
+    """EMI_MC_BATCH: the worker threads share a KktBatcher -- their factorisations and single-right-hand-side solves go out as
+    batched launches (emi_kkt_factor_batch / emi_kkt_solve_batch).  The iteration of each scenario is the same algorithm on the same
+    matrices; only the factorisation's blocking differs (two-level form at every size, batched rocBLAS kernels), so every scenario
+    must be solved and end within 1e-6 relative of the cost its own-launch run reaches (129 nodes: device Newton step on every
+    mesh of the ladder above 33 nodes; 10 scenarios on 5 threads in 1 and in 2 groups)."""
+    exe = os.path.join(ROOT, "etol_amd", "lib", "etol_mi355x_montecarlo")
+
+    def run(threads, **extra):
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", EMI_MC_GATHER="0", **extra)
+        r = subprocess.run([exe, "10", "128", "8", str(threads)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines = r.stdout.strip().split("\n")
+        summary = json.loads([l for l in lines if "solves_per_s" in l][-1])
+        costs = {int(l.split()[1]): float(l.split()[l.split().index("cost") + 1]) for l in lines if l.startswith("scenario")}
+        batch = [l for l in lines if l.startswith("batcher")]
+        return summary, costs, batch
+
+    s_ref, c_ref, _ = run(5)
+    assert s_ref["solved"] == 10 and s_ref["kkt_batch_groups"] == 0
+    for groups in ("1", "2"):
+        s_b, c_b, lines = run(5, EMI_MC_BATCH=groups)
+        assert s_b["solved"] == 10 and s_b["kkt_batch_groups"] == int(groups) and len(lines) == int(groups)
+        largest = max(int(l.split("largest batch")[1]) for l in lines)
+        assert largest >= 2, lines                      # launches really were shared
+        for sc, c in c_ref.items():
+            assert abs(c_b[sc] - c) < 1e-6 * abs(c), (groups, sc, c_b[sc], c)
+
+
 def test_montecarlo_scenario_without_a_feasible_path_on_its_side_ends_early(built):
     """Scenario 27 of the 257-node / 10 keep-out set cannot clear its keep-outs from the side the coarse meshes chose:
     the largest elastic variable stays at 0.15 whatever the penalty weight.  The solve must say so (or, should a later
