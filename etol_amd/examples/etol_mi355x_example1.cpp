@@ -72,6 +72,7 @@ void editAlgo(ETOL::TrajectoryOptimizer* t) {
     }
     mx::Alg* algo = ptr->getAlgorithm();
     algo->nlp_tolerance = 1.e-8;
+    algo->defect_scaling = "jacobian-based";       // as the reference example asks of PSOPT (etol_psopt_example1.cpp:91)
     algo->max_cpu_time = 100;
 }
 

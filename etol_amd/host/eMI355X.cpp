@@ -933,6 +933,8 @@ void eMI355X::solve() {
                           : nullptr;
         if (_algorithm.scaling == "automatic") nlp.vscale = mi355x::bound_scales(P);
         else if (_algorithm.scaling != "none") die("Alg::scaling must be \"automatic\" or \"none\"");
+        if (_algorithm.defect_scaling == "jacobian-based") nlp.jacobian_defect_scaling = true;
+        else if (_algorithm.defect_scaling != "state-based") die("Alg::defect_scaling must be \"state-based\" or \"jacobian-based\"");
         _solution.linear_solver = dev_kkt ? "device: structured KKT factorisation (Schur complement + Cholesky), Woodbury-corrected" : "host LDL^T";
         if (P.guess_lamF.size() == ns * P.nodes) nlp.lamF0 = P.guess_lamF;
         if (P.guess_lamC.size() == P.npath * P.nodes) nlp.lamC0 = P.guess_lamC;

@@ -655,6 +655,21 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
     it.y.assign(mc, 0.0);
     if ((int)P.lamF0.size() == md) std::copy(P.lamF0.begin(), P.lamF0.end(), it.lam.begin());
     auto eqr = [&](const Eval& e, int r) { return r < md ? e.RES[r] : e.LNK[r - md]; };      // residual of equality row r
+    // row weights of the merit function (jacobian_defect_scaling): 1 / max(1, inf-norm of the defect row of the Jacobian at the start)
+    std::vector<double> rs(me, 1.0);
+    if (P.jacobian_defect_scaling) {
+        const double* V0 = E.VALS.data();
+        for (int k = 0; k < M; ++k) {
+            double dmax = 0;
+            for (int j = 0; j < M; ++j)
+                if (j != k) dmax = std::max(dmax, std::fabs(P.D[(size_t)k * M + j]));
+            for (int i = 0; i < ns; ++i) {
+                double nrm = dmax;
+                for (int v = 0; v < nv; ++v) nrm = std::max(nrm, std::fabs(V0[(size_t)(i * nv + v) * M + k]));
+                rs[i * M + k] = 1.0 / std::max(1.0, nrm);
+            }
+        }
+    }
     if ((int)P.lamC0.size() == mc)      // iterated on in scaled form; inside the penalty box
         for (int r = 0; r < mc; ++r) it.y[r] = std::min(std::max(P.lamC0[r] / sig[r / M], -0.9 * rho), 0.9 * rho);
     it.zL.assign(nz, 0.0); it.zU.assign(nz, 0.0);
@@ -762,7 +777,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             phi += rho * (e1[r] + e2[r]) - mu_t * (std::log(e1[r]) + std::log(e2[r]));
             viol += std::fabs(row_res(e, s, e1, e2, r));
         }
-        for (int r = 0; r < me; ++r) viol += std::fabs(eqr(e, r));
+        for (int r = 0; r < me; ++r) viol += rs[r] * std::fabs(eqr(e, r));
         if (infeas) *infeas = viol;
         return phi + nu_t * viol;
     };
@@ -1225,7 +1240,7 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
         // far-from-feasible iterations are orders of magnitude above those near the solution, and a weight
         // frozen at that level rejects every step whose constraint curvature shows at all.
         double mmax = 0;
-        for (int r = 0; r < me; ++r) mmax = std::max(mmax, std::fabs(it.lam[r] + dlam[r]));
+        for (int r = 0; r < me; ++r) mmax = std::max(mmax, std::fabs(it.lam[r] + dlam[r]) / rs[r]);
         for (int r = 0; r < mc; ++r) mmax = std::max(mmax, std::fabs(it.y[r] + dy[r]));
         double nu_want = std::max(1.0, std::min(1.1 * mmax, 1e8));
         if (infeas0 > 0) nu_want = std::max(nu_want, dphi / (0.9 * infeas0) + 1.0);

@@ -79,6 +79,13 @@ struct NlpProblem {
     std::vector<double> cscale;         // np positive row scalings applied inside the iteration (empty = 1)
     std::vector<double> vscale;         // ns+nc positive variable scales: the iteration runs on z_v / vscale[v], defect rows of state i
                                         // on defect_i / vscale[i] (PSOPT's scaling = "automatic" with state-based defect scaling); empty = none
+    bool jacobian_defect_scaling = false;   // PSOPT's defect_scaling = "jacobian-based" (reference src/Examples/PSOPT/etol_psopt_example1.cpp:90-91):
+                                        // defect row r is weighted by s_r = 1 / max(1, ||row r of the constraint Jacobian at the first point||_inf)
+                                        // wherever the iteration MEASURES the defects against each other or against the objective -- the l1 merit
+                                        // function and its penalty weight (which then bounds the scaled multipliers lambda_r / s_r).  A row scaling
+                                        // is diag(s) (D (x) I - h f_x): D stays an operator, and the Newton step is invariant under it, so the
+                                        // linear algebra (node blocks, Schur complement, backend) is untouched; the convergence test keeps the
+                                        // unscaled defects (answers are compared at 1e-6 in the caller's units)
     std::vector<double> lamF0, lamC0;   // optional warm start of the defect / path-row multipliers (ns*M, np*M)
     std::vector<NlpLink> links;         // linear coupling rows (delayed values); the dense host backend only (kkt must be null)
     NlpEvaluator* ev = nullptr;

@@ -59,6 +59,10 @@ struct Alg {
                                                    // iterations (0.92 -> 3.05 s, and to a worse local optimum, 416.19 against 400.47) and the 129-node
                                                    // fixed wing from 11 to 79 (1.05 -> 2.32 s); on Monte-Carlo sets it saves ~10 % of the iterations.
                                                    // Results are always in the caller's units.
+    std::string defect_scaling = "state-based";    // PSOPT's Alg::defect_scaling.  "state-based": defect rows follow their state's scale (what `scaling`
+                                                   // does); "jacobian-based" (the shipped example sets it, etol_psopt_example1.cpp:90-91): every defect row is
+                                                   // weighted by the reciprocal of its Jacobian row norm in the merit function of the NLP iteration
+                                                   // (mi355x::NlpProblem::jacobian_defect_scaling: the Newton step is invariant under row scalings)
     int mr_max_iterations = 10;                    // ePSOPT.cpp:70
     double ode_tolerance = 1.e-4;                  // ePSOPT.cpp:71
     int mr_max_nodes = 513;                        // refinement stops adding nodes here

@@ -184,6 +184,8 @@ HostKkt g_host_kkt;
 
 int g_scaling = -1;               // -1: defaults (oracle-evaluator solves unscaled, eMI355X as Alg::scaling says); 0 / 1: scaling "none" / "automatic"
 extern "C" void harness_set_scaling(int on) { g_scaling = on; }
+int g_defect_scaling = 0;         // 1: Alg::defect_scaling = "jacobian-based" (etol_psopt_example1.cpp:90-91) on every eMI355X the harness sets up
+extern "C" void harness_set_defect_scaling(int jacobian_based) { g_defect_scaling = jacobian_based; }
 extern "C" int harness_kkt_standin_wrong_inertia(void) { return g_host_kkt.wrong_inertia; }
 
 extern "C" int harness_solve_example1_oracle(const char* xml, const char* oracle_so, int with_obstacles, double tol,
@@ -508,6 +510,7 @@ extern "C" int harness_solve_quadrotor(int nsteps, double dt, int ndiscs, double
     solver.getAlgorithm()->ode_tolerance = ode_tol;
     solver.getAlgorithm()->linear_solver = g_linear_solver;
     solver.getAlgorithm()->scaling = g_scaling < 0 ? solver.getAlgorithm()->scaling : (g_scaling ? "automatic" : "none");
+    if (g_defect_scaling) solver.getAlgorithm()->defect_scaling = "jacobian-based";
     solver.solve();
     g_out2 = solver.getSolution()->linear_solver;
     const mx::Sol* s = solver.getSolution();
@@ -708,6 +711,7 @@ extern "C" int harness_solve_fixedwing(int nsteps, double tf, double lateral, do
     solver.getAlgorithm()->mesh_refinement = "none";
     solver.getAlgorithm()->linear_solver = g_linear_solver;
     solver.getAlgorithm()->scaling = g_scaling < 0 ? solver.getAlgorithm()->scaling : (g_scaling ? "automatic" : "none");
+    if (g_defect_scaling) solver.getAlgorithm()->defect_scaling = "jacobian-based";
     solver.solve();
     const mx::Sol* s = solver.getSolution();
     *iters = s->nlp_iterations;
@@ -964,6 +968,7 @@ int harness_solve_example1(const char* xml, int with_obstacles, double tol, int 
     e.solver.getAlgorithm()->print_level = print_level;
     e.solver.getAlgorithm()->linear_solver = g_linear_solver;
     e.solver.getAlgorithm()->scaling = g_scaling < 0 ? e.solver.getAlgorithm()->scaling : (g_scaling ? "automatic" : "none");
+    if (g_defect_scaling) e.solver.getAlgorithm()->defect_scaling = "jacobian-based";
     if (g_refine >= 0) e.solver.getAlgorithm()->mesh_refinement = g_refine ? "automatic" : "none";
     t->solve();
     g_out2 = e.solver.getSolution()->linear_solver;

@@ -131,6 +131,26 @@ def test_quadrotor_41_nodes_matches_an_independent_optimiser(H):
     _assert_trajectory_parity("quadrotor_41", cost, X, U, "quadrotor_41")
 
 
+def test_jacobian_based_defect_scaling_reaches_the_stored_optima(H, xmls):
+    """Alg::defect_scaling = "jacobian-based" (the shipped example asks PSOPT for it, reference
+    src/Examples/PSOPT/etol_psopt_example1.cpp:90-91): defect rows weighted by the reciprocal of their Jacobian row norm in the merit
+    function of the NLP iteration.  The shipped problem with all 11 rows (33 nodes, host LDL^T) and the 41-node quadrotor (device
+    Newton step) must still end within 1e-6 of an optimum the independent CPU optimiser holds or confirms."""
+    H.harness_set_refine.argtypes = [C.c_int]
+    H.harness_set_defect_scaling.argtypes = [C.c_int]
+    H.harness_set_defect_scaling(1)
+    H.harness_set_refine(0)
+    try:
+        cost, X, U, T, iters = solve(H, xmls["ocp_2d_ex1.xml"], 1, tol=1e-10)
+        _assert_trajectory_parity("ocp_2d_ex1 (jacobian-based defect scaling)", cost, X, U, "ocp_2d_ex1")
+        cost, X, U, iters, mesh_iters, _ = _solve_quadrotor(H, 40, 0.1, 2, refine=0, tol=1e-10)
+        _assert_trajectory_parity("quadrotor_41 (jacobian-based defect scaling)", cost, X, U, "quadrotor_41")
+        print(f"quadrotor_41 with jacobian-based defect scaling: {iters} iterations")
+    finally:
+        H.harness_set_refine(-1)
+        H.harness_set_defect_scaling(0)
+
+
 def test_shipped_mip_configuration_is_solved_from_a_bent_start(H, xmls):
     """mip_2d_ex1.xml as the reference's container feeds it to the PSOPT example: 17 nodes, tf = 8, four controls of
     which the callbacks read two.  The straight-line start ends locally infeasible; solve() retries from bent lines
@@ -390,6 +410,10 @@ def test_config3_sized_problem_end_to_end(H):
     assert H.harness_last_linear_solver().decode().startswith("device")
     m = X.shape[1]
     assert m == 1024 and mesh_iters >= 6 and iters < 200
+    # regression guard (round 3 shipped Alg::scaling = "automatic" as the default: 58 iterations on the last mesh and a worse local
+    # optimum, 416.19; profiles/r04_regress_probe.json): the 1024-node solve of this problem takes 12 iterations from the 513-node
+    # interpolant and ends at cost 400.468
+    assert iters <= 30 and abs(cost - 400.468) < 0.5, (iters, cost)
     discs = [(4.0, 3.2, 0.8), (6.3, 4.4, 0.7), (2.5, 1.2, 0.4), (1.6, 3.4, 0.35), (3.1, 5.2, 0.30), (5.2, 1.4, 0.35),
              (7.4, 2.6, 0.30), (8.6, 4.2, 0.25), (5.0, 6.3, 0.35), (2.2, 7.1, 0.30), (6.9, 7.4, 0.35), (8.9, 7.9, 0.30),
              (0.9, 5.6, 0.25), (3.9, 8.4, 0.30), (9.2, 1.3, 0.30), (7.0, 0.8, 0.25), (4.6, 4.9, 0.20), (2.9, 2.9, 0.20),
@@ -440,6 +464,23 @@ def test_fixedwing_lateral_offset_solves_on_the_gpu(H):
     assert scaled.max() < 1e-6 and abs(COST[0] - cost.value) < 1e-8 * abs(cost.value)
     assert abs(X[1, -1] - 10.0) <= 0.5 + 1e-9 and np.abs(X[3]).max() > 0.02
     assert U[0].min() >= -1e-9 and U[0].max() <= 60 + 1e-9 and np.abs(U[1:]).max() <= 0.5 + 1e-9
+
+
+def test_fixedwing_129_nodes_iteration_count_regression_guard(H):
+    """The 129-node fixed-wing lateral offset (tools/solve_times.py): 11 iterations on the last mesh in round 2, 103 in round 3
+    (Alg::scaling = "automatic" as the default, together with the primal regularisation ladder: profiles/r04_regress_probe.json), 11
+    again with the default back at "none".  Guard on the count and on the optimum."""
+    D = C.POINTER(C.c_double)
+    H.harness_solve_fixedwing.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, D, C.POINTER(C.c_int), D, D,
+                                          C.c_int, C.POINTER(C.c_int)]
+    n = 128
+    X, U = np.zeros(12 * (n + 1)), np.zeros(4 * (n + 1))
+    cost, M, it = C.c_double(), C.c_int(), C.c_int()
+    rc = H.harness_solve_fixedwing(n, 12.0, 20.0, 1e-7, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D), n + 1,
+                                   C.byref(it))
+    assert rc == 0, H.harness_last_message().decode()
+    assert M.value == n + 1 and it.value <= 30, it.value
+    assert abs(cost.value - 3101.9036) < 1e-2, cost.value
 
 
 def test_montecarlo_example_shards_scenarios_over_ranks_and_threads(built):
