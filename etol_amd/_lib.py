@@ -70,6 +70,9 @@ SYMBOLS = {
     "emi_kkt_last_regularisation": (C.c_int, [_P, _D, _D]),
     "emi_kkt_factor_batch": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_D), C.POINTER(_D), C.POINTER(C.POINTER(C.c_ubyte)), _D, _I]),
     "emi_kkt_solve_batch": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_D)]),
+    "emi_kkt_is_schur": (C.c_int, [_P]),
+    "emi_kkt_solve_refined": (C.c_int, [_P, _D, C.c_double, C.c_int, _D, _I, _I, _I]),
+    "emi_kkt_solve_refined_batch": (C.c_int, [C.c_int, C.POINTER(_P), C.POINTER(_D), _D, C.c_int, _D, _I, _I, _I]),
     "emi_kkt_lowrank": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), _D, _D, C.POINTER(C.c_int)]),
     "emi_set_batch": (C.c_int, [_P, C.c_int]),
     "emi_set_path": (C.c_int, [_P, C.c_int, C.c_int, _D, C.c_int, C.c_int]),

@@ -1292,6 +1292,37 @@ int emi_kkt_solve_batch(int n, const emi_ctx_t* ctxs, double* const* rhs) {
     return st;
 }
 
+int emi_kkt_solve_refined_batch(int n, const emi_ctx_t* ctxs, double* const* rhs, const double* dc_nominal, int max_steps, double* rel,
+                                int* nsolve, int* reverted, int* status) {
+    int st = batch_compatible(n, ctxs, "emi_kkt_solve_refined_batch");
+    if (st) return st;
+    emi_ctx_t c0 = ctxs[0];
+    if (!rhs || !dc_nominal || !rel || !nsolve || !reverted || !status || max_steps < 0)
+        return fail(c0, EMI_ERR_ARG, "emi_kkt_solve_refined_batch: bad argument");
+    HIP_TRY(c0, hipSetDevice(c0->device));
+    std::vector<emi::KktWorkspace*> ws(n);
+    for (int b = 0; b < n; ++b) {
+        if (!rhs[b] || !(dc_nominal[b] >= 0.0)) return fail(c0, EMI_ERR_ARG, "emi_kkt_solve_refined_batch: bad argument for scenario %d", b);
+        if (!emi::kkt_is_schur(ctxs[b]->kkt))
+            return fail(c0, EMI_ERR_UNSUPPORTED, "emi_kkt_solve_refined_batch: scenario %d holds no factorisation of the Schur path (the LU fallback "
+                                                 "is refined by the caller: emi_kkt_solve)", b);
+        HIP_TRY(c0, hipStreamSynchronize(ctxs[b]->stream));
+        ws[b] = ctxs[b]->kkt;
+    }
+    std::string err;
+    st = emi::kkt_solve_refined_batch(n, ws.data(), c0->stream, rhs, dc_nominal, max_steps, rel, nsolve, reverted, status, &err);
+    if (st) c0->err = err;
+    return st;
+}
+
+int emi_kkt_solve_refined(emi_ctx_t c, double* rhs, double dc_nominal, int max_steps, double* rel, int* nsolve, int* reverted, int* status) {
+    if (!c) return EMI_ERR_ARG;
+    double* r1 = rhs;
+    return emi_kkt_solve_refined_batch(1, &c, &r1, &dc_nominal, max_steps, rel, nsolve, reverted, status);
+}
+
+int emi_kkt_is_schur(emi_ctx_t c) { return c && emi::kkt_is_schur(c->kkt) ? 1 : 0; }
+
 int emi_kkt_last_regularisation(emi_ctx_t c, double* dc, double* dw) {
     if (!c || (!dc && !dw)) return EMI_ERR_ARG;
     if (!c->kkt) return fail(c, EMI_ERR_STATE, "emi_kkt_last_regularisation: no factorisation");

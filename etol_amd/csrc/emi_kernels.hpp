@@ -82,5 +82,7 @@ int kkt_factor_batch(int n, KktWorkspace** const* pws, hipStream_t stream, const
                      const double* const* Qblk, const double* const* Jblk, const unsigned char* const* fixed, const double* dc, int* info,
                      std::string* err);
 int kkt_solve_batch(int n, KktWorkspace* const* ws, hipStream_t stream, int nz, double* const* rhs, std::string* err);
+int kkt_solve_refined_batch(int n, KktWorkspace* const* ws, hipStream_t stream, double* const* rhs, const double* dc_nominal, int max_steps,
+                            double* rel, int* nsolve, int* reverted, int* status, std::string* err);
 
 }  // namespace emi

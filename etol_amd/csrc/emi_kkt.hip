@@ -130,6 +130,9 @@ struct KktWorkspace {
     int* lr_node = nullptr;
     double* lr_vec = nullptr;   // [r][nv]
     double* lr_delta = nullptr;
+    // refined solves (kkt_solve_refined_batch): right-hand side, solution, previous solution on the device
+    double *ref_b = nullptr, *ref_x = nullptr, *ref_p = nullptr;
+    size_t cap_ref_b = 0, cap_ref_x = 0, cap_ref_p = 0;
     // Doff is a function of the mesh only: rebuilt when the mesh changes (kkt_mesh_changed), not at every factorisation
     const double* doff_src = nullptr;
     int doff_M = 0;
@@ -835,6 +838,10 @@ __global__ void emi_trsv_copy_kernel(const double* __restrict__ src, double* __r
 // (96 diagonal-block steps at 1024 nodes) over n matrices.
 struct KktDev {                 // device pointers of one workspace, as the batched kernels see them
     double *Q, *J, *Pinv, *G, *Rk, *S, *W, *chol_blk, *Linv, *LinvT, *T, *Cb, *rhs, *y;
+    double *bb, *xx, *xp;       // refined solves: right-hand side, solution, solution before the last correction
+    const int* lr_node;         // low-rank correction of the scenario (lr_r = 0: none active)
+    const double *lr_vec, *lr_delta;
+    int lr_r;
     const double* Doff;
     unsigned char* fixed;
     int *flag, *info;
@@ -1209,6 +1216,9 @@ void kkt_destroy(KktWorkspace* w) {
                     w->Cb, w->flag, w->chol_blk, w->chol_copy, w->Linv, w->LinvT, w->trsv_tmp, w->trsv_y, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (w->ref_b) (void)hipFree(w->ref_b);
+    if (w->ref_x) (void)hipFree(w->ref_x);
+    if (w->ref_p) (void)hipFree(w->ref_p);
     if (w->b_tab) (void)hipFree(w->b_tab);
     if (w->b_ptrs) (void)hipFree(w->b_ptrs);
     if (w->b_stat) (void)hipFree(w->b_stat);
@@ -1901,124 +1911,383 @@ int kkt_factor_batch(int n, KktWorkspace** const* pws, hipStream_t stream, const
     return EMI_OK;
 }
 
-// One right-hand side per scenario, all factorised on the same mesh (Schur path): rhs[b] [N] host, in place.  Scenarios with an active
-// low-rank correction get their Woodbury term after the common part.
-int kkt_solve_batch(int n, KktWorkspace* const* ws, hipStream_t stream, int nz, double* const* rhs, std::string* err) {
-    if (n < 1) { *err = "emi_kkt_solve_batch: empty batch"; return EMI_ERR_ARG; }
-    KktWorkspace* L = ws[0];
-    const int M = L->M, ns = L->ns, nv = L->nv, N = L->N, md = ns * M;
-    for (int b = 0; b < n; ++b) {
-        KktWorkspace* w = ws[b];
-        if (!w || !w->factored || w->method_used != 1 || w->M != M || w->ns != ns || w->nv != nv || w->N != N) {
-            *err = "emi_kkt_solve_batch: every scenario must hold a Schur factorisation on the same mesh";
-            return EMI_ERR_STATE;
-        }
-        if (w->rhs_elems < (size_t)N) {
-            if (w->rhs) KKT_HIP(hipFree(w->rhs));
-            w->rhs = nullptr; w->rhs_elems = 0;
-            KKT_HIP(hipMalloc(&w->rhs, (size_t)N * sizeof(double)));
-            w->rhs_elems = (size_t)N;
-        }
-        if (w->T_elems < (size_t)nz) {
-            if (w->T) KKT_HIP(hipFree(w->T));
-            w->T = nullptr; w->T_elems = 0;
-            KKT_HIP(hipMalloc(&w->T, (size_t)nz * sizeof(double)));
-            w->T_elems = (size_t)nz;
-        }
-        if (w->Cb_elems < (size_t)md) {
-            if (w->Cb) KKT_HIP(hipFree(w->Cb));
-            w->Cb = nullptr; w->Cb_elems = 0;
-            KKT_HIP(hipMalloc(&w->Cb, (size_t)md * sizeof(double)));
-            w->Cb_elems = (size_t)md;
-        }
-        KKT_ENSURE(w->trsv_y, w->cap_trsv_y, (size_t)md * sizeof(double));
-        KKT_HIP(hipMemcpyAsync(w->rhs, rhs[b], (size_t)N * sizeof(double), hipMemcpyHostToDevice, stream));
+// ---- batched solves with the refinement on the device ---------------------------------------------------------------------------
+namespace {
+
+// r = b - K x per scenario, K = [[Q - U Delta U^T (while a low-rank correction is active), J^T], [J, -dc I]] with the nominal node
+// blocks Q and the nominal dc (what the caller means by "the matrix"; the factorisation may hold a regularised one).  Node part here,
+// the two D products as batched GEMMs around it (kkt_residual).  xs = x with fixed variables zeroed (in T), Cb = Doff xs_states.
+__global__ void emi_kkt_mask_copy_b_kernel(const KktDev* __restrict__ tab, int nz) {
+    const KktDev t = tab[blockIdx.y];
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nz) t.T[q] = t.fixed[q] ? 0.0 : t.xx[q];
+}
+__global__ void emi_kkt_residual_node_b_kernel(const KktDev* __restrict__ tab, int M, int ns, int nv, double dc) {
+    const KktDev t = tab[blockIdx.y];
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    const int nz = nv * M;
+    double x[KKT_NV_MAX], lam[KKT_NV_MAX];
+    for (int q = 0; q < nv; ++q) x[q] = t.T[(size_t)q * M + k];
+    for (int i = 0; i < ns; ++i) lam[i] = t.xx[(size_t)nz + (size_t)i * M + k];
+    for (int i = 0; i < ns; ++i) {
+        double acc = t.Cb[(size_t)i * M + k] - dc * lam[i];
+        for (int v = 0; v < nv; ++v) acc += t.J[(size_t)(i * nv + v) * M + k] * x[v];
+        t.rhs[(size_t)nz + (size_t)i * M + k] = t.bb[(size_t)nz + (size_t)i * M + k] - acc;
     }
-    KKT_RB(rocblas_set_stream(L->handle, stream));
-    bool blk = true;
-    for (int b = 0; b < n; ++b) blk = blk && ws[b]->linv_n == md;
-    const int nblk = (md + TRSV_NB - 1) / TRSV_NB;
-    const size_t ptr_count = (size_t)n * (6 + (blk ? 6 * nblk : 0));
-    const size_t tab_bytes = (size_t)n * sizeof(KktDev), ptr_bytes = ptr_count * sizeof(double*), stat_bytes = (size_t)2 * n * sizeof(int);
+    for (int v = 0; v < nv; ++v) {
+        double acc = 0.0;
+        for (int q = 0; q < nv; ++q) {
+            const int hi = v > q ? v : q, lo = v > q ? q : v;
+            acc += t.Q[(size_t)(hi * (hi + 1) / 2 + lo) * M + k] * x[q];
+        }
+        for (int i = 0; i < ns; ++i) acc += t.J[(size_t)(i * nv + v) * M + k] * lam[i];
+        t.rhs[(size_t)v * M + k] = t.bb[(size_t)v * M + k] - acc;      // (fixed variables: masked after the D product)
+    }
+}
+// + U Delta (U^T x) of the scenarios whose low-rank correction is active: one thread per FIRST column of a node walks the node's columns
+// (the columns come node by node: fixed order of the additions)
+__global__ void emi_kkt_residual_lr_b_kernel(const KktDev* __restrict__ tab, int M, int nv) {
+    const KktDev t = tab[blockIdx.y];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= t.lr_r) return;
+    const int node = t.lr_node[c];
+    if (c > 0 && t.lr_node[c - 1] == node) return;
+    for (int a = c; a < t.lr_r && t.lr_node[a] == node; ++a) {
+        double dot = 0.0;
+        for (int v = 0; v < nv; ++v) dot += t.lr_vec[(size_t)a * nv + v] * t.T[(size_t)v * M + node];
+        dot *= t.lr_delta[a];
+        for (int v = 0; v < nv; ++v) t.rhs[(size_t)v * M + node] += t.lr_vec[(size_t)a * nv + v] * dot;
+    }
+}
+// stat[item] = max |v| over the N entries of the chosen vector (which: 0 rhs, 1 bb); NaN propagates as +inf
+__global__ __launch_bounds__(256) void emi_kkt_absmax_b_kernel(const KktDev* __restrict__ tab, int N, int which, double* __restrict__ out) {
+    __shared__ double red[256];
+    const KktDev t = tab[blockIdx.x];
+    const double* v = which ? t.bb : t.rhs;
+    double m = 0.0;
+    for (int q = threadIdx.x; q < N; q += 256) {
+        const double a = fabs(v[q]);
+        m = (a > m || a != a) ? (a != a ? INFINITY : a) : m;
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) {
+        if (threadIdx.x < sft) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + sft]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+// dst <- src (+ add) over N entries: sel 0: rhs <- bb; 1: xx <- rhs; 2: xp <- xx; 3: xx <- xp; 4: xx += rhs
+__global__ void emi_kkt_vecop_b_kernel(const KktDev* __restrict__ tab, int N, int sel) {
+    const KktDev t = tab[blockIdx.y];
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    if (sel == 0) t.rhs[q] = t.bb[q];
+    else if (sel == 1) t.xx[q] = t.rhs[q];
+    else if (sel == 2) t.xp[q] = t.xx[q];
+    else if (sel == 3) t.xx[q] = t.xp[q];
+    else t.xx[q] += t.rhs[q];
+}
+
+struct SolveShape { int M, ns, nv, N, nz, md, nblk; bool blk; };
+
+void fill_solve_entry(KktDev& t, KktWorkspace* w, const KktWorkspace* L) {
+    t.Q = w->Q; t.J = w->J; t.Pinv = w->Pinv; t.S = w->S; t.Linv = w->Linv; t.LinvT = w->LinvT; t.T = w->T; t.Cb = w->Cb; t.rhs = w->rhs;
+    t.y = w->trsv_y; t.bb = w->ref_b; t.xx = w->ref_x; t.xp = w->ref_p;
+    t.fixed = w->fixed;
+    t.Doff = L->Doff;
+    t.lr_r = w->lr_active ? w->lr_r : 0;
+    t.lr_node = w->lr_node; t.lr_vec = w->lr_vec; t.lr_delta = w->lr_delta;
+}
+
+// table + the pointer arrays every batched call below needs, for the n workspaces of this step
+struct SolveArrays {
+    KktDev* d_tab;
+    double** P;
+    size_t at_D, at_T, at_Cb, at_X, at_S, at_Y, at_XX, at_lam;
+    std::vector<size_t> at_LT, at_LI, at_xj, at_yj, at_Sr;
+};
+int solve_arrays(KktWorkspace* L, hipStream_t stream, const SolveShape& sh, int n, KktWorkspace* const* ws, SolveArrays* A, std::string* err) {
+    const size_t ptr_count = (size_t)n * (8 + (sh.blk ? 5 * sh.nblk : 0));
+    const size_t tab_bytes = (size_t)n * sizeof(KktDev), ptr_bytes = ptr_count * sizeof(double*), stat_bytes = (size_t)4 * n * sizeof(double);
     if (int st = batch_scratch(L, tab_bytes, ptr_bytes, stat_bytes, err)) return st;
     KktDev* h_tab = reinterpret_cast<KktDev*>(L->b_pin);
     double** h_ptr = reinterpret_cast<double**>(L->b_pin + tab_bytes);
-    KktDev* d_tab = reinterpret_cast<KktDev*>(L->b_tab);
+    A->d_tab = reinterpret_cast<KktDev*>(L->b_tab);
+    A->P = L->b_ptrs;
     for (int b = 0; b < n; ++b) {
-        KktWorkspace* w = ws[b];
         KktDev t{};
-        t.J = w->J; t.Pinv = w->Pinv; t.S = w->S; t.Linv = w->Linv; t.LinvT = w->LinvT; t.T = w->T; t.Cb = w->Cb; t.rhs = w->rhs; t.y = w->trsv_y;
-        t.fixed = w->fixed;
-        t.Doff = L->Doff;
+        fill_solve_entry(t, ws[b], L);
         h_tab[b] = t;
     }
     size_t q = 0;
     auto arr = [&](auto f) { const size_t at = q; for (int b = 0; b < n; ++b) h_ptr[q++] = f(ws[b]); return at; };
-    const size_t at_D = arr([&](KktWorkspace*) { return L->Doff; });
-    const size_t at_T = arr([](KktWorkspace* w) { return w->T; });
-    const size_t at_Cb = arr([](KktWorkspace* w) { return w->Cb; });
-    const size_t at_X = arr([](KktWorkspace* w) { return w->rhs; });
-    const size_t at_S = arr([](KktWorkspace* w) { return w->S; });
-    const size_t at_Y = arr([](KktWorkspace* w) { return w->trsv_y; });
-    std::vector<size_t> at_LT(nblk), at_LI(nblk), at_xj(nblk), at_yj(nblk), at_Sr(nblk);
-    if (blk)
-        for (int j = 0; j < nblk; ++j) {
+    A->at_D = arr([&](KktWorkspace*) { return L->Doff; });
+    A->at_T = arr([](KktWorkspace* w) { return w->T; });
+    A->at_Cb = arr([](KktWorkspace* w) { return w->Cb; });
+    A->at_X = arr([](KktWorkspace* w) { return w->rhs; });
+    A->at_S = arr([](KktWorkspace* w) { return w->S; });
+    A->at_Y = arr([](KktWorkspace* w) { return w->trsv_y; });
+    A->at_XX = arr([](KktWorkspace* w) { return w->ref_x; });
+    A->at_lam = arr([&](KktWorkspace* w) { return w->ref_x + sh.nz; });
+    A->at_LT.assign(sh.nblk, 0); A->at_LI.assign(sh.nblk, 0); A->at_xj.assign(sh.nblk, 0); A->at_yj.assign(sh.nblk, 0); A->at_Sr.assign(sh.nblk, 0);
+    if (sh.blk)
+        for (int j = 0; j < sh.nblk; ++j) {
             const size_t j0 = (size_t)j * TRSV_NB;
-            at_LT[j] = arr([&](KktWorkspace* w) { return w->LinvT + (size_t)j * TRSV_NB * TRSV_NB; });
-            at_LI[j] = arr([&](KktWorkspace* w) { return w->Linv + (size_t)j * TRSV_NB * TRSV_NB; });
-            at_xj[j] = arr([&](KktWorkspace* w) { return w->Cb + j0; });
-            at_yj[j] = arr([&](KktWorkspace* w) { return w->trsv_y + j0; });
-            at_Sr[j] = arr([&](KktWorkspace* w) { return w->S + j0; });
+            A->at_LT[j] = arr([&](KktWorkspace* w) { return w->LinvT + (size_t)j * TRSV_NB * TRSV_NB; });
+            A->at_LI[j] = arr([&](KktWorkspace* w) { return w->Linv + (size_t)j * TRSV_NB * TRSV_NB; });
+            A->at_xj[j] = arr([&](KktWorkspace* w) { return w->Cb + j0; });
+            A->at_yj[j] = arr([&](KktWorkspace* w) { return w->trsv_y + j0; });
+            A->at_Sr[j] = arr([&](KktWorkspace* w) { return w->S + j0; });
         }
-    KKT_HIP(hipMemcpyAsync(d_tab, h_tab, (size_t)n * sizeof(KktDev), hipMemcpyHostToDevice, stream));
-    KKT_HIP(hipMemcpyAsync(L->b_ptrs, h_ptr, q * sizeof(double*), hipMemcpyHostToDevice, stream));
-    double** P = L->b_ptrs;
+    // the previous step's launches read the device copies: they are done before the pinned staging is overwritten, because every
+    // step of the callers ends with a stream synchronisation (status words) -- except the first, which has nothing in flight
+    KKT_HIP(hipMemcpyAsync(A->d_tab, h_tab, (size_t)n * sizeof(KktDev), hipMemcpyHostToDevice, stream));
+    KKT_HIP(hipMemcpyAsync(A->P, h_ptr, q * sizeof(double*), hipMemcpyHostToDevice, stream));
+    return EMI_OK;
+}
+
+// rhs <- K~^-1 rhs (+ Woodbury term of the scenarios that hold a low-rank correction), in place on every ws[b]->rhs
+int solve_core(KktWorkspace* L, hipStream_t stream, const SolveShape& sh, int n, KktWorkspace* const* ws, const SolveArrays& A, std::string* err) {
+    const int M = sh.M, ns = sh.ns, nv = sh.nv, N = sh.N, nz = sh.nz, md = sh.md, nblk = sh.nblk;
+    const KktDev* d_tab = A.d_tab;
+    double** P = A.P;
     const double one = 1.0, zero = 0.0, mone = -1.0;
     dim3 gk((M + 127) / 128, n), bk(128);
-    hipLaunchKernelGGL(emi_kkt_mask_rhs_b_kernel, dim3((nz + 255) / 256, n), dim3(256), 0, stream, (const KktDev*)d_tab, nz, N);
-    hipLaunchKernelGGL(emi_kkt_apply_p_b_kernel, gk, bk, 0, stream, (const KktDev*)d_tab, M, nv, 0);           // t = P a
+    hipLaunchKernelGGL(emi_kkt_mask_rhs_b_kernel, dim3((nz + 255) / 256, n), dim3(256), 0, stream, d_tab, nz, N);
+    hipLaunchKernelGGL(emi_kkt_apply_p_b_kernel, gk, bk, 0, stream, d_tab, M, nv, 0);           // t = P a
     KKT_HIP(hipGetLastError());
-    KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_transpose, rocblas_operation_none, M, ns, M, &one, (const double* const*)(P + at_D), M,
-                                 (const double* const*)(P + at_T), M, &zero, P + at_Cb, M, n));                 // Cb = Doff t_states
-    hipLaunchKernelGGL(emi_kkt_jnode_minus_b_b_kernel, gk, bk, 0, stream, (const KktDev*)d_tab, M, ns, nv);    // Cb += J_node t - b
+    KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_transpose, rocblas_operation_none, M, ns, M, &one, (const double* const*)(P + A.at_D), M,
+                                 (const double* const*)(P + A.at_T), M, &zero, P + A.at_Cb, M, n));                 // Cb = Doff t_states
+    hipLaunchKernelGGL(emi_kkt_jnode_minus_b_b_kernel, gk, bk, 0, stream, d_tab, M, ns, nv);    // Cb += J_node t - b
     KKT_HIP(hipGetLastError());
-    if (blk) {                                          // lambda = S^-1 Cb through the block inverses (blk_potrs, gemv form)
+    if (sh.blk) {                                       // lambda = S^-1 Cb through the block inverses (blk_potrs, gemv form)
         for (int j = 0; j < nblk; ++j) {
             const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, md - j0), rest = md - j0 - bs;
-            KKT_RB(rocblas_dgemv_batched(L->handle, rocblas_operation_transpose, bs, bs, &one, (const double* const*)(P + at_LT[j]), TRSV_NB,
-                                         (const double* const*)(P + at_xj[j]), 1, &zero, P + at_yj[j], 1, n));
+            KKT_RB(rocblas_dgemv_batched(L->handle, rocblas_operation_transpose, bs, bs, &one, (const double* const*)(P + A.at_LT[j]), TRSV_NB,
+                                         (const double* const*)(P + A.at_xj[j]), 1, &zero, P + A.at_yj[j], 1, n));
             if (rest > 0)
-                hipLaunchKernelGGL(emi_trsv_update_b_kernel, dim3((rest + 63) / 64, n), dim3(256), 0, stream, (const KktDev*)d_tab, md, j0, bs, rest);
+                hipLaunchKernelGGL(emi_trsv_update_b_kernel, dim3((rest + 63) / 64, n), dim3(256), 0, stream, d_tab, md, j0, bs, rest);
         }
         for (int j = nblk - 1; j >= 0; --j) {
             const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, md - j0);
-            KKT_RB(rocblas_dgemv_batched(L->handle, rocblas_operation_transpose, bs, bs, &one, (const double* const*)(P + at_LI[j]), TRSV_NB,
-                                         (const double* const*)(P + at_yj[j]), 1, &zero, P + at_xj[j], 1, n));
+            KKT_RB(rocblas_dgemv_batched(L->handle, rocblas_operation_transpose, bs, bs, &one, (const double* const*)(P + A.at_LI[j]), TRSV_NB,
+                                         (const double* const*)(P + A.at_yj[j]), 1, &zero, P + A.at_xj[j], 1, n));
             if (j0 > 0)
-                KKT_RB(rocblas_dgemv_batched(L->handle, rocblas_operation_transpose, bs, j0, &mone, (const double* const*)(P + at_Sr[j]), md,
-                                             (const double* const*)(P + at_xj[j]), 1, &one, P + at_Y, 1, n));
+                KKT_RB(rocblas_dgemv_batched(L->handle, rocblas_operation_transpose, bs, j0, &mone, (const double* const*)(P + A.at_Sr[j]), md,
+                                             (const double* const*)(P + A.at_xj[j]), 1, &one, P + A.at_Y, 1, n));
         }
         KKT_HIP(hipGetLastError());
     } else {
-        KKT_RB(rocsolver_dpotrs_batched(L->handle, rocblas_fill_lower, md, 1, P + at_S, md, P + at_Cb, md, n));
+        KKT_RB(rocsolver_dpotrs_batched(L->handle, rocblas_fill_lower, md, 1, P + A.at_S, md, P + A.at_Cb, md, n));
     }
-    KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_none, rocblas_operation_none, M, ns, M, &mone, (const double* const*)(P + at_D), M,
-                                 (const double* const*)(P + at_Cb), M, &one, P + at_X, M, n));                  // y = a - J^T lambda ...
-    hipLaunchKernelGGL(emi_kkt_jnode_t_b_kernel, gk, bk, 0, stream, (const KktDev*)d_tab, M, ns, nv);
-    hipLaunchKernelGGL(emi_kkt_apply_p_b_kernel, gk, bk, 0, stream, (const KktDev*)d_tab, M, nv, 1);           // ... x = P y
-    hipLaunchKernelGGL(emi_kkt_finish_solve_b_kernel, dim3((N + 255) / 256, n), dim3(256), 0, stream, (const KktDev*)d_tab, nz, md);
+    KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_none, rocblas_operation_none, M, ns, M, &mone, (const double* const*)(P + A.at_D), M,
+                                 (const double* const*)(P + A.at_Cb), M, &one, P + A.at_X, M, n));                  // y = a - J^T lambda ...
+    hipLaunchKernelGGL(emi_kkt_jnode_t_b_kernel, gk, bk, 0, stream, d_tab, M, ns, nv);
+    hipLaunchKernelGGL(emi_kkt_apply_p_b_kernel, gk, bk, 0, stream, d_tab, M, nv, 1);           // ... x = P y
+    hipLaunchKernelGGL(emi_kkt_finish_solve_b_kernel, dim3((N + 255) / 256, n), dim3(256), 0, stream, d_tab, nz, md);
     KKT_HIP(hipGetLastError());
     for (int b = 0; b < n; ++b) {
         KktWorkspace* w = ws[b];
-        if (w->lr_active) {             // x <- x + Y C^-1 (U^T x), with the scenario's own handle on this stream
-            const int r = w->lr_r;
-            KKT_RB(rocblas_set_stream(w->handle, stream));
-            hipLaunchKernelGGL(emi_kkt_lr_utx_kernel, dim3((r + 63) / 64, 1), dim3(64), 0, stream, w->lrT, w->rhs, w->lr_node, w->lr_vec, r, N, M, nv);
-            KKT_HIP(hipGetLastError());
-            KKT_RB(rocsolver_dpotrs(w->handle, rocblas_fill_lower, r, 1, w->lrC, r, w->lrT, r));
-            KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_none, N, r, &one, w->lrY, N, w->lrT, 1, &one, w->rhs, 1));
+        if (!w->lr_active) continue;    // x <- x + Y C^-1 (U^T x), with the scenario's own handle on this stream
+        const int r = w->lr_r;
+        KKT_RB(rocblas_set_stream(w->handle, stream));
+        hipLaunchKernelGGL(emi_kkt_lr_utx_kernel, dim3((r + 63) / 64, 1), dim3(64), 0, stream, w->lrT, w->rhs, w->lr_node, w->lr_vec, r, N, M, nv);
+        KKT_HIP(hipGetLastError());
+        KKT_RB(rocsolver_dpotrs(w->handle, rocblas_fill_lower, r, 1, w->lrC, r, w->lrT, r));
+        KKT_RB(rocblas_dgemv(w->handle, rocblas_operation_none, N, r, &one, w->lrY, N, w->lrT, 1, &one, w->rhs, 1));
+    }
+    return EMI_OK;
+}
+
+// rhs <- bb - K xx for every scenario of the table; out_max[b] = max |rhs_b| (device array of doubles)
+int residual_core(KktWorkspace* L, hipStream_t stream, const SolveShape& sh, int n, const SolveArrays& A, double dc_nominal, double* d_max,
+                  std::string* err) {
+    const int M = sh.M, ns = sh.ns, nv = sh.nv, N = sh.N, nz = sh.nz;
+    const double one = 1.0, zero = 0.0, mone = -1.0;
+    hipLaunchKernelGGL(emi_kkt_mask_copy_b_kernel, dim3((nz + 255) / 256, n), dim3(256), 0, stream, (const KktDev*)A.d_tab, nz);
+    KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_transpose, rocblas_operation_none, M, ns, M, &one, (const double* const*)(A.P + A.at_D), M,
+                                 (const double* const*)(A.P + A.at_T), M, &zero, A.P + A.at_Cb, M, n));            // Cb = Doff xs_states
+    hipLaunchKernelGGL(emi_kkt_residual_node_b_kernel, dim3((M + 127) / 128, n), dim3(128), 0, stream, (const KktDev*)A.d_tab, M, ns, nv, dc_nominal);
+    KKT_HIP(hipGetLastError());
+    KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_none, rocblas_operation_none, M, ns, M, &mone, (const double* const*)(A.P + A.at_D), M,
+                                 (const double* const*)(A.P + A.at_lam), M, &one, A.P + A.at_X, M, n));            // states' rows -= Doff^T lambda
+    hipLaunchKernelGGL(emi_kkt_residual_lr_b_kernel, dim3(64, n), dim3(64), 0, stream, (const KktDev*)A.d_tab, M, nv);
+    hipLaunchKernelGGL(emi_kkt_mask_rhs_b_kernel, dim3((nz + 255) / 256, n), dim3(256), 0, stream, (const KktDev*)A.d_tab, nz, N);
+    hipLaunchKernelGGL(emi_kkt_absmax_b_kernel, dim3(n), dim3(256), 0, stream, (const KktDev*)A.d_tab, N, 0, d_max);
+    KKT_HIP(hipGetLastError());
+    return EMI_OK;
+}
+
+int solve_buffers(KktWorkspace* w, int N, int nz, int md, bool refine, std::string* err) {
+    if (w->rhs_elems < (size_t)N) {
+        if (w->rhs) KKT_HIP(hipFree(w->rhs));
+        w->rhs = nullptr; w->rhs_elems = 0;
+        KKT_HIP(hipMalloc(&w->rhs, (size_t)N * sizeof(double)));
+        w->rhs_elems = (size_t)N;
+    }
+    if (w->T_elems < (size_t)nz) {
+        if (w->T) KKT_HIP(hipFree(w->T));
+        w->T = nullptr; w->T_elems = 0;
+        KKT_HIP(hipMalloc(&w->T, (size_t)nz * sizeof(double)));
+        w->T_elems = (size_t)nz;
+    }
+    if (w->Cb_elems < (size_t)md) {
+        if (w->Cb) KKT_HIP(hipFree(w->Cb));
+        w->Cb = nullptr; w->Cb_elems = 0;
+        KKT_HIP(hipMalloc(&w->Cb, (size_t)md * sizeof(double)));
+        w->Cb_elems = (size_t)md;
+    }
+    KKT_ENSURE(w->trsv_y, w->cap_trsv_y, (size_t)md * sizeof(double));
+    if (refine) {
+        KKT_ENSURE(w->ref_b, w->cap_ref_b, (size_t)N * sizeof(double));
+        KKT_ENSURE(w->ref_x, w->cap_ref_x, (size_t)N * sizeof(double));
+        KKT_ENSURE(w->ref_p, w->cap_ref_p, (size_t)N * sizeof(double));
+    }
+    return EMI_OK;
+}
+
+int solve_shape(int n, KktWorkspace* const* ws, SolveShape* sh, std::string* err) {
+    KktWorkspace* L = ws[0];
+    sh->M = L->M; sh->ns = L->ns; sh->nv = L->nv; sh->N = L->N; sh->nz = L->nv * L->M; sh->md = L->ns * L->M;
+    sh->nblk = (sh->md + TRSV_NB - 1) / TRSV_NB;
+    sh->blk = true;
+    for (int b = 0; b < n; ++b) {
+        KktWorkspace* w = ws[b];
+        if (!w || !w->factored || w->method_used != 1 || w->M != sh->M || w->ns != sh->ns || w->nv != sh->nv || w->N != sh->N) {
+            *err = "batched solve: every scenario must hold a Schur factorisation on the same mesh";
+            return EMI_ERR_STATE;
         }
-        KKT_HIP(hipMemcpyAsync(rhs[b], w->rhs, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, stream));
+        sh->blk = sh->blk && w->linv_n == sh->md;
+    }
+    return EMI_OK;
+}
+
+}  // namespace
+
+// One right-hand side per scenario, all factorised on the same mesh (Schur path): rhs[b] [N] host, in place.  Scenarios with an active
+// low-rank correction get their Woodbury term after the common part.
+int kkt_solve_batch(int n, KktWorkspace* const* ws, hipStream_t stream, int nz, double* const* rhs, std::string* err) {
+    if (n < 1) { *err = "emi_kkt_solve_batch: empty batch"; return EMI_ERR_ARG; }
+    (void)nz;
+    SolveShape sh;
+    if (int st = solve_shape(n, ws, &sh, err)) return st;
+    KktWorkspace* L = ws[0];
+    for (int b = 0; b < n; ++b) {
+        if (int st = solve_buffers(ws[b], sh.N, sh.nz, sh.md, false, err)) return st;
+        KKT_HIP(hipMemcpyAsync(ws[b]->rhs, rhs[b], (size_t)sh.N * sizeof(double), hipMemcpyHostToDevice, stream));
+    }
+    KKT_RB(rocblas_set_stream(L->handle, stream));
+    SolveArrays A;
+    if (int st = solve_arrays(L, stream, sh, n, ws, &A, err)) return st;
+    if (int st = solve_core(L, stream, sh, n, ws, A, err)) return st;
+    for (int b = 0; b < n; ++b) KKT_HIP(hipMemcpyAsync(rhs[b], ws[b]->rhs, (size_t)sh.N * sizeof(double), hipMemcpyDeviceToHost, stream));
+    KKT_HIP(hipStreamSynchronize(stream));
+    return EMI_OK;
+}
+
+// The Newton step WITH its iterative refinement on the device: x = K~^-1 b, then up to max_steps rounds of  r = b - K x,  x += K~^-1 r
+// against the NOMINAL matrix K (nominal node blocks and dc_nominal[b]; minus the low-rank term while a scenario's correction is
+// active, i.e. the matrix its exact step belongs to) -- the loop of the host iteration (emi_nlp.cpp), rule for rule: stop when the
+// residual is at round-off or no longer halves; a correction that made the residual WORSE is taken back.  Only the residual norms
+// cross to the host (n doubles per round).  Out per scenario: rel[b] = final max |r| / max(1, max |b|), nsolve[b] = solves used,
+// reverted[b] = 1 if the last correction was taken back, status[b] = 0 ok, 2 the first solution is not finite (the caller regularises).
+int kkt_solve_refined_batch(int n, KktWorkspace* const* ws, hipStream_t stream, double* const* rhs, const double* dc_nominal, int max_steps,
+                            double* rel, int* nsolve, int* reverted, int* status, std::string* err) {
+    if (n < 1) { *err = "emi_kkt_solve_refined_batch: empty batch"; return EMI_ERR_ARG; }
+    SolveShape sh;
+    if (int st = solve_shape(n, ws, &sh, err)) return st;
+    KktWorkspace* L = ws[0];
+    const int N = sh.N;
+    for (int b = 0; b < n; ++b) {
+        if (int st = solve_buffers(ws[b], sh.N, sh.nz, sh.md, true, err)) return st;
+        KKT_HIP(hipMemcpyAsync(ws[b]->ref_b, rhs[b], (size_t)N * sizeof(double), hipMemcpyHostToDevice, stream));
+        rel[b] = 0.0; nsolve[b] = 0; reverted[b] = 0; status[b] = 0;
+    }
+    KKT_RB(rocblas_set_stream(L->handle, stream));
+    double* d_stat = reinterpret_cast<double*>(L->b_stat);              // (batch_scratch sizes it for 4 n doubles)
+    std::vector<double> h_max(n), bmax(n), prev(n, 1e300), rlast(n, 0.0);
+    std::vector<char> have_prev(n, 0);
+    std::vector<KktWorkspace*> act(ws, ws + n);
+    std::vector<int> idx(n);
+    for (int b = 0; b < n; ++b) idx[b] = b;
+    SolveArrays A;
+    if (int st = solve_arrays(L, stream, sh, n, act.data(), &A, err)) return st;
+    d_stat = reinterpret_cast<double*>(L->b_stat);
+    // mask the right-hand sides as the single path does (fixed variables: 0), |b|, first solve
+    dim3 gN((N + 255) / 256, n);
+    hipLaunchKernelGGL(emi_kkt_vecop_b_kernel, gN, dim3(256), 0, stream, (const KktDev*)A.d_tab, N, 0);                 // rhs <- bb
+    hipLaunchKernelGGL(emi_kkt_mask_rhs_b_kernel, dim3((sh.nz + 255) / 256, n), dim3(256), 0, stream, (const KktDev*)A.d_tab, sh.nz, N);
+    hipLaunchKernelGGL(emi_kkt_absmax_b_kernel, dim3(n), dim3(256), 0, stream, (const KktDev*)A.d_tab, N, 0, d_stat);    // max |b| (masked)
+    KKT_HIP(hipMemcpyAsync(bmax.data(), d_stat, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
+    // (bb itself stays unmasked in the fixed slots; the residual kernels mask their result, so those entries never matter)
+    if (int st = solve_core(L, stream, sh, n, act.data(), A, err)) return st;
+    hipLaunchKernelGGL(emi_kkt_vecop_b_kernel, gN, dim3(256), 0, stream, (const KktDev*)A.d_tab, N, 1);                 // xx <- rhs
+    for (int b = 0; b < n; ++b) nsolve[b] = 1;
+    for (int ir = 0; ir <= max_steps; ++ir) {
+        const int na = (int)act.size();
+        if (na == 0) break;
+        double dcn = dc_nominal[idx[0]];
+        bool same_dc = true;
+        for (int a = 1; a < na; ++a) same_dc = same_dc && dc_nominal[idx[a]] == dcn;
+        if (same_dc) {
+            if (int st = residual_core(L, stream, sh, na, A, dcn, d_stat, err)) return st;
+        } else {                                                        // (different nominal dc in one batch: one scenario at a time)
+            for (int a = 0; a < na; ++a) {
+                SolveArrays A1;
+                KktWorkspace* one_ws = act[a];
+                KKT_HIP(hipStreamSynchronize(stream));
+                if (int st = solve_arrays(L, stream, sh, 1, &one_ws, &A1, err)) return st;
+                if (int st = residual_core(L, stream, sh, 1, A1, dc_nominal[idx[a]], d_stat + a, err)) return st;
+            }
+            KKT_HIP(hipStreamSynchronize(stream));
+            if (int st = solve_arrays(L, stream, sh, na, act.data(), &A, err)) return st;
+        }
+        KKT_HIP(hipMemcpyAsync(h_max.data(), d_stat, (size_t)na * sizeof(double), hipMemcpyDeviceToHost, stream));
+        KKT_HIP(hipStreamSynchronize(stream));
+        std::vector<KktWorkspace*> next;
+        std::vector<int> next_idx, revert;
+        for (int a = 0; a < na; ++a) {
+            const int b = idx[a];
+            const double rmax = h_max[a];
+            if (ir == 0 && !std::isfinite(rmax)) { status[b] = 2; rlast[b] = rmax; continue; }
+            if (have_prev[b] && !(rmax < prev[b])) {                     // the last correction did harm: undo it and stop
+                revert.push_back(a);
+                reverted[b] = 1;
+                rlast[b] = prev[b];
+                continue;
+            }
+            rlast[b] = rmax;
+            if (ir == max_steps || !(rmax > 1e-14 * std::max(1.0, bmax[b])) || !(rmax < 0.5 * prev[b])) continue;
+            prev[b] = rmax;
+            next.push_back(act[a]);
+            next_idx.push_back(b);
+        }
+        if (!revert.empty()) {                                           // xx <- xp for those (their own small table)
+            std::vector<KktWorkspace*> rv;
+            for (int a : revert) rv.push_back(act[a]);
+            SolveArrays Ar;
+            if (int st = solve_arrays(L, stream, sh, (int)rv.size(), rv.data(), &Ar, err)) return st;
+            hipLaunchKernelGGL(emi_kkt_vecop_b_kernel, dim3((N + 255) / 256, (unsigned)rv.size()), dim3(256), 0, stream, (const KktDev*)Ar.d_tab, N, 3);
+            KKT_HIP(hipGetLastError());
+            KKT_HIP(hipStreamSynchronize(stream));
+        }
+        act.swap(next);
+        idx.swap(next_idx);
+        const int nc = (int)act.size();
+        if (nc == 0) break;
+        if (int st = solve_arrays(L, stream, sh, nc, act.data(), &A, err)) return st;
+        dim3 gc((N + 255) / 256, nc);
+        hipLaunchKernelGGL(emi_kkt_vecop_b_kernel, gc, dim3(256), 0, stream, (const KktDev*)A.d_tab, N, 2);             // xp <- xx
+        if (int st = solve_core(L, stream, sh, nc, act.data(), A, err)) return st;                                      // rhs (= r) <- K~^-1 r
+        hipLaunchKernelGGL(emi_kkt_vecop_b_kernel, gc, dim3(256), 0, stream, (const KktDev*)A.d_tab, N, 4);             // xx += correction
+        KKT_HIP(hipGetLastError());
+        for (int a = 0; a < nc; ++a) { ++nsolve[idx[a]]; have_prev[idx[a]] = 1; }
+    }
+    for (int b = 0; b < n; ++b) {
+        rel[b] = rlast[b] / std::max(1.0, bmax[b]);
+        KKT_HIP(hipMemcpyAsync(rhs[b], ws[b]->ref_x, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, stream));
     }
     KKT_HIP(hipStreamSynchronize(stream));
     return EMI_OK;

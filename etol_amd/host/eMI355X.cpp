@@ -122,6 +122,12 @@ struct eMI355X::Device : public mi355x::NlpEvaluator, public mi355x::KktBackend 
     }
     int solve(double* rhs, int nrhs) override { return emi_kkt_solve(ctx, rhs, nrhs) == EMI_OK ? 0 : -1; }
     void applied_regularisation(double* dc, double* dw) override { (void)emi_kkt_last_regularisation(ctx, dc, dw); }
+    int solve_refined(double* rhs, double dc_nominal, int max_steps, double* rel, int* nsolve, int* reverted) override {
+        int status = 0;
+        const int st = emi_kkt_solve_refined(ctx, rhs, dc_nominal, max_steps, rel, nsolve, reverted, &status);
+        if (st == EMI_ERR_UNSUPPORTED) return 1;          // LU fallback: the host loop refines around solve()
+        return st == EMI_OK ? status : -1;
+    }
     std::string last_error() const override { return ctx ? emi_last_error(ctx) : "no device context"; }
 };
 
@@ -132,13 +138,15 @@ namespace mi355x {
 
 struct KktBatcher::Impl {
     struct Req {
-        int op = 0;                                 // 0 factor, 1 solve (one right-hand side)
+        int op = 0;                                 // 0 factor, 1 solve (one right-hand side), 2 solve with the refinement on the device
         emi_ctx_t ctx = nullptr;
         int nodes = 0;
         const double *Q = nullptr, *J = nullptr;
         const unsigned char* fixed = nullptr;
         double dc = 0;
         double* rhs = nullptr;
+        double rel = 0;                             // op 2 (refined solve): relative residual, solves used, a correction was taken back
+        int nsolve = 0, reverted = 0;
         int result = -1;
         bool done = false;
         std::chrono::steady_clock::time_point posted;
@@ -188,13 +196,40 @@ static void run_batch(KktBatcher* B, std::vector<KktBatcher::Impl::Req*>& take) 
             for (int b = 0; b < n; ++b) take[i + b]->result = st == EMI_OK ? info[b] : -1;
             ++B->factor_calls;
             B->factor_items += n;
-        } else {
+        } else if (take[i]->op == 1) {
             std::vector<double*> rhs(n);
             for (int b = 0; b < n; ++b) rhs[b] = take[i + b]->rhs;
             const int st = n == 1 ? emi_kkt_solve(ctxs[0], rhs[0], 1) : emi_kkt_solve_batch(n, ctxs.data(), rhs.data());
             for (int b = 0; b < n; ++b) take[i + b]->result = st == EMI_OK ? 0 : -1;
             ++B->solve_calls;
             B->solve_items += n;
+        } else {
+            // refined solves: the scenarios whose factorisation is the LU fallback answer "not offered" (1) and refine on the host
+            std::vector<double*> rhs;
+            std::vector<double> dcn, rel;
+            std::vector<emi_ctx_t> cs;
+            std::vector<int> which;
+            for (int b = 0; b < n; ++b) {
+                double d0 = 0, d1 = 0;
+                if (emi_kkt_last_regularisation(ctxs[b], &d0, &d1) == EMI_OK && emi_kkt_is_schur(ctxs[b])) {
+                    which.push_back(b); cs.push_back(ctxs[b]); rhs.push_back(take[i + b]->rhs); dcn.push_back(take[i + b]->dc);
+                } else {
+                    take[i + b]->result = 1;
+                }
+            }
+            const int m = (int)which.size();
+            if (m > 0) {
+                rel.assign(m, 0.0);
+                std::vector<int> nsv(m, 0), rev(m, 0), stat(m, 0);
+                const int st = emi_kkt_solve_refined_batch(m, cs.data(), rhs.data(), dcn.data(), 8, rel.data(), nsv.data(), rev.data(), stat.data());
+                for (int a = 0; a < m; ++a) {
+                    KktBatcher::Impl::Req* q = take[i + which[a]];
+                    q->result = st == EMI_OK ? stat[a] : -1;
+                    q->rel = rel[a]; q->nsolve = nsv[a]; q->reverted = rev[a];
+                }
+                ++B->solve_calls;
+                B->solve_items += m;
+            }
         }
         B->largest_batch = std::max(B->largest_batch, n);
         i = j;
@@ -253,6 +288,14 @@ struct BatchedKkt : public mi355x::KktBackend {
         mi355x::KktBatcher::Impl::Req r;
         r.op = 1; r.ctx = ctx; r.nodes = nodes; r.rhs = rhs;
         return mi355x::submit(B, r);
+    }
+    int solve_refined(double* rhs, double dc_nominal, int max_steps, double* rel, int* nsolve, int* reverted) override {
+        (void)max_steps;
+        mi355x::KktBatcher::Impl::Req r;
+        r.op = 2; r.ctx = ctx; r.nodes = nodes; r.rhs = rhs; r.dc = dc_nominal;
+        const int rc = mi355x::submit(B, r);
+        *rel = r.rel; *nsolve = r.nsolve; *reverted = r.reverted;
+        return rc;
     }
     void applied_regularisation(double* dc, double* dw) override { direct->applied_regularisation(dc, dw); }
     std::string last_error() const override { return direct->last_error(); }

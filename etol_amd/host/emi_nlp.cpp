@@ -1132,6 +1132,31 @@ NlpResult solve_nlp(const NlpProblem& P, const NlpOptions& opt, const std::vecto
             build_rhs(rhs_full.data(), eqres.data());
             std::copy(rhs_full.begin(), rhs_full.begin() + NN, rhs_keep.begin());
             const auto ts0 = now();
+            // a backend that refines on its own (the device: residuals and corrections never leave HBM) ...
+            double rel_dev = 0.0;
+            int ns_dev = 0, rev_dev = 0;
+            const int rr = kkt->solve_refined(rhs_full.data(), dc, 8, &rel_dev, &ns_dev, &rev_dev);
+            if (rr == 0 || rr == 2) {
+                R.t_solve += secs(ts0, now());
+                R.n_solve += ns_dev;
+                if (rr == 2) { dc = dc == 0.0 ? 1e-8 * std::pow(mu, 0.25) : dc * 100.0; continue; }
+                bool fin = true;
+                for (size_t r = 0; r < NN && fin; ++r) fin = std::isfinite(rhs_full[r]);
+                if (!fin) { dc = dc == 0.0 ? 1e-8 * std::pow(mu, 0.25) : dc * 100.0; continue; }
+                double dc_applied = dc, dw_applied = 0.0;
+                kkt->applied_regularisation(&dc_applied, &dw_applied);
+                const bool shifted = dw_applied > 0.0 || dc_applied > std::max(dc, 1e-9) * 1.0001;
+                if (shifted) ++R.n_backend_shifted;
+                R.n_refine_reverted += rev_dev;
+                R.worst_step_residual = std::max(R.worst_step_residual, rel_dev);
+                if (opt.print_level >= 5 && shifted && rel_dev > 1e-6)
+                    printf("          backend factorised with dc %.1e dw %.1e; step used with relative residual %.2e\n", dc_applied, dw_applied, rel_dev);
+                if (exact_step) dw = dw_shift;
+                factored = true;
+                break;
+            }
+            if (rr < 0) { R.msg = "KKT solve failed: " + kkt->last_error(); return R; }
+            // ... otherwise: solve, then refine against the host's own matrix-vector product
             const int sst = kkt->solve(rhs_full.data(), 1);
             R.t_solve += secs(ts0, now());
             ++R.n_solve;

@@ -50,6 +50,14 @@ class KktBackend {
     // correction kept by the backend), otherwise for K~.  r = 0 clears.  0 on success.
     virtual int lowrank(int r, const int* node, const double* vec, const double* delta, bool* exact) = 0;
     virtual int solve(double* rhs, int nrhs) = 0;   // rhs [nrhs][nz+md], in place; 0 on success
+    // The step with its iterative refinement done by the backend (against the nominal matrix with dual regularisation dc_nominal,
+    // exact or convexified as the last lowrank() verdict says): rhs [nz+md] in place.  Returns 0 done (rel = final relative residual,
+    // nsolve = solves used, reverted = a correction was taken back), 2 the first solution is not finite, < 0 failure,
+    // 1 not offered by this backend (the caller refines around solve()).
+    virtual int solve_refined(double* rhs, double dc_nominal, int max_steps, double* rel, int* nsolve, int* reverted) {
+        (void)rhs; (void)dc_nominal; (void)max_steps; (void)rel; (void)nsolve; (void)reverted;
+        return 1;
+    }
     // what the last factor() really factorised: [[Q + dw I_x, J^T], [J, -dc I]] (dw on the free state variables).  A backend
     // that never regularises on its own leaves both untouched (the caller presets them to its nominal dc and 0).
     virtual void applied_regularisation(double* dc, double* dw) { (void)dc; (void)dw; }

@@ -255,6 +255,25 @@ int emi_kkt_factor_batch(int n, const emi_ctx_t* ctxs, const double* const* Qblk
 /* one right-hand side [N] per scenario, in place (host pointers); low-rank
  * corrections of the scenarios that hold one are applied                          */
 int emi_kkt_solve_batch(int n, const emi_ctx_t* ctxs, double* const* rhs);
+/* 1 if the context holds a factorisation of the Schur path (what the batched and refined solves take), else 0 */
+int emi_kkt_is_schur(emi_ctx_t ctx);
+/* The Newton step WITH its iterative refinement on the device: x = K~^-1 b, then
+ * up to max_steps rounds of  r = b - K x,  x += K~^-1 r  against the NOMINAL
+ * matrix K -- the node blocks and dc_nominal the caller handed emi_kkt_factor
+ * (the factorisation may hold a regularised matrix: emi_kkt_last_regularisation),
+ * minus the low-rank term while emi_kkt_lowrank reported "exact".  A round stops
+ * when the residual is at round-off or no longer halves; a correction that made
+ * the residual worse is taken back.  Only residual norms cross to the host.  Out:
+ * rel = final max|r| / max(1, max|b|), nsolve = solves with the factors used,
+ * reverted = 1 if the last correction was taken back, status = 0 ok / 2 the first
+ * solution is not finite.  Schur-path factorisations only (EMI_ERR_UNSUPPORTED
+ * otherwise: refine around emi_kkt_solve).  What IPOPT's own iterative refinement
+ * does behind ePSOPT (reference src/ePSOPT/ePSOPT.cpp:62-66).                     */
+int emi_kkt_solve_refined(emi_ctx_t ctx, double* rhs, double dc_nominal, int max_steps,
+                          double* rel, int* nsolve, int* reverted, int* status);
+int emi_kkt_solve_refined_batch(int n, const emi_ctx_t* ctxs, double* const* rhs,
+                                const double* dc_nominal, int max_steps, double* rel,
+                                int* nsolve, int* reverted, int* status);
 /* What the last emi_kkt_factor really factorised: [[Q + dw I_x, J^T], [J, -dc I]]
  * with dw on the diagonal of the free STATE variables.  dc >= the caller's and
  * dw >= 0; they exceed the nominal (dc, 0) when the Schur path had to climb its

@@ -438,3 +438,73 @@ def test_batched_factor_and_solve_match_numpy_and_the_single_path(built, M, mode
         ev.close()
     for ev in evs:
         ev.close()
+
+
+@pytest.mark.parametrize("M,n", [(65, 1), (200, 3), (256, 4)])
+def test_refined_solves_on_the_device_reach_round_off_in_the_nominal_matrix(built, M, n):
+    """emi_kkt_solve_refined(_batch): the Newton step with its iterative refinement done on the device (residual r = b - K x with the
+    nominal node blocks, the D operator as two batched GEMMs, the low-rank term of the scenarios whose correction is active; only
+    the residual norms cross to the host).  Against numpy: the returned x solves the NOMINAL matrix to round-off although the
+    factorisation holds dc = 1e-9 more than the nominal 0 in one scenario; rel reports the residual honestly."""
+    import ctypes as C
+    import etol_amd as E
+    from etol_amd import _lib as L
+    from etol_amd import workloads as W
+    lib = L.load()
+    ns, nv = 6, 8
+    N = (2 * ns + 2) * M
+    rng = np.random.default_rng(9100 + M)
+    evs, probs = [], []
+    for b in range(n):
+        ev = E.Evaluator(0)
+        ev.set_mesh(M, 0.0, 4.0)
+        ev.set_model(1, W.QUAD_PARAMS)
+        ev.set_batch(1)
+        evs.append(ev)
+        probs.append(_random_kkt(ev, M, ns, nv, rng))
+    dcs = np.array([1e-9, 0.0, 1e-8, 1e-9][:n])
+    D = C.POINTER(C.c_double)
+    dp = lambda a: a.ctypes.data_as(D)
+    ctxs = (C.c_void_p * n)(*[ev.ctx for ev in evs])
+    for b in range(n):
+        assert evs[b].kkt_factor(*probs[b], dc=max(dcs[b], 0.0)) == 0
+    lr = None
+    if n >= 3:          # scenario 2: an active low-rank correction (K = K~ - d u u^T)
+        node, vec, delta = np.array([M // 3], dtype=np.int32), rng.standard_normal((1, nv)) * 0.3, np.array([0.5])
+        assert evs[2].kkt_lowrank(node, vec, delta)
+        lr = (node, vec, delta)
+    rhs = [rng.standard_normal(N) for _ in range(n)]
+    work = [r.copy() for r in rhs]
+    Rp = (D * n)(*[dp(w) for w in work])
+    rel = np.zeros(n)
+    nsv, rev, stat = (np.zeros(n, dtype=np.int32) for _ in range(3))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    st = lib.emi_kkt_solve_refined_batch(n, ctxs, Rp, dp(dcs), 8, dp(rel), ip(nsv), ip(rev), ip(stat))
+    assert st == 0, lib.emi_last_error(evs[0].ctx)
+    assert np.all(stat == 0) and np.all(nsv >= 1)
+    for b in range(n):
+        K = dense_kkt(evs[b].D, probs[b][0], probs[b][1], probs[b][2], dcs[b], M, ns, nv)      # the NOMINAL matrix
+        if lr is not None and b == 2:
+            u = np.zeros(N)
+            u[np.arange(nv) * M + lr[0][0]] = lr[1][0]
+            u[np.nonzero(probs[b][2])[0]] = 0
+            K -= lr[2][0] * np.outer(u, u)
+        ref = rhs[b].copy()
+        ref[np.nonzero(probs[b][2])[0]] = 0
+        res = np.abs(K @ work[b] - ref).max() / max(1.0, np.abs(ref).max())
+        assert res < 1e-11, (b, res, rel[b], nsv[b])
+        assert abs(res - rel[b]) < 1e-11            # what the device reports is what numpy sees
+        x = np.linalg.solve(K, ref)
+        assert np.abs(x - work[b]).max() < 1e-8 * (np.abs(x).max() + 1)
+    # the single entry point
+    w1 = rhs[0].copy()
+    r1, n1, v1, s1 = C.c_double(), C.c_int(), C.c_int(), C.c_int()
+    assert lib.emi_kkt_solve_refined(evs[0].ctx, dp(w1), float(dcs[0]), 8, C.byref(r1), C.byref(n1), C.byref(v1), C.byref(s1)) == 0
+    assert np.abs(w1 - work[0]).max() < 1e-12 * (np.abs(w1).max() + 1)
+    # an LU factorisation is not offered: EMI_ERR_UNSUPPORTED (5)
+    evs[0].set_option("kkt_method", 0)
+    assert evs[0].kkt_factor(*probs[0], dc=1e-9) == 0
+    assert lib.emi_kkt_is_schur(evs[0].ctx) == 0
+    assert lib.emi_kkt_solve_refined(evs[0].ctx, dp(w1), 1e-9, 8, C.byref(r1), C.byref(n1), C.byref(v1), C.byref(s1)) == 5
+    for ev in evs:
+        ev.close()
