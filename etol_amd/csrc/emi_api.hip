@@ -83,6 +83,7 @@ struct emi_ctx_s {
     DevBuf d_ticket;            // [B] arrival counters of the in-kernel COST finish (zeroed once, self-resetting)
     bool cost_in_kernel = true; // "cost_in_kernel": the node kernel of the overlapped pass finishes COST itself (ticket), no emi_cost_finish_kernel
     int sym_nst = 3;            // "sym_nst": ring stages of the one-launch pass (3 or 4)
+    int sym_bk = 0;             // "sym_bk": depth of a K tile of the one-launch pass (8 or 16; 0: by batch size, plan_pass)
     // delayed values (emi_set_delays): x_horizon - 1 delayed copies of every state and u_horizon of every control, appended to the
     // controls the node functions see: nc = nc_free + nch; W[d] = interpolation matrix of delay (d + 1) dt on this mesh
     int xh = 0, uh = 0, nch = 0;
@@ -277,6 +278,9 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
         plan.ks = 1;
     }
     plan.nst = c->rtc ? 3 : c->sym_nst;
+    // K tiles of 16 (built-in models, SW 1 or 2, three stages, unsplit): "sym_bk" 16 forces them
+    const int bk_want = c->sym_bk ? c->sym_bk : 8;
+    if (bk_want == 16 && !c->rtc && plan.ks == 1 && (plan.sw == 1 || plan.sw == 2) && plan.nst == 3) plan.bk = 16;
     p.sym = plan;
     p.mfma_first = c->pass_order >= 0 ? c->pass_order
                                       : (p.tiles16 < 208 ? 1 : (p.tiles16 < 384 ? 125 : (p.tiles16 < 768 ? 110 : 0)));
@@ -958,7 +962,8 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             if (plv) HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
             if (pe) pe->level = -1;                 // one bracket: the pass kernel
             c->last_defect_kernel = "emi_pass_f64_kernel<SW=" + std::to_string(plan.sw) + "> (MFMA + node roles, one launch" +
-                                    (plan.ks > 1 ? ", " + std::to_string(plan.ks) + " K slices per tile" : "") + ")";
+                                    (plan.ks > 1 ? ", " + std::to_string(plan.ks) + " K slices per tile" : "") + ")" +
+                                    (plan.bk == 16 ? " [K tiles of 16]" : "");
             return EMI_OK;
         }
         const bool two = c->overlap_mode != 1;
@@ -1473,6 +1478,11 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         c->sym_nst = value;
         return EMI_OK;
     }
+    if (strcmp(name, "sym_bk") == 0) {
+        if (value != 0 && value != 8 && value != 16) return fail(c, EMI_ERR_ARG, "sym_bk must be 0 (by batch size), 8 or 16");
+        c->sym_bk = value;
+        return EMI_OK;
+    }
     if (strcmp(name, "sym_cpart") == 0) {
         if (value != -1 && value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, EMI_ERR_ARG, "sym_cpart must be -1 (plain order), 0 (by mesh size), 1, 2, 4 or 8");
         c->sym_cpart = value;
@@ -1523,6 +1533,7 @@ int emi_plan_pass(emi_ctx_t c, int B, emi_pass_plan_t* out) {
         out->sw = p.sym.sw;
         out->ksplit = p.sym.ks;
         out->ring_stages = p.sym.nst;
+        out->k_tile = p.sym.bk;
         out->cpart = p.sym.cpart;
         out->cx = p.sym.cx;
         out->mfma_workgroups = p.sym.tiles * p.sym.ks;

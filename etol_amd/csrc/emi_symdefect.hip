@@ -99,10 +99,11 @@ static hipError_t launch_ring2_model(const SymDefectArgs& a, hipStream_t s) {
 //   fewer (the shard of config 4: 128 instances = 64 tiles for 256 CUs): SW = 1 (<= 96 tiles) or 2, i.e. more workgroups
 //      than CUs (0.055 ms at 128 instances; SW = NS with 4 K slices, the choice before the K loop was software-pipelined: 0.089).
 // ct 5 / 6 / 7 / 8 force SW = NS / 2 / 1 / 3; ksplit_opt > 0 forces the slice count.
-SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_opt, int gblk_opt, int cx_opt) {
+SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_opt, int gblk_opt, int cx_opt, int bk_opt) {
     SymPlan p;
+    p.bk = bk_opt == 16 ? 16 : 8;
     const int tiles = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64);
-    const int nkt = (M / 2) / 8;
+    const int nkt = (M / 2) / p.bk;
     if (ct == 0 || ct == 4) {
         if (tiles >= 448) p.sw = (ns % 2 == 0 && ns > 2) ? 2 : ns;
         else if (tiles >= 320) p.sw = ns;
@@ -161,7 +162,7 @@ static hipError_t launch_ring2_planned(const SymDefectArgs& a, hipStream_t s, co
 
 // ---------------------------------------------------------------------------------------------
 // the pass as one launch (emi_pass_f64_kernel): MFMA-role and node-role workgroups interleaved per XCD
-template <class Model, int SW, int NST>
+template <class Model, int SW, int NST, int BK = 8>
 static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<double>& na, hipStream_t s) {
     constexpr int NS = Model::NS;
     PassArgs a;
@@ -175,11 +176,11 @@ static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<doub
     a.nn = nn;
     a.nm8 = (nm + 7) / 8;
     a.nn8 = (nn + 7) / 8;
-    const size_t lds = (size_t)NST * ((2 * SW * FUSED_TI + 2 * 64 + 63) / 64 * 64) * 8 * sizeof(double);
+    const size_t lds = (size_t)NST * ((2 * SW * FUSED_TI + 2 * 64 + 63) / 64 * 64) * BK * sizeof(double);
     static bool attr_done[4] = {false, false, false, false};
     const int st = (na.store_mode >= 0 && na.store_mode <= 3) ? na.store_mode : 0;   // result stores: plain / sc1 (write-through) / non-temporal / nt sc1
-    auto kern = st == 2 ? emi_pass_f64_kernel<Model, SW, 2, 2, NST>
-              : (st == 1 ? emi_pass_f64_kernel<Model, SW, 2, 1, NST> : (st == 3 ? emi_pass_f64_kernel<Model, SW, 2, 3, NST> : emi_pass_f64_kernel<Model, SW, 2, 0, NST>));
+    auto kern = st == 2 ? emi_pass_f64_kernel<Model, SW, 2, 2, NST, BK>
+              : (st == 1 ? emi_pass_f64_kernel<Model, SW, 2, 1, NST, BK> : (st == 3 ? emi_pass_f64_kernel<Model, SW, 2, 3, NST, BK> : emi_pass_f64_kernel<Model, SW, 2, 0, NST, BK>));
     if (!attr_done[st]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -194,11 +195,13 @@ static hipError_t launch_pass_planned(const SymDefectArgs& sa, const NodeArgs<do
     constexpr int NS = Model::NS;
     if (p.sw == NS) return launch_pass_model<Model, NS, 3>(sa, na, s);
     if constexpr (NS > 2 && NS % 2 == 0) {
+        if (p.sw == 2 && p.bk == 16) return launch_pass_model<Model, 2, 3, 16>(sa, na, s);
         if (p.sw == 2) return p.nst > 3 ? launch_pass_model<Model, 2, 4>(sa, na, s) : launch_pass_model<Model, 2, 3>(sa, na, s);
     }
     if constexpr (NS > 3 && NS % 3 == 0) {
         if (p.sw == 3) return launch_pass_model<Model, 3, 3>(sa, na, s);
     }
+    if (p.bk == 16) return launch_pass_model<Model, 1, 3, 16>(sa, na, s);
     return p.nst > 3 ? launch_pass_model<Model, 1, 4>(sa, na, s) : launch_pass_model<Model, 1, 3>(sa, na, s);
 }
 

@@ -358,6 +358,11 @@ __global__ __launch_bounds__(256, 2) void emi_symdefect_ring_f64_kernel(SymDefec
 // 16-lane groups of a ds_read_b128 then covers a 256-byte bank row exactly once (MI355X_MICROARCH.md, LDS).
 // ---------------------------------------------------------------------------------------------
 EMI_DEV constexpr int ring_swz(int r) { return (0 - (r >> 2)) & 3; }
+// The same for K tiles of depth BK (rows of BK doubles = BK / 2 sixteen-byte chunks): the sixteen rows r .. r + 15 a lane group of a
+// ds_read_b128 touches at one logical chunk must land on sixteen different 16-byte bank slots of a 256-byte bank row.  BK = 8 (64-byte
+// rows, four to a bank row): the chunk position changes every four rows, ring_swz above.  BK = 16 (128-byte rows, two to a bank row):
+// it changes every two rows, eight positions.
+template <int BK> EMI_DEV constexpr int ring_swz_k(int r) { return BK == 8 ? ring_swz(r) : ((r >> 1) & 7); }
 
 // defect = D.X - h f at the tile's output nodes: forward node i (a + b) and mirrored node N-i (b - a), states
 // S0 .. S0+SW-1; lane (r16, kq) of wave wid holds half-index column 16 wid + r16 and instances kq + 4 i.
@@ -478,13 +483,20 @@ EMI_DEV void ring_epilogue(const SymDefectArgs& a, const d4 (&acc_a)[SW], const 
 // a.ksplit > 1: the K range of a tile is cut into ksplit slices, one workgroup each (a shard of config 4 has 64
 // tiles for 256 CUs); a slice leaves its partial sums in a.slab[tile][slice][2 SW][4][256 threads] and
 // emi_symdefect_combine_kernel adds the slices IN SLICE ORDER (bitwise reproducible) and runs the epilogue.
-template <class Model, int SW, int NST = 3>
+// BK = 16 (round 4): K tiles twice as deep -- half as many barriers, counted waits and ring bookkeeping per flop, twice the bytes in
+// flight per stage.  A pass of a small batch (the 128-instance shard of config 4) is the MFMA role's dependency chain of K tiles, and
+// with one state per workgroup a tile holds only four MFMAs (256 matrix-pipe cycles) against several hundred cycles of per-tile
+// work (profiles/r03_notes.md section 7: ~0.3 us per tile); the deep form halves the number of tiles.
+template <class Model, int SW, int NST = 3, int BK = 8>
 EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-slice id, XCD-local runs */) {
     constexpr int NS = Model::NS;
-    constexpr int TI = FUSED_TI, TM = SW * TI, TN = 64, BK = 8, CH = 4, NSG = NS / SW;
+    constexpr int TI = FUSED_TI, TM = SW * TI, TN = 64, CH = BK / 2, NSG = NS / SW;
+    constexpr int KH = BK / 8;                           // 16-byte fragment reads per operand row and K tile (each: two k-steps)
+    constexpr int RPI = 64 / CH;                         // rows one DMA wave instruction moves (1 KB)
+    static_assert(BK == 8 || BK == 16, "K tiles of 8 or 16");
     constexpr int LOOK = NST - 1;                        // K tiles in flight ahead of the one being multiplied
     constexpr int ROWS = 2 * TM + 2 * TN;
-    constexpr int ROWS_PAD = (ROWS + 63) / 64 * 64;      // a DMA wave instruction moves 16 rows: 4 waves x 16 rows
+    constexpr int ROWS_PAD = (ROWS + 63) / 64 * 64;      // a DMA wave instruction moves RPI rows: whole instructions for 4 waves
     constexpr int STAGE = ROWS_PAD * BK;                 // doubles per ring stage
     constexpr int L = ROWS_PAD * CH / 256;               // LDS-DMA instructions per wave and stage (1 KB each)
     static_assert(NS % SW == 0, "states split evenly over workgroups");
@@ -522,12 +534,12 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     int gstep[L];                      // wave-uniform: bytes per K tile (+64 forward, -64 mirrored x, 0 padding)
 #pragma unroll
     for (int t = 0; t < L; ++t) {
-        const int row0 = (wid + 4 * t) * 16;           // wave-uniform
-        const int row = row0 + (lane >> 2), p = lane & 3;
+        const int row0 = (wid + 4 * t) * RPI;          // wave-uniform
+        const int row = row0 + lane / CH, p = lane % CH;
         if (row0 < 2 * TM) {
             const bool mir = row0 >= TM;
             const int rr = row - (mir ? TM : 0);
-            const int c = p ^ ring_swz(rr);
+            const int c = p ^ ring_swz_k<BK>(rr);
             int inst = inst0 + (rr & 15);
             inst = inst < B ? inst : B - 1;            // rows past the batch are never written out
             if (a.ablate & 8) inst &= 15;              // diagnostics: every tile reads the first 16 instances (X traffic ~ 0)
@@ -537,7 +549,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         } else if (row0 < ROWS) {
             const bool od = row0 >= 2 * TM + TN;
             const int rr = row - 2 * TM - (od ? TN : 0);
-            const int c = p ^ ring_swz(rr);
+            const int c = p ^ ring_swz_k<BK>(rr);
             voff[t] = (unsigned)(((size_t)((a.ablate & 64) ? rr : i0 + rr) * Hh + 2 * c) * sizeof(double));   // (64: diagnostics, all tiles read the first 64 rows)
             gbase[t] = (unsigned long long)(od ? a.Do : a.De);
             gstep[t] = (int)(BK * sizeof(double));
@@ -588,34 +600,45 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     for (int t = 0; t < LOOK; ++t)
         if (t < nkt) issue();
     // fragment addresses (doubles within a stage): B rows of this wave, A rows of every state
+    // (half h of a deep tile: chunk kq + 4 h forward, k = 8 h + 2 kq, + 1; its mirror sits at position BK - 1 - k of the mirrored
+    // tile, i.e. in chunk CH - 1 - kq - 4 h)
     const int rb = wid * 16 + r16;
-    const int off_b = rb * BK + ((kq ^ ring_swz(rb)) << 1);
-    int off_f[SW], off_m[SW];
+    int off_b[KH], off_f[SW][KH], off_m[SW][KH];
+#pragma unroll
+    for (int h = 0; h < KH; ++h) off_b[h] = rb * BK + (((kq + 4 * h) ^ ring_swz_k<BK>(rb)) << 1);
 #pragma unroll
     for (int s = 0; s < SW; ++s) {
         const int r = s * 16 + r16;
-        off_f[s] = r * BK + ((kq ^ ring_swz(r)) << 1);               // chunk kq: x_(2kq), x_(2kq+1)
-        off_m[s] = (TM + r) * BK + (((3 - kq) ^ ring_swz(r)) << 1);  // chunk 3-kq of the mirrored tile
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+            off_f[s][h] = r * BK + (((kq + 4 * h) ^ ring_swz_k<BK>(r)) << 1);                  // chunk kq + 4h: x_(8h + 2kq), x_(8h + 2kq + 1)
+            off_m[s][h] = (TM + r) * BK + (((CH - 1 - kq - 4 * h) ^ ring_swz_k<BK>(r)) << 1);  // their mirrors
+        }
     }
     // fragments of one K tile: De / Do rows of this wave (B operands) and, per state, the A operands of the even / odd products:
     // sp = forward + mirrored x, dm = forward - mirrored x for the tile's two k-steps.  They are formed when the x fragments have
     // arrived (in the gaps of the PREVIOUS tile's MFMAs), not in front of the MFMA that consumes them: a v_add_f64 directly ahead of
     // its MFMA holds the matrix pipe for the result (the same finding as the shift subtractions of the fp32 kernel, r03_notes.md).
     struct Frag {
-        double2 be, bo, sp[SW], dm[SW];
+        double2 be[KH], bo[KH], sp[SW][KH], dm[SW][KH];
     };
-    double2 txf[SW], txm[SW];                           // x fragments between their read and their sums
-    constexpr int NR = 2 + 2 * SW, NM = 4 * SW;         // fragment reads / MFMAs per wave and K tile
+    double2 txf[SW][KH], txm[SW][KH];                   // x fragments between their read and their sums
+    constexpr int NR = (2 + 2 * SW) * KH, NM = 4 * SW * KH;     // fragment reads / MFMAs per wave and K tile
+    // read r of a tile: half h = r / (2 + 2 SW), then De, Do, and (forward, mirrored) x of every state
     auto read_one = [&](Frag& f, const double* S, int r) {
-        if (r == 0) f.be = *reinterpret_cast<const double2*>(S + 2 * TM * BK + off_b);
-        else if (r == 1) f.bo = *reinterpret_cast<const double2*>(S + (2 * TM + TN) * BK + off_b);
-        else if (r & 1) txm[(r - 2) >> 1] = *reinterpret_cast<const double2*>(S + off_m[(r - 2) >> 1]);
-        else txf[(r - 2) >> 1] = *reinterpret_cast<const double2*>(S + off_f[(r - 2) >> 1]);
+        const int h = r / (2 + 2 * SW), q = r % (2 + 2 * SW);
+        if (q == 0) f.be[h] = *reinterpret_cast<const double2*>(S + 2 * TM * BK + off_b[h]);
+        else if (q == 1) f.bo[h] = *reinterpret_cast<const double2*>(S + (2 * TM + TN) * BK + off_b[h]);
+        else if (q & 1) txm[(q - 2) >> 1][h] = *reinterpret_cast<const double2*>(S + off_m[(q - 2) >> 1][h]);
+        else txf[(q - 2) >> 1][h] = *reinterpret_cast<const double2*>(S + off_f[(q - 2) >> 1][h]);
     };
-    // k = 2kq (+1): forward x_k in xf.x (.y), its mirror x_(N-k) at position 7-k of the mirrored tile: xm.y (.x)
+    // k = 8h + 2kq (+1): forward x_k in xf.x (.y), its mirror x_(N-k) at position BK-1-k of the mirrored tile: xm.y (.x)
     auto sums_one = [&](Frag& f, int s) {
-        f.sp[s] = double2{txf[s].x + txm[s].y, txf[s].y + txm[s].x};
-        f.dm[s] = double2{txf[s].x - txm[s].y, txf[s].y - txm[s].x};
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+            f.sp[s][h] = double2{txf[s][h].x + txm[s][h].y, txf[s][h].y + txm[s][h].x};
+            f.dm[s][h] = double2{txf[s][h].x - txm[s][h].y, txf[s][h].y - txm[s][h].x};
+        }
     };
     auto rd_stage = [&]() -> const double* {            // stage of the next fragment set; moves on
         const double* S = smem + (st_rd >> 3);
@@ -629,12 +652,13 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
 #pragma unroll
         for (int s = 0; s < SW; ++s) sums_one(f, s);
     };
-    // MFMA i of a tile: first the 2 SW MFMAs of the tile's first k-step, then those of the second
+    // MFMA i of a tile: the 2 SW MFMAs of the tile's first k-step, then those of the second, ... (2 KH k-steps; k-step j uses half
+    // j / 2 of the fragments, element j % 2)
     auto mfma_one = [&](const Frag& f, int i) {
-        const int s = (i % (2 * SW)) >> 1;
-        const bool second = i >= 2 * SW, odd = i & 1;
-        if (!odd) acc_a[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(second ? f.sp[s].y : f.sp[s].x, second ? f.be.y : f.be.x, acc_a[s], 0, 0, 0);
-        else      acc_b[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(second ? f.dm[s].y : f.dm[s].x, second ? f.bo.y : f.bo.x, acc_b[s], 0, 0, 0);
+        const int s = (i % (2 * SW)) >> 1, j = i / (2 * SW), h = j >> 1;
+        const bool second = j & 1, odd = i & 1;
+        if (!odd) acc_a[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(second ? f.sp[s][h].y : f.sp[s][h].x, second ? f.be[h].y : f.be[h].x, acc_a[s], 0, 0, 0);
+        else      acc_b[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(second ? f.dm[s][h].y : f.dm[s][h].x, second ? f.bo[h].y : f.bo[h].x, acc_b[s], 0, 0, 0);
     };
     auto multiply = [&](const Frag& f) {
 #pragma unroll
@@ -815,7 +839,7 @@ __global__ __launch_bounds__(256) void emi_symdefect_combine_kernel(SymDefectArg
 #else
 #define EMI_PASS_OCC
 #endif
-template <class Model, int SW, int VEC, int ST, int NST = 3>
+template <class Model, int SW, int VEC, int ST, int NST = 3, int BK = 8>
 __global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs a) {
 #ifdef EMI_ENTRY_PAD_NOPS      // build-time experiment (tools/ab_build.sh): shift the whole instruction stream by 4-byte steps
     asm volatile(".rept " EMI_STR(EMI_ENTRY_PAD_NOPS) "\n\ts_nop 0\n\t.endr" ::: "memory");
@@ -829,7 +853,7 @@ __global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs
         // the MFMA role is the latency chain of a small pass (64 dependent K tiles); the streaming role beside it on the
         // same SIMDs waits on memory most of the time: instruction arbitration goes to the MFMA waves first
         __builtin_amdgcn_s_setprio(3);
-        emi_ring2_body<Model, SW, NST>(a.s, tid);
+        emi_ring2_body<Model, SW, NST, BK>(a.s, tid);
     } else {
         const int nid = xcd * a.nn8 + role.index;
         if (nid >= a.nn) return;

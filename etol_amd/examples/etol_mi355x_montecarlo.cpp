@@ -258,7 +258,7 @@ int main(int argc, char** argv) {
     std::vector<std::shared_ptr<mx::KktBatcher>> batchers;
     for (int g = 0; g < groups; ++g) {
         batchers.push_back(std::make_shared<mx::KktBatcher>());
-        batchers.back()->flush_us = env_int("EMI_MC_FLUSH_US", 300);
+        batchers.back()->flush_us = env_int("EMI_MC_FLUSH_US", 20000);
     }
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;

@@ -138,7 +138,15 @@ namespace mi355x {
 
 struct KktBatcher::Impl {
     struct Req {
-        int op = 0;                                 // 0 factor, 1 solve (one right-hand side), 2 solve with the refinement on the device
+        int op = 0;                                 // 0 factor, 1 solve (one right-hand side), 2 solve with the refinement on the device,
+                                                    // 3 low-rank correction (one scenario after the other on the leader's thread: its kernels
+                                                    // are large, r right-hand sides each, and do not gain from sharing launches -- but many
+                                                    // host threads launching them at once take turns on the runtime's lock)
+        mi355x::KktBackend* direct = nullptr;       // op 3: the scenario's own adapter
+        int lr_r = 0;
+        const int* lr_node = nullptr;
+        const double *lr_vec = nullptr, *lr_delta = nullptr;
+        bool lr_exact = false;
         emi_ctx_t ctx = nullptr;
         int nodes = 0;
         const double *Q = nullptr, *J = nullptr;
@@ -196,6 +204,11 @@ static void run_batch(KktBatcher* B, std::vector<KktBatcher::Impl::Req*>& take) 
             for (int b = 0; b < n; ++b) take[i + b]->result = st == EMI_OK ? info[b] : -1;
             ++B->factor_calls;
             B->factor_items += n;
+        } else if (take[i]->op == 3) {
+            for (int b = 0; b < n; ++b) {
+                KktBatcher::Impl::Req* q = take[i + b];
+                q->result = q->direct->lowrank(q->lr_r, q->lr_node, q->lr_vec, q->lr_delta, &q->lr_exact);
+            }
         } else if (take[i]->op == 1) {
             std::vector<double*> rhs(n);
             for (int b = 0; b < n; ++b) rhs[b] = take[i + b]->rhs;
@@ -281,7 +294,12 @@ struct BatchedKkt : public mi355x::KktBackend {
         return mi355x::submit(B, r);
     }
     int lowrank(int r, const int* node, const double* vec, const double* delta, bool* exact) override {
-        return direct->lowrank(r, node, vec, delta, exact);
+        if (r == 0) return direct->lowrank(r, node, vec, delta, exact);        // (clears the correction: no device work)
+        mi355x::KktBatcher::Impl::Req q;
+        q.op = 3; q.ctx = ctx; q.nodes = nodes; q.direct = direct; q.lr_r = r; q.lr_node = node; q.lr_vec = vec; q.lr_delta = delta;
+        const int rc = mi355x::submit(B, q);
+        *exact = q.lr_exact;
+        return rc;
     }
     int solve(double* rhs, int nrhs) override {
         if (nrhs != 1) return direct->solve(rhs, nrhs);

@@ -23,9 +23,10 @@ namespace mi355x {
 
 // Rendezvous of the Newton steps of CONCURRENT solves on one device (a Monte-Carlo batch: one host thread and one eMI355X per
 // scenario in flight, BASELINE configs[3]).  Solvers that share a batcher hand their factorisations and single-right-hand-side
-// solves to it instead of launching them themselves; whichever worker finds every member waiting (or has waited `flush_us`) runs
-// what has gathered as ONE batched call (emi_kkt_factor_batch / emi_kkt_solve_batch: every launch carries all scenarios of one mesh
-// size) and hands the answers back.  The iteration of each scenario is untouched -- same matrices, same steps, its own factors --
+// solves to it instead of launching them themselves; whichever worker finds every member waiting (or the oldest request older than
+// `flush_us`) runs what has gathered as ONE batched call (emi_kkt_factor_batch / emi_kkt_solve_refined_batch: every launch carries
+// all scenarios of one mesh size) and hands the answers back.  The members of a batcher therefore move in step, one Newton iteration
+// per round; with two or three batchers one group's batch runs on the device while the others do their host work.  The iteration of each scenario is untouched -- same matrices, same steps, its own factors --
 // only the launches are shared.  A worker thread joins before its first solve() and leaves after its last (Member guard).
 class KktBatcher {
  public:
@@ -36,7 +37,8 @@ class KktBatcher {
         ~Member();
         std::shared_ptr<KktBatcher> batcher;
     };
-    int flush_us = 300;                             // a request older than this is run with whatever has gathered
+    int flush_us = 20000;                           // a request older than this is run with whatever has gathered (a member in a long
+                                                    // host phase -- setting up its next scenario -- must not hold the others for good)
     // totals, for reports: batched calls, scenarios they carried, largest batch
     long factor_calls = 0, factor_items = 0, solve_calls = 0, solve_items = 0;
     int largest_batch = 0;

@@ -300,6 +300,7 @@ typedef struct emi_pass_plan {
   int block_order;     /* 1 MFMA workgroups first, 0 evenly interleaved, >= 100: MFMA workgroups at that % of the even density */
   int tiles16;         /* 16-instance x 128-node tiles of the (first) launch */
   int piece, tail;     /* > 0: the batch goes out in launches of `piece` instances and a last one of `tail` (0: none) */
+  int k_tile;          /* depth of a K tile of the MFMA role: 8 or 16 */
 } emi_pass_plan_t;
 int emi_plan_pass(emi_ctx_t ctx, int B, emi_pass_plan_t* out);
 

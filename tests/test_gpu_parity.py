@@ -658,6 +658,52 @@ def test_every_mfma_defect_kernel_variant_matches_the_oracle(built, sym_ct, shap
     ev.close()
 
 
+@pytest.mark.parametrize("shape", [(1024, 128), (1024, 19), (128, 40), (384, 33), (2048, 16), (1024, 512)])
+def test_deep_k_tiles_of_the_mfma_role_match_the_oracle(built, shape):
+    """"sym_bk" 16: K tiles of 16 instead of 8 in the MFMA role of the one-launch pass (half as many barriers and counted waits per
+    flop; 128-byte operand rows, eight chunks, their own swizzle; two ds_read_b128 per operand row and tile; mirrored chunks 7 - kq
+    and 3 - kq).  SW = 1 and SW = 2, every store flavour, tile orders, against the oracle and -- same sums in another order of
+    the k-steps? no: the k terms of a row are added in the SAME order, tile after tile, so the defect rows must be BITWISE those of
+    the 8-deep form."""
+    import etol_amd as E
+    M, B = shape
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 9.0)
+    ev.set_model(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS)
+    ev.set_batch(B)
+    X, U, recs = cases.W.quadrotor_batch(29, B, M, 3)
+    ev.set_path(recs[:1], 0, 1)
+    ref = O.evaluate(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, 9.0, X, U, recs[:1])
+    c = dict(X=X)
+    ev.set_option("overlap_mode", 3)
+    for sym_ct in (7, 6):
+        ev.set_option("sym_ct", sym_ct)
+        ev.set_option("sym_ksplit", 1)
+        ev.set_option("sym_bk", 8)
+        base = ev.eval_host(X, U)
+        assert "one launch" in ev.last_defect_kernel and "K tiles of 16" not in ev.last_defect_kernel
+        check(c, ev, base, ref)
+        ev.set_option("sym_bk", 16)
+        assert ev.plan(B)["k_tile"] == 16
+        for store in (0, 2, 1, 3):
+            ev.set_option("node_store", store)
+            for cpart, gblk in ((0, 0), (-1, 0), (2, 0), (0, 2)):
+                ev.set_option("sym_cpart", cpart)
+                ev.set_option("sym_gblk", gblk)
+                poison = ev.eval_host(X + 1.0, U)
+                got = ev.eval_host(X, U)
+                assert "K tiles of 16" in ev.last_defect_kernel, ev.last_defect_kernel
+                check(c, ev, got, ref)
+                assert not np.array_equal(poison[0], got[0])
+                # k-steps in another grouping: (0,2,4,6 | 1,3,5,7) per 8 against (0,2,4,6 | 1,3,5,7 | 8,.. | 9,..) per 16 -- the same
+                # sequence of additions per accumulator, hence the same bits
+                assert np.array_equal(got[0], base[0]), (sym_ct, store, cpart, gblk)
+        ev.set_option("node_store", -1)
+        ev.set_option("sym_cpart", 0)
+        ev.set_option("sym_gblk", 0)
+    ev.close()
+
+
 @pytest.mark.parametrize("shape", [(1024, 40), (2048, 24), (512, 72), (256, 128), (1280, 32), (768, 48), (1024, 256), (512, 384)])
 def test_partitioned_tile_orders_of_the_mfma_role(built, shape):
     """"sym_cpart": the column tiles of the state-split ring cut into 1 / 2 / 4 / 8 partitions over the XCDs (the default

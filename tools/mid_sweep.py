@@ -103,6 +103,18 @@ FORMS = {
     "abl_mfma_off": dict(overlap_mode=3, sym_ct=6, sym_ablate=16),
     "abl_node_off": dict(overlap_mode=3, sym_ct=6, sym_ablate=32),
     "one_sw2_nst4": dict(overlap_mode=3, sym_ct=6, sym_nst=4),
+    "bk16": dict(sym_bk=16),
+    "sw1_bk16": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1, sym_bk=16),
+    "sw2_bk16": dict(overlap_mode=3, sym_ct=6, sym_ksplit=1, sym_bk=16),
+    "sw1_bk16_first": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1, sym_bk=16, pass_order=1),
+    "sw2_bk16_first": dict(overlap_mode=3, sym_ct=6, sym_ksplit=1, sym_bk=16, pass_order=1),
+    "sw1_bk16_inter": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1, sym_bk=16, pass_order=0),
+    "sw2_bk16_inter": dict(overlap_mode=3, sym_ct=6, sym_ksplit=1, sym_bk=16, pass_order=0),
+    "sw1_bk16_node_off": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1, sym_bk=16, sym_ablate=32),
+    "sw1_bk8_node_off": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1, sym_bk=8, sym_ablate=32),
+    "sw2_bk16_node_off": dict(overlap_mode=3, sym_ct=6, sym_ksplit=1, sym_bk=16, sym_ablate=32),
+    "sw2_bk8_node_off": dict(overlap_mode=3, sym_ct=6, sym_ksplit=1, sym_bk=8, sym_ablate=32),
+    "sw2_bk16_g2c2": dict(overlap_mode=3, sym_ct=6, sym_bk=16, sym_gblk=2, sym_cx=2),
     "one_sw2_g2c2_nst4": dict(overlap_mode=3, sym_ct=6, sym_nst=4, sym_gblk=2, sym_cx=2),
     "one_sw2_sc1": dict(overlap_mode=3, sym_ct=6, node_store=1),
     "one_sw2_sc1_plainorder": dict(overlap_mode=3, sym_ct=6, node_store=1, sym_cpart=-1),
@@ -133,7 +145,7 @@ FORMS = {
     "one_sw1_g4c4": dict(overlap_mode=3, sym_ct=7, sym_gblk=4, sym_cx=4),
     "one_sw3_cp4": dict(overlap_mode=3, sym_ct=8, sym_cpart=4),
 }
-RESET = dict(small_rows=24, overlap_mode=0, sym_ct=0, pass_order=-1, slice=0, node_store=-1, sym_cpart=0, sym_gblk=0, sym_cx=0, sym_nst=3, sym_ksplit=0, sym_ablate=0)
+RESET = dict(small_rows=24, overlap_mode=0, sym_ct=0, pass_order=-1, slice=0, node_store=-1, sym_cpart=0, sym_gblk=0, sym_cx=0, sym_nst=3, sym_ksplit=0, sym_ablate=0, sym_bk=0)
 
 
 def main():
