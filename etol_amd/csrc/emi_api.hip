@@ -91,6 +91,7 @@ struct emi_ctx_s {
     bool delay_dirty = true;    // W must be rebuilt (mesh or delays changed)
     DevBuf d_W;                 // [max(xh - 1, uh)][M][M]
     DevBuf d_uext;              // [B][nc][M]: the caller's controls, then the delayed values
+    int f32_ring_wgs = 2;       // "f32_ring_wgs": workgroups of the fp32 ring kernel per CU (1: room for a node kernel's waves beside it, overlap_mode 2)
     int f32_ring = 1;           // "f32_ring": the fp32 MFMA defect kernel in its LDS-DMA ring form (0: register-staged operands, the round-2 form)
     int f32_one_launch = 0;     // "f32_one_launch": fp32 contexts take the one-launch pass (emi_pass_f32_kernel) by themselves where it applies.
                                 // Off: measured at config 5 (256 instances, 4096 nodes) 1.12 - 1.26 ms per pass in every block order against
@@ -1071,14 +1072,23 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         if (est) return est;
         pre.cost_part = (float*)c->d_cost_part2.p;      // its cost partials go nowhere
         pre.np = 0;                                      // ... and it leaves the path rows to the full kernel
-        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        // (round 4, "f32_ring_wgs" 1: the ring kernel at one workgroup per CU, which costs it nothing, leaves the node kernel's waves
+        // room on every SIMD; the node kernel is then released only once the values-only kernel is through, so that it does not fill the
+        // chip before the ring kernel's workgroups arrive)
+        if (c->f32_ring_wgs != 1) {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        }
         HIP_TRY(c, emi::launch_nodes<float>(c->model, pre, false, true, c->stream));
+        if (c->f32_ring_wgs == 1) {
+            HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        }
         emi::DefectArgsF32 da{(const float*)dX, (const float*)c->d_D.p, (float*)dRES, c->B * c->ns, c->M, c->ns, nres_of(c)};
         if (plv == 1 || plv == 2) HIP_TRY(c, hipEventRecord(pe->k[0], c->stream));
-        HIP_TRY(c, emi::launch_defect_f32_mfma(da, c->stream));
+        HIP_TRY(c, emi::launch_defect_f32_mfma(da, c->stream, c->f32_ring, c->f32_ring_wgs));
         if (plv == 1 || plv == 2) HIP_TRY(c, hipEventRecord(pe->k[1], c->stream));
-        c->last_defect_kernel = "emi_defect_f32_mfma_kernel";
+        c->last_defect_kernel = c->f32_ring ? "emi_defect_f32_ring_kernel" : "emi_defect_f32_mfma_kernel";
         if (plv == 1 || plv == 3) HIP_TRY(c, hipEventRecord(pe->k[2], c->stream2));
         HIP_TRY(c, emi::launch_nodes<float>(c->model, full, true, false, c->stream2));
         if (plv == 1 || plv == 3) HIP_TRY(c, hipEventRecord(pe->k[3], c->stream2));
@@ -1114,7 +1124,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         if (c->f32) {
             emi::DefectArgsF32 a{(const float*)dX, (const float*)c->d_D.p, (float*)dRES, c->B * c->ns,
                                  c->M, c->ns, nres_of(c)};
-            if (emi::defect_f32_mfma_supported(c->M) && c->allow_fused) { HIP_TRY(c, emi::launch_defect_f32_mfma(a, c->stream, c->f32_ring)); c->last_defect_kernel = c->f32_ring ? "emi_defect_f32_ring_kernel" : "emi_defect_f32_mfma_kernel"; }
+            if (emi::defect_f32_mfma_supported(c->M) && c->allow_fused) { HIP_TRY(c, emi::launch_defect_f32_mfma(a, c->stream, c->f32_ring, c->f32_ring_wgs)); c->last_defect_kernel = c->f32_ring ? "emi_defect_f32_ring_kernel" : "emi_defect_f32_mfma_kernel"; }
             else { HIP_TRY(c, emi::launch_defect_f32(a, c->stream)); c->last_defect_kernel = "emi_defect_f32_kernel"; }
         } else {
             emi::DefectArgs a{(const double*)dX, (const double*)c->d_D.p, (double*)dRES, c->B * c->ns,
@@ -1464,6 +1474,7 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
     }
     if (strcmp(name, "sym_order") == 0) { c->sym_order = value != 0; return EMI_OK; }
     if (strcmp(name, "f32_ring") == 0) { c->f32_ring = value != 0; return EMI_OK; }
+    if (strcmp(name, "f32_ring_wgs") == 0) { c->f32_ring_wgs = value == 1 ? 1 : 2; return EMI_OK; }
     if (strcmp(name, "f32_one_launch") == 0) { c->f32_one_launch = value != 0; return EMI_OK; }
     if (strcmp(name, "slice") == 0) {
         if (value < 0 || (value > 0 && value % 16 != 0)) return fail(c, EMI_ERR_ARG, "slice must be 0 (never) or a multiple of 16 instances");

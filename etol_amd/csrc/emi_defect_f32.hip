@@ -416,14 +416,18 @@ __global__ __launch_bounds__(256, 2) void emi_defect_f32_ring_kernel(DefectArgsF
 
 bool defect_f32_mfma_supported(int M) { return M >= 128 && M % 128 == 0; }
 
-hipError_t launch_defect_f32_mfma(const DefectArgsF32& a, hipStream_t s, int ring) {
+hipError_t launch_defect_f32_mfma(const DefectArgsF32& a, hipStream_t s, int ring, int wgs_per_cu) {
     const int mtiles = (a.R + 63) / 64, ntiles = a.M / 128;
     dim3 grid(mtiles * ntiles), block(256);
     if (ring) {
-        const size_t lds = (size_t)3 * (64 + 128) * 32 * sizeof(float);      // 72 KB: two workgroups per CU
+        // 72 KB: two workgroups per CU.  wgs_per_cu == 1: the launch ASKS for 100 KB, so that one workgroup takes a CU -- the kernel is as
+        // fast that way (0.8879 against 0.8908 ms, profiles/r03_notes.md section 6) and leaves 300 registers per SIMD to the waves of a
+        // node kernel running beside it on a second stream (with two ring workgroups per CU at 212 registers each none fits)
+        const size_t lds_min = (size_t)3 * (64 + 128) * 32 * sizeof(float), lds_one = (size_t)100 * 1024;
+        const size_t lds = wgs_per_cu == 1 ? lds_one : lds_min;
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute((const void*)emi_defect_f32_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute((const void*)emi_defect_f32_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_one);
             if (e != hipSuccess) return e;
             attr_done = true;
         }

@@ -24,7 +24,7 @@ bool defect_small_supported(int R);
 hipError_t launch_defect_small_f64(const DefectArgs& a, hipStream_t s);
 hipError_t launch_defect_f32(const DefectArgsF32& a, hipStream_t s);
 bool defect_f32_mfma_supported(int M);
-hipError_t launch_defect_f32_mfma(const DefectArgsF32& a, hipStream_t s, int ring = 0);    // ring: the LDS-DMA operand ring form
+hipError_t launch_defect_f32_mfma(const DefectArgsF32& a, hipStream_t s, int ring = 0, int wgs_per_cu = 2);    // ring: the LDS-DMA operand ring form
 // the fp32 pass as one launch (MFMA role + node role, defect rows by float atomics onto zeroed rows): emi_defect_f32.hip
 bool pass_f32_supported(int model, int R, int M, int B);
 hipError_t launch_pass_f32(int model, const DefectArgsF32& d, const NodeArgs<float>& n, int order, hipStream_t s);
