@@ -1241,14 +1241,16 @@ int emi_kkt_lowrank(emi_ctx_t c, int r, const int* node, const double* vec, cons
 }
 
 // ---- batched Newton steps: n contexts (one scenario each) on the same mesh and model ---------------------------------------
-static int batch_compatible(int n, const emi_ctx_t* ctxs, const char* what) {
+static int batch_compatible(int n, const emi_ctx_t* ctxs, const char* what, bool factorising) {
     if (n < 1 || !ctxs || !ctxs[0]) return EMI_ERR_ARG;
     emi_ctx_t c0 = ctxs[0];
     for (int b = 0; b < n; ++b) {
         emi_ctx_t c = ctxs[b];
         if (!c) return EMI_ERR_ARG;
-        if (c->M <= 0 || c->model < 0 || c->f32 || c->points_only || c->kkt_method != 1)
-            return fail(c0, EMI_ERR_STATE, "%s: context %d is not an f64 context with a collocation mesh, a model and the Schur method", what, b);
+        if (c->M <= 0 || c->model < 0 || c->f32 || c->points_only)
+            return fail(c0, EMI_ERR_STATE, "%s: context %d is not an f64 context with a collocation mesh and a model", what, b);
+        if (factorising && c->kkt_method != 1)
+            return fail(c0, EMI_ERR_UNSUPPORTED, "%s: context %d is set to the LU method (\"kkt_method\" 0): emi_kkt_factor", what, b);
         if (c->device != c0->device || c->M != c0->M || c->ns != c0->ns || c->nc != c0->nc)
             return fail(c0, EMI_ERR_ARG, "%s: context %d differs from context 0 in device, mesh size or model dimensions", what, b);
         for (int a = 0; a < b; ++a)
@@ -1259,7 +1261,7 @@ static int batch_compatible(int n, const emi_ctx_t* ctxs, const char* what) {
 
 int emi_kkt_factor_batch(int n, const emi_ctx_t* ctxs, const double* const* Qblk, const double* const* Jblk,
                          const unsigned char* const* fixed, const double* dc, int* info) {
-    int st = batch_compatible(n, ctxs, "emi_kkt_factor_batch");
+    int st = batch_compatible(n, ctxs, "emi_kkt_factor_batch", true);
     if (st) return st;
     emi_ctx_t c0 = ctxs[0];
     if (!Qblk || !Jblk || !fixed || !dc || !info) return fail(c0, EMI_ERR_ARG, "emi_kkt_factor_batch: null argument");
@@ -1286,7 +1288,7 @@ int emi_kkt_factor_batch(int n, const emi_ctx_t* ctxs, const double* const* Qblk
 }
 
 int emi_kkt_solve_batch(int n, const emi_ctx_t* ctxs, double* const* rhs) {
-    int st = batch_compatible(n, ctxs, "emi_kkt_solve_batch");
+    int st = batch_compatible(n, ctxs, "emi_kkt_solve_batch", false);
     if (st) return st;
     emi_ctx_t c0 = ctxs[0];
     if (!rhs) return fail(c0, EMI_ERR_ARG, "emi_kkt_solve_batch: null argument");
@@ -1309,7 +1311,7 @@ int emi_kkt_solve_batch(int n, const emi_ctx_t* ctxs, double* const* rhs) {
 
 int emi_kkt_solve_refined_batch(int n, const emi_ctx_t* ctxs, double* const* rhs, const double* dc_nominal, int max_steps, double* rel,
                                 int* nsolve, int* reverted, int* status) {
-    int st = batch_compatible(n, ctxs, "emi_kkt_solve_refined_batch");
+    int st = batch_compatible(n, ctxs, "emi_kkt_solve_refined_batch", false);
     if (st) return st;
     emi_ctx_t c0 = ctxs[0];
     if (!rhs || !dc_nominal || !rel || !nsolve || !reverted || !status || max_steps < 0)

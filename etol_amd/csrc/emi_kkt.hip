@@ -118,6 +118,8 @@ struct KktWorkspace {
     size_t cap_trsv_tmp = 0;
     double* trsv_y = nullptr;      // [n] forward-sweep solution of the gemv form of blk_potrs
     size_t cap_trsv_y = 0;
+    double* trsm_y = nullptr;      // [n][nrhs] the same for many right-hand sides (blk_potrs_multi)
+    size_t cap_trsm_y = 0;
     double* chol_blk = nullptr;    // [64][64] + [64]: factorised diagonal block and reciprocal diagonal of the current block column
     double* chol_copy = nullptr;   // the matrix handed to dpotrf, kept until the factorisation is confirmed (potrf_checked)
     size_t cap_chol_copy = 0;
@@ -1207,13 +1209,43 @@ int blk_potrs(KktWorkspace* w, hipStream_t stream, rocblas_int n, const double* 
     return EMI_OK;
 }
 
+// X <- (L L^T)^-1 X for MANY right-hand sides (X: n x nrhs, column-major, ldx) through the same block inverses: per block column one
+// GEMM with the inverted diagonal block and one with the rows below (forward) / the columns left of it (backward) -- 4 nblk large GEMMs,
+// n^2 nrhs flops per sweep like a triangular solve, none of its dependency chains.  The r columns of the low-rank correction
+// (r ~ 800 at 1024 nodes) went through rocsolver_dpotrs before (blocked substitution kernels, 225 launches of 56 - 76 us per solve of
+// a 1024-node problem: profiles/r04_one_solve_kernel_stats_before_batching.csv).
+int blk_potrs_multi(KktWorkspace* w, hipStream_t stream, rocblas_int n, const double* L, double* X, rocblas_int ldx, rocblas_int nrhs,
+                    std::string* err) {
+    const int nblk = (n + TRSV_NB - 1) / TRSV_NB;
+    const double one = 1.0, mone = -1.0, zero = 0.0;
+    KKT_ENSURE(w->trsm_y, w->cap_trsm_y, (size_t)n * nrhs * sizeof(double));
+    double* Y = w->trsm_y;                              // n x nrhs, leading dimension n
+    for (int j = 0; j < nblk; ++j) {                    // forward: L Y = B (B in X, consumed block row by block row)
+        const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, (int)n - j0), rest = (int)n - j0 - bs;
+        KKT_RB(rocblas_dgemm(w->handle, rocblas_operation_none, rocblas_operation_none, bs, nrhs, bs, &one, w->Linv + (size_t)j * TRSV_NB * TRSV_NB,
+                             TRSV_NB, X + j0, ldx, &zero, Y + j0, n));
+        if (rest > 0)
+            KKT_RB(rocblas_dgemm(w->handle, rocblas_operation_none, rocblas_operation_none, rest, nrhs, bs, &mone, L + (size_t)j0 * n + j0 + bs, n,
+                                 Y + j0, n, &one, X + j0 + bs, ldx));
+    }
+    for (int j = nblk - 1; j >= 0; --j) {               // backward: L^T X = Y (Y consumed block row by block row)
+        const int j0 = j * TRSV_NB, bs = std::min(TRSV_NB, (int)n - j0);
+        KKT_RB(rocblas_dgemm(w->handle, rocblas_operation_transpose, rocblas_operation_none, bs, nrhs, bs, &one, w->Linv + (size_t)j * TRSV_NB * TRSV_NB,
+                             TRSV_NB, Y + j0, n, &zero, X + j0, ldx));
+        if (j0 > 0)
+            KKT_RB(rocblas_dgemm(w->handle, rocblas_operation_transpose, rocblas_operation_none, j0, nrhs, bs, &mone, L + j0, n, X + j0, ldx, &one, Y,
+                                 n));
+    }
+    return EMI_OK;
+}
+
 }  // namespace
 
 void kkt_destroy(KktWorkspace* w) {
     if (!w) return;
     if (w->handle) (void)rocblas_destroy_handle(w->handle);
     void* bufs[] = {w->K, w->ipiv, w->info, w->Q, w->J, w->rhs, w->fixed, w->S, w->Pinv, w->G, w->Rk, w->Doff, w->W, w->gemm_ptrs, w->T,
-                    w->Cb, w->flag, w->chol_blk, w->chol_copy, w->Linv, w->LinvT, w->trsv_tmp, w->trsv_y, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
+                    w->Cb, w->flag, w->chol_blk, w->chol_copy, w->Linv, w->LinvT, w->trsv_tmp, w->trsv_y, w->trsm_y, w->lrY, w->lrC, w->lrT, w->lr_node, w->lr_vec, w->lr_delta};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (w->ref_b) (void)hipFree(w->ref_b);
@@ -1491,6 +1523,7 @@ static int solve_dev(KktWorkspace* w, hipStream_t stream, int nz, double* X, int
         KKT_HIP(hipGetLastError());
         // lambda = S^-1 Cb
         if (nrhs == 1 && w->linv_n == md) { if (int st = blk_potrs(w, stream, md, w->S, w->Cb, err)) return st; }
+        else if (nrhs >= 16 && w->linv_n == md) { if (int st = blk_potrs_multi(w, stream, md, w->S, w->Cb, md, nrhs, err)) return st; }
         else KKT_RB(rocsolver_dpotrs(w->handle, rocblas_fill_lower, md, nrhs, w->S, md, w->Cb, md));
         // y = a - J^T lambda  (in place in the primal part of X), then x = P y
         if (nrhs >= 8)

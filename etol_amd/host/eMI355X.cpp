@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <map>
 #include <mutex>
 
 #include "emi_nlp.hpp"
@@ -159,27 +160,35 @@ struct KktBatcher::Impl {
         bool done = false;
         std::chrono::steady_clock::time_point posted;
     };
+    // One rendezvous per MESH SIZE: the solves in flight sit on different rungs of their mesh ladders (33, 65, ... nodes), and only
+    // requests of one size share launches.  The members of a level are the solves currently iterating on that mesh; they move in step
+    // (one Newton iteration per round), cheap coarse-mesh rounds at their own pace beside the expensive fine-mesh ones.
+    struct Level {
+        int members = 0;
+        bool leading = false;
+        std::vector<Req*> pending;
+    };
     std::mutex m;
     std::condition_variable cv;
-    int members = 0;
-    bool leading = false;
-    std::vector<Req*> pending;
+    std::map<int, Level> levels;
 };
 
 KktBatcher::KktBatcher() : impl(new Impl()) {}
 KktBatcher::~KktBatcher() { delete impl; }
-KktBatcher::Member::Member(const std::shared_ptr<KktBatcher>& b) : batcher(b) {
+KktBatcher::Member::Member(const std::shared_ptr<KktBatcher>& b) : batcher(b) {}
+KktBatcher::Member::~Member() {}
+KktBatcher::OnMesh::OnMesh(KktBatcher* b, int nodes_) : batcher(b), nodes(nodes_) {
     if (!batcher) return;
     std::lock_guard<std::mutex> lk(batcher->impl->m);
-    ++batcher->impl->members;
+    ++batcher->impl->levels[nodes].members;
 }
-KktBatcher::Member::~Member() {
+KktBatcher::OnMesh::~OnMesh() {
     if (!batcher) return;
     {
         std::lock_guard<std::mutex> lk(batcher->impl->m);
-        --batcher->impl->members;
+        --batcher->impl->levels[nodes].members;
     }
-    batcher->impl->cv.notify_all();                 // whoever waits for "everyone is here" counts again
+    batcher->impl->cv.notify_all();                 // whoever waits for "everyone on this mesh is here" counts again
 }
 
 // what has gathered, as batched calls: one per operation and mesh size
@@ -199,11 +208,15 @@ static void run_batch(KktBatcher* B, std::vector<KktBatcher::Impl::Req*>& take) 
             std::vector<double> dc(n);
             std::vector<int> info(n, -1);
             for (int b = 0; b < n; ++b) { Q[b] = take[i + b]->Q; J[b] = take[i + b]->J; fx[b] = take[i + b]->fixed; dc[b] = take[i + b]->dc; }
-            const int st = n == 1 ? emi_kkt_factor(ctxs[0], Q[0], J[0], fx[0], dc[0], &info[0])
-                                  : emi_kkt_factor_batch(n, ctxs.data(), Q.data(), J.data(), fx.data(), dc.data(), info.data());
+            int st = n == 1 ? emi_kkt_factor(ctxs[0], Q[0], J[0], fx[0], dc[0], &info[0])
+                            : emi_kkt_factor_batch(n, ctxs.data(), Q.data(), J.data(), fx.data(), dc.data(), info.data());
+            if (st == EMI_ERR_UNSUPPORTED && n > 1) {               // (a context forced onto the LU method: one by one)
+                st = EMI_OK;
+                for (int b = 0; b < n && st == EMI_OK; ++b) st = emi_kkt_factor(ctxs[b], Q[b], J[b], fx[b], dc[b], &info[b]);
+            }
             for (int b = 0; b < n; ++b) take[i + b]->result = st == EMI_OK ? info[b] : -1;
-            ++B->factor_calls;
-            B->factor_items += n;
+            __sync_fetch_and_add(&B->factor_calls, 1L);
+            __sync_fetch_and_add(&B->factor_items, (long)n);
         } else if (take[i]->op == 3) {
             for (int b = 0; b < n; ++b) {
                 KktBatcher::Impl::Req* q = take[i + b];
@@ -214,8 +227,8 @@ static void run_batch(KktBatcher* B, std::vector<KktBatcher::Impl::Req*>& take) 
             for (int b = 0; b < n; ++b) rhs[b] = take[i + b]->rhs;
             const int st = n == 1 ? emi_kkt_solve(ctxs[0], rhs[0], 1) : emi_kkt_solve_batch(n, ctxs.data(), rhs.data());
             for (int b = 0; b < n; ++b) take[i + b]->result = st == EMI_OK ? 0 : -1;
-            ++B->solve_calls;
-            B->solve_items += n;
+            __sync_fetch_and_add(&B->solve_calls, 1L);
+            __sync_fetch_and_add(&B->solve_items, (long)n);
         } else {
             // refined solves: the scenarios whose factorisation is the LU fallback answer "not offered" (1) and refine on the host
             std::vector<double*> rhs;
@@ -240,11 +253,11 @@ static void run_batch(KktBatcher* B, std::vector<KktBatcher::Impl::Req*>& take) 
                     q->result = st == EMI_OK ? stat[a] : -1;
                     q->rel = rel[a]; q->nsolve = nsv[a]; q->reverted = rev[a];
                 }
-                ++B->solve_calls;
-                B->solve_items += m;
+                __sync_fetch_and_add(&B->solve_calls, 1L);
+                __sync_fetch_and_add(&B->solve_items, (long)m);
             }
         }
-        B->largest_batch = std::max(B->largest_batch, n);
+        if (n > B->largest_batch) B->largest_batch = n;
         i = j;
     }
 }
@@ -252,30 +265,31 @@ static void run_batch(KktBatcher* B, std::vector<KktBatcher::Impl::Req*>& take) 
 static int submit(KktBatcher* B, KktBatcher::Impl::Req& r) {
     KktBatcher::Impl* I = B->impl;
     std::unique_lock<std::mutex> lk(I->m);
+    KktBatcher::Impl::Level& Lv = I->levels[r.nodes];          // (std::map: references stay valid)
     r.posted = std::chrono::steady_clock::now();
-    I->pending.push_back(&r);
+    Lv.pending.push_back(&r);
     I->cv.notify_all();
     for (;;) {
         if (r.done) return r.result;
-        if (!I->leading && !I->pending.empty()) {
-            const bool everyone = (int)I->pending.size() >= I->members;
-            const auto oldest = (*std::min_element(I->pending.begin(), I->pending.end(),
+        if (!Lv.leading && !Lv.pending.empty()) {
+            const bool everyone = (int)Lv.pending.size() >= Lv.members;
+            const auto oldest = (*std::min_element(Lv.pending.begin(), Lv.pending.end(),
                                                    [](const KktBatcher::Impl::Req* a, const KktBatcher::Impl::Req* b) { return a->posted < b->posted; }))->posted;
             const bool stale = std::chrono::steady_clock::now() - oldest > std::chrono::microseconds(B->flush_us);
             if (everyone || stale) {
-                I->leading = true;
+                Lv.leading = true;
                 std::vector<KktBatcher::Impl::Req*> take;
-                take.swap(I->pending);
+                take.swap(Lv.pending);
                 lk.unlock();
                 run_batch(B, take);
                 lk.lock();
                 for (KktBatcher::Impl::Req* q : take) q->done = true;
-                I->leading = false;
+                Lv.leading = false;
                 I->cv.notify_all();
                 continue;
             }
         }
-        I->cv.wait_for(lk, std::chrono::microseconds(100));
+        I->cv.wait_for(lk, std::chrono::microseconds(50));
     }
 }
 }  // namespace mi355x
@@ -287,7 +301,8 @@ struct BatchedKkt : public mi355x::KktBackend {
     mi355x::KktBackend* direct;          // the solver's own device adapter
     emi_ctx_t ctx;
     int nodes;
-    BatchedKkt(mi355x::KktBatcher* b, mi355x::KktBackend* d, emi_ctx_t c, int n) : B(b), direct(d), ctx(c), nodes(n) {}
+    mi355x::KktBatcher::OnMesh on_mesh;  // this solve counts as a member of its mesh size while it iterates
+    BatchedKkt(mi355x::KktBatcher* b, mi355x::KktBackend* d, emi_ctx_t c, int n) : B(b), direct(d), ctx(c), nodes(n), on_mesh(b, n) {}
     int factor(const double* Qblk, const double* Jblk, const unsigned char* fixed, double dc) override {
         mi355x::KktBatcher::Impl::Req r;
         r.op = 0; r.ctx = ctx; r.nodes = nodes; r.Q = Qblk; r.J = Jblk; r.fixed = fixed; r.dc = dc;
@@ -989,7 +1004,7 @@ void eMI355X::solve() {
         const size_t kkt_rows = (2 * ns + nc) * P.nodes;
         const bool dev_kkt = !P.lifted && (_algorithm.linear_solver == "device" ||
                                            (_algorithm.linear_solver == "auto" && kkt_rows > 400));
-        BatchedKkt shared(_algorithm.kkt_batcher.get(), static_cast<mi355x::KktBackend*>(_dev.get()), _dev->ctx, _dev->nodes);
+        BatchedKkt shared(dev_kkt ? _algorithm.kkt_batcher.get() : nullptr, static_cast<mi355x::KktBackend*>(_dev.get()), _dev->ctx, _dev->nodes);
         nlp.kkt = dev_kkt ? (_algorithm.kkt_batcher ? static_cast<mi355x::KktBackend*>(&shared) : static_cast<mi355x::KktBackend*>(_dev.get()))
                           : nullptr;
         if (_algorithm.scaling == "automatic") nlp.vscale = mi355x::bound_scales(P);
@@ -999,8 +1014,20 @@ void eMI355X::solve() {
         _solution.linear_solver = dev_kkt ? "device: structured KKT factorisation (Schur complement + Cholesky), Woodbury-corrected" : "host LDL^T";
         if (P.guess_lamF.size() == ns * P.nodes) nlp.lamF0 = P.guess_lamF;
         if (P.guess_lamC.size() == P.npath * P.nodes) nlp.lamC0 = P.guess_lamC;
-        r = mi355x::solve_nlp(nlp, o, mi355x::initial_guess(P));
+        mi355x::NlpOptions ob = o;
+        if (_algorithm.nlp_iter_budget > 0) {           // what is left of the solve()'s iteration budget
+            const int left = _algorithm.nlp_iter_budget - _solution.nlp_iterations_total;
+            if (left <= 0) {
+                r = mi355x::NlpResult();
+                r.msg = "iteration budget exhausted (" + std::to_string(_solution.nlp_iterations_total) + " iterations over all meshes and restarts)";
+                return;
+            }
+            ob.max_iter = std::min(ob.max_iter, left);
+        }
+        r = mi355x::solve_nlp(nlp, ob, mi355x::initial_guess(P));
         _solution.nlp_iterations_total += r.iterations;
+        if (!r.ok && _algorithm.nlp_iter_budget > 0 && _solution.nlp_iterations_total >= _algorithm.nlp_iter_budget)
+            r.msg = "iteration budget exhausted (" + std::to_string(_solution.nlp_iterations_total) + " iterations over all meshes and restarts); last: " + r.msg;
     };
     // A warm start that wanders (no failure, just hundreds of regularised steps along a flat valley; Monte-Carlo scenario 10 of
     // profiles/r02_notes.md section 12) is cut off after Alg::warm_patience iterations and repeated from the same interpolated

@@ -22,23 +22,31 @@ namespace ETOL {
 namespace mi355x {
 
 // Rendezvous of the Newton steps of CONCURRENT solves on one device (a Monte-Carlo batch: one host thread and one eMI355X per
-// scenario in flight, BASELINE configs[3]).  Solvers that share a batcher hand their factorisations and single-right-hand-side
-// solves to it instead of launching them themselves; whichever worker finds every member waiting (or the oldest request older than
-// `flush_us`) runs what has gathered as ONE batched call (emi_kkt_factor_batch / emi_kkt_solve_refined_batch: every launch carries
-// all scenarios of one mesh size) and hands the answers back.  The members of a batcher therefore move in step, one Newton iteration
-// per round; with two or three batchers one group's batch runs on the device while the others do their host work.  The iteration of each scenario is untouched -- same matrices, same steps, its own factors --
-// only the launches are shared.  A worker thread joins before its first solve() and leaves after its last (Member guard).
+// scenario in flight, BASELINE configs[3]).  Solvers that share a batcher hand their factorisations, low-rank corrections and
+// single-right-hand-side solves to it instead of launching them themselves.  The batcher keeps one rendezvous per MESH SIZE (the
+// solves in flight sit on different rungs of their mesh ladders, and only requests of one size share launches): the solves currently
+// iterating on a mesh are its members, and whichever of them finds every member waiting (or the oldest request older than `flush_us`)
+// runs what has gathered as ONE batched call (emi_kkt_factor_batch / emi_kkt_solve_refined_batch: every launch carries all scenarios)
+// and hands the answers back.  The members of a mesh size therefore move in step, one Newton iteration per round -- the cheap
+// coarse-mesh rounds, which are pure launch latency for a single scenario, at their own pace beside the expensive fine-mesh ones.
+// The iteration of each scenario is untouched: same matrices, same steps, its own factors; only the launches are shared.
 class KktBatcher {
  public:
     KktBatcher();
     ~KktBatcher();
-    struct Member {                                 // RAII membership of the calling thread
+    struct Member {                                 // (kept for callers of the first form: membership is per mesh now, OnMesh)
         explicit Member(const std::shared_ptr<KktBatcher>& b);
         ~Member();
         std::shared_ptr<KktBatcher> batcher;
     };
-    int flush_us = 20000;                           // a request older than this is run with whatever has gathered (a member in a long
-                                                    // host phase -- setting up its next scenario -- must not hold the others for good)
+    struct OnMesh {                                 // RAII: the calling solve iterates on a mesh of `nodes` nodes (solve() holds one per NLP solve)
+        OnMesh(KktBatcher* b, int nodes);
+        ~OnMesh();
+        KktBatcher* batcher;
+        int nodes;
+    };
+    int flush_us = 20000;                           // a request older than this is run with whatever has gathered (safety: a member that
+                                                    // spends unusually long between two Newton steps must not hold the others for good)
     // totals, for reports: batched calls, scenarios they carried, largest batch
     long factor_calls = 0, factor_items = 0, solve_calls = 0, solve_items = 0;
     int largest_batch = 0;
@@ -84,7 +92,11 @@ struct Alg {
     double crawl_frac = 0.3;
     std::string linear_solver = "auto";            // Newton step: "host" (dense LDL^T), "device" (structured
                                                    // factorisation in HBM, emi_kkt_*), "auto" = device above 400 KKT rows
-    int nlp_iter_max = 200;
+    int nlp_iter_max = 200;                        // per NLP solve (one mesh, one start), as ePSOPT.cpp:66
+    int nlp_iter_budget = 0;                       // > 0: iterations ONE solve() may spend over all its meshes, rungs and restarts; when they are used
+                                                   // up the problem is reported unsolved ("iteration budget exhausted") instead of being carried on
+                                                   // -- a Monte-Carlo batch waits for its slowest scenario, and the slowest are the ones that wander
+                                                   // (profiles/r04_notes.md: median 105 iterations, 90th percentile 411, maximum 1028 at 1024 nodes)
     double nlp_tolerance = 1.e-6;
     double max_cpu_time = 1.e9;
     int print_level = 0;
