@@ -266,12 +266,19 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
     const int gblk = (c->sym_gblk == 0 && c->sym_cpart == 0 && B > 2048 && B % 256 == 0) ? 2 : c->sym_gblk;
     const int gblk_first = (auto_ct || c->rtc) ? gblk : c->sym_gblk;
     int ct = c->sym_ct;                                  // 5 / 6 / 7 / 8 = SW NS / 2 / 1 / 3 (plan_symdefect)
+    // Round 4: between 64 and 127 tiles (128 .. 255 instances at 1024 nodes: the shard of config 4) two states per workgroup with K
+    // tiles of 16 -- half the barriers and counted waits of the MFMA role's dependency chain, which is what such a pass waits for.
+    // One box, ms per pass, SW = 1 / 8-deep (the round-3 choice) against SW = 2 / 16-deep (profiles/r04_mid_sweep.jsonl): 128 instances
+    // 0.0320 / 0.0300, 192: 0.0482 / 0.0442; at 64 instances the sliced SW = 1 form stays ahead (0.0210 / 0.0269), from 256 the 8-deep
+    // SW = 2 form (0.0548 / 0.0617).
+    const bool deep_mid = auto_ct && !c->rtc && c->sym_bk == 0 && c->sym_ksplit == 0 && c->sym_nst == 3 && c->ns % 2 == 0 && c->ns > 2 &&
+                          p.tiles16 >= 64 && p.tiles16 < 128;
     if (c->rtc) ct = (p.store_mode == 2 && emi::rtc_pass_sw_large(c->rtc) == 2) ? 6 : 7;
-    else if (auto_ct) ct = p.tiles16 < 128 ? 7 : 6;
+    else if (auto_ct) ct = (p.tiles16 < 128 && !deep_mid) ? 7 : 6;
     emi::SymPlan plan = emi::plan_symdefect(c->ns, B, c->M, ct, 1, c->sym_cpart, gblk_first, c->sym_cx);
     if (plan.ring1) plan = emi::plan_symdefect(c->ns, B, c->M, 5, 1, c->sym_cpart, c->sym_gblk, c->sym_cx);
     int ks_want = c->sym_ksplit;
-    if (ks_want == 0 && auto_ct) ks_want = plan.tiles * 4 <= 256 ? 4 : (plan.tiles * 2 <= 512 ? 2 : 1);
+    if (ks_want == 0 && auto_ct && !deep_mid) ks_want = plan.tiles * 4 <= 256 ? 4 : (plan.tiles * 2 <= 512 ? 2 : 1);
     if (ks_want > 1) {
         const int ct_now = plan.sw == c->ns ? 5 : (plan.sw == 2 ? 6 : (plan.sw == 3 ? 8 : 7));
         plan = emi::plan_symdefect(c->ns, B, c->M, ct_now, ks_want, c->sym_cpart, c->rtc ? gblk : c->sym_gblk, c->sym_cx);
@@ -280,7 +287,7 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
     }
     plan.nst = c->rtc ? 3 : c->sym_nst;
     // K tiles of 16 (built-in models, SW 1 or 2, three stages, unsplit): "sym_bk" 16 forces them
-    const int bk_want = c->sym_bk ? c->sym_bk : 8;
+    const int bk_want = c->sym_bk ? c->sym_bk : (deep_mid ? 16 : 8);
     if (bk_want == 16 && !c->rtc && plan.ks == 1 && (plan.sw == 1 || plan.sw == 2) && plan.nst == 3) plan.bk = 16;
     p.sym = plan;
     p.mfma_first = c->pass_order >= 0 ? c->pass_order

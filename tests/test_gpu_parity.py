@@ -827,11 +827,11 @@ def _expected_default_form(ev, B):
     last = p["tail"] if p["tail"] else (p["piece"] if p["piece"] else B)
     q = ev.plan(last)
     assert q["one_launch"] == 1 and q["piece"] == 0
-    return (f"emi_pass_f64_kernel<SW={q['sw']}> (MFMA + node roles, one launch" + (f", {q['ksplit']} K slices" if q["ksplit"] > 1 else ")")), p
+    return (f"emi_pass_f64_kernel<SW={q['sw']}> (MFMA + node roles, one launch" + (f", {q['ksplit']} K slices" if q["ksplit"] > 1 else ")")), q
 
 
 # the shapes the benchmark lines and the profiles quote, pinned: a policy change has to be made here as well as in plan_pass
-PINNED_PLANS = {128: dict(sw=1, ksplit=1, store_mode=0, block_order=1, piece=0), 1024: dict(sw=2, ksplit=1, store_mode=2, piece=0),
+PINNED_PLANS = {128: dict(sw=2, ksplit=1, k_tile=16, store_mode=0, block_order=1, piece=0), 1024: dict(sw=2, ksplit=1, k_tile=8, store_mode=2, piece=0),
                 16: dict(sw=1, ksplit=4), 64: dict(sw=1, ksplit=2), 4096: dict(sw=2, store_mode=2, piece=0)}
 
 
