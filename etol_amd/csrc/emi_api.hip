@@ -287,7 +287,12 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
     }
     plan.nst = c->rtc ? 3 : c->sym_nst;
     // K tiles of 16 (built-in models, SW 1 or 2, three stages, unsplit): "sym_bk" 16 forces them
-    const int bk_want = c->sym_bk ? c->sym_bk : (deep_mid ? 16 : 8);
+    // ... and between 208 and 767 tiles (416 .. 1535 instances, SW = 2 at 1.25 x / 1.1 x the even MFMA density): one box, ms per pass 8- /
+    // 16-deep, 448 instances 0.1112 / 0.1018, 512: 0.1226 / 0.1151, 576: 0.1351 / 0.1277, 640: 0.1492 / 0.1431, 768: 0.1675 / 0.1649,
+    // 896: 0.1921 / 0.1896, 1024: 0.2164 / 0.2143; not at 256 .. 384 instances (MFMA workgroups first: 320: 0.0752 / 0.0924) nor from 2048
+    // (0.4147 / 0.4205; 4096 in the grouped order 1.081 / 1.175)
+    const bool deep_large = auto_ct && !c->rtc && c->sym_bk == 0 && c->sym_nst == 3 && c->pass_order < 0 && p.tiles16 >= 208 && p.tiles16 < 768;
+    const int bk_want = c->sym_bk ? c->sym_bk : ((deep_mid || deep_large) ? 16 : 8);
     if (bk_want == 16 && !c->rtc && plan.ks == 1 && (plan.sw == 1 || plan.sw == 2) && plan.nst == 3) plan.bk = 16;
     p.sym = plan;
     p.mfma_first = c->pass_order >= 0 ? c->pass_order

@@ -53,6 +53,12 @@ struct KktTuning {
     std::atomic<int> sticky_reg{1};         // "kkt_sticky_reg": start the Schur path at the regularisation level that worked last on this mesh
     std::atomic<int> block_trsv{1};         // "kkt_block_trsv": 1 single right-hand sides through the block-inverse triangular solves below (gemv form), 2 the same with the library's own diagonal-block kernel, 0 rocsolver_dpotrs (trsv)
     std::atomic<int> primal_levels{1};      // "kkt_primal_levels": 1 primal regularisation levels behind the dual ones before the LU fallback, 0 the round-2 ladder
+    // batched entry points: from this many rows of the Schur complement on, the rocBLAS calls of a batch go out once per scenario
+    // (plain dgemm / dsyrk / dtrtri: large problems, where the pointer-array forms of the library run far below the plain ones)
+    // instead of as *_batched calls (small problems, where a launch per scenario is what a batch is there to avoid)
+    std::atomic<int> batch_gemm_rows{3072};   // "kkt_batch_gemm_rows"
+    std::atomic<int> batch_syrk_rows{3072};   // "kkt_batch_syrk_rows"
+    std::atomic<int> batch_trtri_rows{3072};  // "kkt_batch_trtri_rows"
 };
 static KktTuning g_tune;
 bool kkt_set_option(const char* name, int value) {
@@ -66,6 +72,9 @@ bool kkt_set_option(const char* name, int value) {
     if (!strcmp(name, "kkt_sticky_reg")) { g_tune.sticky_reg = value != 0; return true; }
     if (!strcmp(name, "kkt_block_trsv")) { g_tune.block_trsv = value < 0 ? 0 : (value > 2 ? 2 : value); return true; }
     if (!strcmp(name, "kkt_primal_levels")) { g_tune.primal_levels = value != 0; return true; }
+    if (!strcmp(name, "kkt_batch_gemm_rows")) { g_tune.batch_gemm_rows = value; return true; }
+    if (!strcmp(name, "kkt_batch_syrk_rows")) { g_tune.batch_syrk_rows = value; return true; }
+    if (!strcmp(name, "kkt_batch_trtri_rows")) { g_tune.batch_trtri_rows = value; return true; }
     return false;
 }
 
@@ -1751,14 +1760,26 @@ int chol_batched(KktWorkspace* L, hipStream_t stream, const KktDev* d_tab, int n
                 hipLaunchKernelGGL(emi_chol_diag_b_kernel, dim3(na), dim3(256), 0, stream, d_tab, n, st.j0, st.nb);
             if (st.rest <= 0) continue;
             hipLaunchKernelGGL(emi_chol_panel_mfma_b_kernel, dim3((st.rest + 63) / 64, na), dim3(64), 0, stream, d_tab, n, n, st.j0);
-            if (st.wc > 0)
-                KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_none, rocblas_operation_transpose, st.rest, st.wc, st.nb, &mone,
-                                             (const double* const*)(dp + st.at), n, (const double* const*)(dp + st.at), n, &one,
-                                             dp + st.at + na, n, na));
+            if (st.wc > 0) {
+                if (n < g_tune.batch_gemm_rows.load())
+                    KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_none, rocblas_operation_transpose, st.rest, st.wc, st.nb, &mone,
+                                                 (const double* const*)(dp + st.at), n, (const double* const*)(dp + st.at), n, &one,
+                                                 dp + st.at + na, n, na));
+                else
+                    for (int a = 0; a < na; ++a)
+                        KKT_RB(rocblas_dgemm(L->handle, rocblas_operation_none, rocblas_operation_transpose, st.rest, st.wc, st.nb, &mone, hp[st.at + a], n,
+                                             hp[st.at + a], n, &one, hp[st.at + na + a], n));
+            }
         }
-        if (o.rest2 > 0)
-            KKT_RB(rocblas_dsyrk_batched(L->handle, rocblas_fill_lower, rocblas_operation_none, o.rest2, o.Jend - o.J0, &mone,
-                                         (const double* const*)(dp + o.at), n, &one, dp + o.at + na, n, na));
+        if (o.rest2 > 0) {
+            if (n < g_tune.batch_syrk_rows.load())
+                KKT_RB(rocblas_dsyrk_batched(L->handle, rocblas_fill_lower, rocblas_operation_none, o.rest2, o.Jend - o.J0, &mone,
+                                             (const double* const*)(dp + o.at), n, &one, dp + o.at + na, n, na));
+            else
+                for (int a = 0; a < na; ++a)
+                    KKT_RB(rocblas_dsyrk(L->handle, rocblas_fill_lower, rocblas_operation_none, o.rest2, o.Jend - o.J0, &mone, hp[o.at + a], n, &one,
+                                         hp[o.at + na + a], n));
+        }
     }
     KKT_HIP(hipGetLastError());
     return EMI_OK;
@@ -1863,9 +1884,14 @@ int kkt_factor_batch(int n, KktWorkspace** const* pws, hipStream_t stream, const
         for (int i = 0, p = 0; i < ns; ++i)
             for (int ip = 0; ip <= i; ++ip, ++p) {
                 hipLaunchKernelGGL(emi_kkt_scale_b_kernel, dim3(nb2, na), dim3(256), 0, stream, (const KktDev*)d_tab, M, (i * nv + ip) * M);
-                KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &one,
-                                             (const double* const*)(L->b_ptrs + at_A), M, (const double* const*)(L->b_ptrs + at_B), M, &zero,
-                                             L->b_ptrs + at_C + (size_t)p * na, (rocblas_int)md, na));
+                if (md < g_tune.batch_gemm_rows.load())
+                    KKT_RB(rocblas_dgemm_batched(L->handle, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &one,
+                                                 (const double* const*)(L->b_ptrs + at_A), M, (const double* const*)(L->b_ptrs + at_B), M, &zero,
+                                                 L->b_ptrs + at_C + (size_t)p * na, (rocblas_int)md, na));
+                else
+                    for (int a = 0; a < na; ++a)
+                        KKT_RB(rocblas_dgemm(L->handle, rocblas_operation_transpose, rocblas_operation_none, M, M, M, &one, L->Doff, M, W[act[a]]->W, M, &zero,
+                                             h_ptr[at_C + (size_t)p * na + a], (rocblas_int)md));
                 hipLaunchKernelGGL(emi_kkt_sblock_terms_b_kernel, dim3(nb2, na), dim3(256), 0, stream, (const KktDev*)d_tab, M, ns, i, ip);
             }
         KKT_HIP(hipGetLastError());
@@ -1929,9 +1955,14 @@ int kkt_factor_batch(int n, KktWorkspace** const* pws, hipStream_t stream, const
             for (int a = 0; a < na; ++a) h_ptr[q++] = W[act[a]]->Linv + (size_t)full * TRSV_NB * TRSV_NB;
             KKT_HIP(hipMemcpyAsync(d_tab, h_tab, (size_t)na * sizeof(KktDev), hipMemcpyHostToDevice, stream));
             KKT_HIP(hipMemcpyAsync(L->b_ptrs, h_ptr, q * sizeof(double*), hipMemcpyHostToDevice, stream));
-            if (full > 0)
+            if (full > 0 && md < g_tune.batch_trtri_rows.load())
                 KKT_RB(rocblas_dtrtri_batched(L->handle, rocblas_fill_lower, rocblas_diagonal_non_unit, TRSV_NB,
                                               (const double* const*)(L->b_ptrs + at_LA), md, L->b_ptrs + at_LI, TRSV_NB, full * na));
+            else if (full > 0)
+                for (int a = 0; a < na; ++a)
+                    KKT_RB(rocblas_dtrtri_strided_batched(L->handle, rocblas_fill_lower, rocblas_diagonal_non_unit, TRSV_NB, W[act[a]]->S, md,
+                                                          (rocblas_stride)TRSV_NB * (md + 1), W[act[a]]->Linv, TRSV_NB,
+                                                          (rocblas_stride)TRSV_NB * TRSV_NB, full));
             if (tail > 0)
                 KKT_RB(rocblas_dtrtri_batched(L->handle, rocblas_fill_lower, rocblas_diagonal_non_unit, tail,
                                               (const double* const*)(L->b_ptrs + at_TA), md, L->b_ptrs + at_TI, TRSV_NB, na));

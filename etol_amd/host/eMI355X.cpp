@@ -268,14 +268,20 @@ static int submit(KktBatcher* B, KktBatcher::Impl::Req& r) {
     KktBatcher::Impl::Level& Lv = I->levels[r.nodes];          // (std::map: references stay valid)
     r.posted = std::chrono::steady_clock::now();
     Lv.pending.push_back(&r);
-    I->cv.notify_all();
+    // Nobody is woken by an arrival: the thread that completes the set finds that out itself, right here; the others sleep until the
+    // leader of their batch is through (notify_all), a member leaves their mesh (notify_all), or their own request turns stale.
+    // (The first form polled every 50 us from every waiting thread: 64 workers kept the 16 host cores of a GPU box busy with wake-ups
+    // and the set ran at a third of the speed of 8 free-running threads, profiles/r04_notes.md.)
+    const auto deadline = r.posted + std::chrono::microseconds(B->flush_us);
     for (;;) {
         if (r.done) return r.result;
         if (!Lv.leading && !Lv.pending.empty()) {
             const bool everyone = (int)Lv.pending.size() >= Lv.members;
-            const auto oldest = (*std::min_element(Lv.pending.begin(), Lv.pending.end(),
-                                                   [](const KktBatcher::Impl::Req* a, const KktBatcher::Impl::Req* b) { return a->posted < b->posted; }))->posted;
-            const bool stale = std::chrono::steady_clock::now() - oldest > std::chrono::microseconds(B->flush_us);
+            bool stale = false;
+            if (!everyone) {
+                const auto now = std::chrono::steady_clock::now();
+                for (const KktBatcher::Impl::Req* q : Lv.pending) stale = stale || now - q->posted > std::chrono::microseconds(B->flush_us);
+            }
             if (everyone || stale) {
                 Lv.leading = true;
                 std::vector<KktBatcher::Impl::Req*> take;
@@ -289,7 +295,8 @@ static int submit(KktBatcher* B, KktBatcher::Impl::Req& r) {
                 continue;
             }
         }
-        I->cv.wait_for(lk, std::chrono::microseconds(50));
+        if (std::chrono::steady_clock::now() >= deadline) I->cv.wait_for(lk, std::chrono::microseconds(B->flush_us));   // (stale already, a leader is busy)
+        else I->cv.wait_until(lk, deadline);
     }
 }
 }  // namespace mi355x
@@ -1173,6 +1180,7 @@ void eMI355X::solve() {
                 configureDevice(_dev.get());
                 mi355x::NlpOptions o = li == 0 ? opt : warm;
                 o.tol = std::max(opt.tol, 1e-6);          // intermediate meshes only feed the next guess
+                if (li > 0 && _algorithm.rung_patience > 0) o.max_iter = std::min(o.max_iter, _algorithm.rung_patience);
                 if (li == 0) {
                     P.guess_bend = bend;
                     solve_cold_with_retries(o);

@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--batch", default="1,4,16,32")
     ap.add_argument("--lowrank", type=int, default=770)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--opt", default="", help="process-wide kkt_* options, name=value,...")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "kkt_times.jsonl"))
     a = ap.parse_args()
     lib = L.load()
@@ -58,6 +59,8 @@ def main():
         ev.set_model(1, W.QUAD_PARAMS)
         ev.set_batch(1)
         evs.append(ev)
+    for kv in [x for x in a.opt.split(",") if x]:
+        evs[0].set_option(kv.split("=")[0], int(kv.split("=")[1]))
     probs = [problem(evs[0], M, ns, nv, rng) for _ in range(min(nmax, 4))]
     probs = [probs[b % len(probs)] for b in range(nmax)]
     r = min(a.lowrank, M)
@@ -120,7 +123,7 @@ def main():
                 x[:] = b0
             lib.emi_kkt_solve_refined_batch(n, ctxs, Rp, dp(dc), 8, dp(relv), ip(nsv), ip(rev), ip(stat))
         t["refined"] = 1e3 * (time.perf_counter() - t0) / a.reps / n
-        rec = dict(nodes=M, form="batched", n=n, lowrank_columns=r, ms_per_scenario=t, refined_solves=float(nsv.mean()), refined_rel=float(relv.max()))
+        rec = dict(nodes=M, form="batched", opt=a.opt, n=n, lowrank_columns=r, ms_per_scenario=t, refined_solves=float(nsv.mean()), refined_rel=float(relv.max()))
         print(json.dumps(rec), flush=True)
         open(a.out, "a").write(json.dumps(rec) + "\n")
     for e in evs:

@@ -21,7 +21,8 @@ import csv, glob, json, os, collections
 out = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out"
 KEYS = ("emi_nodes_kernel", "emi_pass_f64_kernel", "emi_symdefect_ring2_f64_kernel", "emi_symdefect_combine_kernel",
         "emi_symdefect_ring_f64_kernel", "emi_symdefect_f64_kernel", "emi_defect_f64_kernel", "emi_defect_f32_mfma_kernel",
-        "emi_cost_finish_kernel")
+        "emi_defect_f32_ring_kernel", "emi_pass_f32_kernel", "emi_cost_finish_kernel")
+MESH = int(os.environ.get("PMC_M", "1024"))
 entries = []
 for b in os.environ["PMC_BATCHES"].split():
     res = {}
@@ -40,12 +41,12 @@ for b in os.environ["PMC_BATCHES"].split():
     # wide coalesced stream -> doubled (MI355X_MICROARCH.md, HBM)
     for k in sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])):
         f, w = res["FETCH_SIZE"].get(k, 0.0), res["WRITE_SIZE"].get(k, 0.0)
-        entries.append({"kernel": k, "B": int(b), "M": 1024, "fetch_bytes": 2.0 * f * 1024.0, "write_bytes": w * 1024.0,
+        entries.append({"kernel": k, "B": int(b), "M": MESH, "fetch_bytes": 2.0 * f * 1024.0, "write_bytes": w * 1024.0,
                         "bytes_per_launch": (2.0 * f + w) * 1024.0, "raw": {"FETCH_SIZE": f, "WRITE_SIZE": w},
                         "source": f"tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) --kernel-trace -- "
                                   f"python bench.py --steps 5 --warmup 2 --scenarios {b} {os.environ.get('PMC_ARGS', '')}".strip()})
         print(b, k, "fetch %.1f MB  write %.1f MB  total %.1f MB" % (2 * f * 1024 / 1e6, w * 1024 / 1e6, (2 * f + w) * 1024 / 1e6))
 summary = {"unit_note": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, per launch, averaged over the dispatches of a run",
            "entries": entries}
-json.dump(summary, open(out + "/pmc_traffic.json", "w"), indent=1)
+json.dump(summary, open(out + "/" + os.environ.get("PMC_OUT", "pmc_traffic.json"), "w"), indent=1)
 PY
