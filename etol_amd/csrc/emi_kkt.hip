@@ -56,7 +56,8 @@ struct KktTuning {
     // batched entry points: from this many rows of the Schur complement on, the rocBLAS calls of a batch go out once per scenario
     // (plain dgemm / dsyrk / dtrtri: large problems, where the pointer-array forms of the library run far below the plain ones)
     // instead of as *_batched calls (small problems, where a launch per scenario is what a batch is there to avoid)
-    std::atomic<int> batch_gemm_rows{3072};   // "kkt_batch_gemm_rows"
+    std::atomic<int> batch_gemm_rows{1 << 30};  // "kkt_batch_gemm_rows" (measured: rocblas_dgemm_batched holds up at 6144 rows -- 5.4 against 6.3 ms per scenario at 8 scenarios of 1024 nodes -- while
+                                              // rocblas_dsyrk_batched takes 121 ms where dsyrk takes a few: profiles/r04_kkt_times.jsonl)
     std::atomic<int> batch_syrk_rows{3072};   // "kkt_batch_syrk_rows"
     std::atomic<int> batch_trtri_rows{3072};  // "kkt_batch_trtri_rows"
 };

@@ -1179,7 +1179,7 @@ void eMI355X::solve() {
                 if (li == 0) setMesh(ladder[0]);
                 configureDevice(_dev.get());
                 mi355x::NlpOptions o = li == 0 ? opt : warm;
-                o.tol = std::max(opt.tol, 1e-6);          // intermediate meshes only feed the next guess
+                o.tol = std::max(opt.tol, _algorithm.rung_tolerance);          // intermediate meshes only feed the next guess
                 if (li > 0 && _algorithm.rung_patience > 0) o.max_iter = std::min(o.max_iter, _algorithm.rung_patience);
                 if (li == 0) {
                     P.guess_bend = bend;

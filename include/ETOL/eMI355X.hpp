@@ -81,6 +81,8 @@ struct Alg {
                                                    // Monte-Carlo sets, off by default)
     bool mesh_sequencing = true;                   // meshes above 80 nodes are reached through 33, 65, 129, ... nodes
     int guess_retries = 4;                         // a locally infeasible cold start is repeated from up to this many bent lines
+    double rung_tolerance = 1e-6;                  // NLP tolerance of the intermediate rungs of the mesh ladder (they only feed the next guess); the
+                                                   // requested mesh is solved to nlp_tolerance
     int rung_patience = 0;                         // > 0: a warm-started rung of the mesh ladder (65, 129, ... nodes) that is still iterating after
                                                    // this many iterations is given up like a failed one -- the ladder starts again from the next bent
                                                    // line.  Rungs that converge take 10 - 70 iterations; the ones that end "locally infeasible" (the
