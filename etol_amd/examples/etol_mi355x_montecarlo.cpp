@@ -191,7 +191,7 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced, co
     solver.getAlgorithm()->mesh_refinement = "none";
     if (getenv("EMI_MC_SCALING")) solver.getAlgorithm()->scaling = getenv("EMI_MC_SCALING");                 // "none" (default) / "automatic"
     if (getenv("EMI_MC_RUNG_TOL")) solver.getAlgorithm()->rung_tolerance = atof(getenv("EMI_MC_RUNG_TOL"));
-    solver.getAlgorithm()->rung_patience = env_int("EMI_MC_RUNG_PATIENCE", 0);                                   // iterations a ladder rung may take (0: nlp_iter_max)
+    if (getenv("EMI_MC_RUNG_PATIENCE")) solver.getAlgorithm()->rung_patience = env_int("EMI_MC_RUNG_PATIENCE", 0);                                   // iterations a ladder rung may take (0: nlp_iter_max)
     solver.getAlgorithm()->nlp_iter_budget = env_int("EMI_MC_BUDGET", 0);                                       // iterations per scenario over all meshes (0: no limit)
     if (getenv("EMI_MC_DEFECT_SCALING")) solver.getAlgorithm()->defect_scaling = getenv("EMI_MC_DEFECT_SCALING");   // "state-based" (default) / "jacobian-based"
     if (getenv("EMI_MC_WARM_MU")) solver.getAlgorithm()->warm_mu_init = atof(getenv("EMI_MC_WARM_MU"));      // experiments

@@ -81,13 +81,16 @@ struct Alg {
                                                    // Monte-Carlo sets, off by default)
     bool mesh_sequencing = true;                   // meshes above 80 nodes are reached through 33, 65, 129, ... nodes
     int guess_retries = 4;                         // a locally infeasible cold start is repeated from up to this many bent lines
-    double rung_tolerance = 1e-6;                  // NLP tolerance of the intermediate rungs of the mesh ladder (they only feed the next guess); the
-                                                   // requested mesh is solved to nlp_tolerance
-    int rung_patience = 0;                         // > 0: a warm-started rung of the mesh ladder (65, 129, ... nodes) that is still iterating after
-                                                   // this many iterations is given up like a failed one -- the ladder starts again from the next bent
-                                                   // line.  Rungs that converge take 10 - 70 iterations; the ones that end "locally infeasible" (the
-                                                   // interpolant sits on the wrong side of a keep-out) take 280 - 360 to say so, twice in a row in the
-                                                   // two slowest scenarios of a 64 x 1024-node set (profiles/r04_notes.md)
+    double rung_tolerance = 1e-4;                  // NLP tolerance of the intermediate rungs of the mesh ladder: they only feed the next guess (the
+                                                   // requested mesh is solved to nlp_tolerance).  1e-6 until round 4; 64 x 1024-node Monte-Carlo set, 8
+                                                   // threads, rung patience 100: 2.59 solves/s and 151 mean iterations at 1e-6, 3.06 / 134 at 1e-4, 3.27 /
+                                                   // 126 at 1e-3 (profiles/r04_montecarlo_ladder_knobs.jsonl)
+    int rung_patience = 100;                       // a warm-started rung of the mesh ladder (65, 129, ... nodes) that is still iterating after this many
+                                                   // iterations is given up like a failed one -- the ladder starts again from the next bent line (0: only
+                                                   // nlp_iter_max applies).  Rungs that converge take 10 - 70 iterations; the ones that end "locally
+                                                   // infeasible" (the interpolant sits on the wrong side of a keep-out) took 280 - 360 to say so, twice in
+                                                   // a row in the two slowest scenarios of the 64 x 1024-node set (943 and 920 iterations): 1.93 solves/s
+                                                   // without the rule, 2.50 - 2.60 with 60 - 100, 2.35 - 2.41 with 80 / 150 (paths differ) (r04_notes.md)
     double mu_restart = 10.0;                      // NlpOptions::mu_restart of the warm starts: barrier parameter x this (at most 1e-3), once, when a warm
                                                    // start stagnates at a small parameter (0: off; 10 and 100 measured: profiles/r02_notes.md section 12)
     int warm_patience = 0;                         // > 0: a warm start (interpolated guess) still running after this many iterations is
