@@ -310,7 +310,7 @@ def main():
         ev.set_batch(B)
         if os.environ.get("EMI_OVERLAP", "1") == "0":
             ev.set_option("overlap", 0)        # A/B switch: sequential general path
-        for opt in ("sym_ct", "overlap_mode", "sym_order", "sym_ablate", "cu_split", "node_store", "sym_cpart", "sym_ksplit", "sym_nst", "f32_ring", "f32_ring_wgs", "sym_bk"):   # experiment knobs
+        for opt in ("sym_ct", "overlap_mode", "sym_order", "sym_ablate", "cu_split", "node_store", "sym_cpart", "sym_ksplit", "sym_nst", "f32_ring", "f32_ring_wgs", "sym_bk", "sym_ctc"):   # experiment knobs
             if os.environ.get("EMI_" + opt.upper()):
                 ev.set_option(opt, int(os.environ["EMI_" + opt.upper()]))
         if c5:

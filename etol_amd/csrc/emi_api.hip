@@ -83,6 +83,7 @@ struct emi_ctx_s {
     DevBuf d_ticket;            // [B] arrival counters of the in-kernel COST finish (zeroed once, self-resetting)
     bool cost_in_kernel = true; // "cost_in_kernel": the node kernel of the overlapped pass finishes COST itself (ticket), no emi_cost_finish_kernel
     int sym_nst = 3;            // "sym_nst": ring stages of the one-launch pass (3 or 4)
+    int sym_ctc = 0;            // "sym_ctc": 64-column sub-tiles per MFMA workgroup of the one-launch pass (1 or 2; 0: by batch size, plan_pass)
     int sym_bk = 0;             // "sym_bk": depth of a K tile of the one-launch pass (8 or 16; 0: by batch size, plan_pass)
     // delayed values (emi_set_delays): x_horizon - 1 delayed copies of every state and u_horizon of every control, appended to the
     // controls the node functions see: nc = nc_free + nch; W[d] = interpolation matrix of delay (d + 1) dt on this mesh
@@ -294,6 +295,16 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
     const bool deep_large = auto_ct && !c->rtc && c->sym_bk == 0 && c->sym_nst == 3 && c->pass_order < 0 && p.tiles16 >= 208 && p.tiles16 < 768;
     const int bk_want = c->sym_bk ? c->sym_bk : ((deep_mid || deep_large) ? 16 : 8);
     if (bk_want == 16 && !c->rtc && plan.ks == 1 && (plan.sw == 1 || plan.sw == 2) && plan.nst == 3) plan.bk = 16;
+    // two column sub-tiles per MFMA workgroup ("sym_ctc" 2; built-in models, SW = 2, unsplit, three stages): the plan is made again with
+    // the wider tiles (tile counts and tile order change with the column width)
+    const int ctc_want = c->sym_ctc ? c->sym_ctc : 1;
+    if (ctc_want == 2 && !c->rtc && plan.ks == 1 && plan.sw == 2 && plan.nst == 3 && c->M % 256 == 0) {
+        const int bk_keep = plan.bk;
+        plan = emi::plan_symdefect(c->ns, B, c->M, 6, 1, c->sym_cpart, gblk_first, c->sym_cx, bk_keep, 2);
+        plan.ks = 1;
+        plan.nst = 3;
+        plan.bk = bk_keep;
+    }
     p.sym = plan;
     p.mfma_first = c->pass_order >= 0 ? c->pass_order
                                       : (p.tiles16 < 208 ? 1 : (p.tiles16 < 384 ? 125 : (p.tiles16 < 768 ? 110 : 0)));
@@ -976,7 +987,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             if (pe) pe->level = -1;                 // one bracket: the pass kernel
             c->last_defect_kernel = "emi_pass_f64_kernel<SW=" + std::to_string(plan.sw) + "> (MFMA + node roles, one launch" +
                                     (plan.ks > 1 ? ", " + std::to_string(plan.ks) + " K slices per tile" : "") + ")" +
-                                    (plan.bk == 16 ? " [K tiles of 16]" : "");
+                                    (plan.bk == 16 ? " [K tiles of 16]" : "") + (plan.ct == 2 ? " [128-column tiles]" : "");
             return EMI_OK;
         }
         const bool two = c->overlap_mode != 1;
@@ -1503,6 +1514,11 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         c->sym_nst = value;
         return EMI_OK;
     }
+    if (strcmp(name, "sym_ctc") == 0) {
+        if (value < 0 || value > 2) return fail(c, EMI_ERR_ARG, "sym_ctc must be 0 (by batch size), 1 or 2");
+        c->sym_ctc = value;
+        return EMI_OK;
+    }
     if (strcmp(name, "sym_bk") == 0) {
         if (value != 0 && value != 8 && value != 16) return fail(c, EMI_ERR_ARG, "sym_bk must be 0 (by batch size), 8 or 16");
         c->sym_bk = value;
@@ -1559,6 +1575,7 @@ int emi_plan_pass(emi_ctx_t c, int B, emi_pass_plan_t* out) {
         out->ksplit = p.sym.ks;
         out->ring_stages = p.sym.nst;
         out->k_tile = p.sym.bk;
+        out->column_tiles = p.sym.ct;
         out->cpart = p.sym.cpart;
         out->cx = p.sym.cx;
         out->mfma_workgroups = p.sym.tiles * p.sym.ks;

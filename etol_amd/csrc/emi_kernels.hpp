@@ -39,11 +39,12 @@ struct SymPlan {
     int ks = 1;               // ... and K slices per tile (> 1: partial sums through a slab, combined in-kernel by ticket or by a second launch)
     int nst = 3;              // ring stages of the one-launch pass (3 or 4: K tiles in flight = nst - 1)
     int bk = 8;               // depth of a K tile of the one-launch pass (8, or 16: SW 1 / 2 with three stages)
+    int ct = 1;               // 64-column sub-tiles per MFMA workgroup of the one-launch pass (2: SW = 2, unsplit, M % 256 == 0)
     size_t slab_bytes = 0;
     int cpart = 0, cx = 0;    // tile order (SymDefectArgs::cpart, cx): 0 = plain, > 0 column partitions, < 0 grouped (-G)
     int tiles = 0;            // tiles of the launch (instance groups x column tiles x state groups): tickets of an in-kernel combine
 };
-SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_opt = 0, int gblk_opt = 0, int cx_opt = 0, int bk_opt = 8);
+SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_opt = 0, int gblk_opt = 0, int cx_opt = 0, int bk_opt = 8, int ct_cols = 1);
 hipError_t launch_symdefect(int model, const SymDefectArgs& a, hipStream_t s, bool set_attr, int ct, const SymPlan& plan);
 // the whole pass as one launch (MFMA-role and node-role workgroups in one grid; COST finished in-kernel)
 bool pass_supported(int model, int ns, int B, int M, const SymPlan& plan);

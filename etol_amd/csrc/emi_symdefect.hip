@@ -99,10 +99,10 @@ static hipError_t launch_ring2_model(const SymDefectArgs& a, hipStream_t s) {
 //   fewer (the shard of config 4: 128 instances = 64 tiles for 256 CUs): SW = 1 (<= 96 tiles) or 2, i.e. more workgroups
 //      than CUs (0.055 ms at 128 instances; SW = NS with 4 K slices, the choice before the K loop was software-pipelined: 0.089).
 // ct 5 / 6 / 7 / 8 force SW = NS / 2 / 1 / 3; ksplit_opt > 0 forces the slice count.
-SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_opt, int gblk_opt, int cx_opt, int bk_opt) {
+SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_opt, int gblk_opt, int cx_opt, int bk_opt, int ct_cols) {
     SymPlan p;
     p.bk = bk_opt == 16 ? 16 : 8;
-    const int tiles = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64);
+    const int tiles = ((B + FUSED_TI - 1) / FUSED_TI) * ((M / 2) / 64);    // in 64-column tiles: what the thresholds below are written in
     const int nkt = (M / 2) / p.bk;
     if (ct == 0 || ct == 4) {
         if (tiles >= 448) p.sw = (ns % 2 == 0 && ns > 2) ? 2 : ns;
@@ -118,10 +118,12 @@ SymPlan plan_symdefect(int ns, int B, int M, int ct, int ksplit_opt, int cpart_o
     }
     if (ksplit_opt > 0) p.ks = ksplit_opt;
     while (p.ks > 1 && (nkt % p.ks != 0 || nkt / p.ks < 2 || (nkt / p.ks) % 2 != 0)) p.ks >>= 1;
-    p.tiles = tiles * (ns / p.sw);
+    p.ct = (ct_cols == 2 && p.sw == 2 && p.ks == 1 && M % 256 == 0) ? 2 : 1;      // column sub-tiles per workgroup (one-launch pass, SW = 2, unsplit)
+    const int TNp = 64 * p.ct;
+    p.tiles = (tiles / p.ct) * (ns / p.sw);
     {   // tile order: the share of De / Do an XCD works on should stay in its 4 MB L2 beside everything else (<= 2 MB)
-        const int ntiles = (M / 2) / 64, ngrp = ((B + FUSED_TI - 1) / FUSED_TI) * (ns / p.sw);
-        const int target_cols = std::max(1, 4096 / M);          // column tiles whose two panels (512 M bytes each) make 2 MB
+        const int ntiles = (M / 2) / TNp, ngrp = ((B + FUSED_TI - 1) / FUSED_TI) * (ns / p.sw);
+        const int target_cols = std::max(1, 4096 / M / p.ct);   // column tiles whose two panels (512 M bytes each per 64 columns) make 2 MB
         auto valid = [&](int cp) { return cp >= 1 && cp <= 8 && ntiles % cp == 0 && ngrp % (8 / cp) == 0 && (ngrp * ntiles) % 8 == 0; };
         int cp = 0;
         if (cpart_opt > 0) cp = valid(cpart_opt) ? cpart_opt : 0;
@@ -162,13 +164,13 @@ static hipError_t launch_ring2_planned(const SymDefectArgs& a, hipStream_t s, co
 
 // ---------------------------------------------------------------------------------------------
 // the pass as one launch (emi_pass_f64_kernel): MFMA-role and node-role workgroups interleaved per XCD
-template <class Model, int SW, int NST, int BK = 8>
+template <class Model, int SW, int NST, int BK = 8, int CT = 1>
 static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<double>& na, hipStream_t s) {
     constexpr int NS = Model::NS;
     PassArgs a;
     a.s = sa;
     a.n = na;
-    const int mtiles = (sa.B + FUSED_TI - 1) / FUSED_TI, ntiles = (sa.M / 2) / 64;
+    const int mtiles = (sa.B + FUSED_TI - 1) / FUSED_TI, ntiles = (sa.M / 2) / (64 * CT);
     const int nm = mtiles * ntiles * (NS / SW) * (sa.ksplit > 1 ? sa.ksplit : 1);
     a.nbx = (na.M + 2 * EMI_NODE_THREADS - 1) / (2 * EMI_NODE_THREADS);
     const int nn = a.nbx * na.B;
@@ -176,11 +178,12 @@ static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<doub
     a.nn = nn;
     a.nm8 = (nm + 7) / 8;
     a.nn8 = (nn + 7) / 8;
-    const size_t lds = (size_t)NST * ((2 * SW * FUSED_TI + 2 * 64 + 63) / 64 * 64) * BK * sizeof(double);
+    const size_t lds = (size_t)NST * ((2 * SW * FUSED_TI + 2 * 64 * CT + 63) / 64 * 64) * BK * sizeof(double);
     static bool attr_done[4] = {false, false, false, false};
     const int st = (na.store_mode >= 0 && na.store_mode <= 3) ? na.store_mode : 0;   // result stores: plain / sc1 (write-through) / non-temporal / nt sc1
-    auto kern = st == 2 ? emi_pass_f64_kernel<Model, SW, 2, 2, NST, BK>
-              : (st == 1 ? emi_pass_f64_kernel<Model, SW, 2, 1, NST, BK> : (st == 3 ? emi_pass_f64_kernel<Model, SW, 2, 3, NST, BK> : emi_pass_f64_kernel<Model, SW, 2, 0, NST, BK>));
+    auto kern = st == 2 ? emi_pass_f64_kernel<Model, SW, 2, 2, NST, BK, CT>
+              : (st == 1 ? emi_pass_f64_kernel<Model, SW, 2, 1, NST, BK, CT>
+                         : (st == 3 ? emi_pass_f64_kernel<Model, SW, 2, 3, NST, BK, CT> : emi_pass_f64_kernel<Model, SW, 2, 0, NST, BK, CT>));
     if (!attr_done[st]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -195,6 +198,7 @@ static hipError_t launch_pass_planned(const SymDefectArgs& sa, const NodeArgs<do
     constexpr int NS = Model::NS;
     if (p.sw == NS) return launch_pass_model<Model, NS, 3>(sa, na, s);
     if constexpr (NS > 2 && NS % 2 == 0) {
+        if (p.sw == 2 && p.ct == 2) return p.bk == 16 ? launch_pass_model<Model, 2, 3, 16, 2>(sa, na, s) : launch_pass_model<Model, 2, 3, 8, 2>(sa, na, s);
         if (p.sw == 2 && p.bk == 16) return launch_pass_model<Model, 2, 3, 16>(sa, na, s);
         if (p.sw == 2) return p.nst > 3 ? launch_pass_model<Model, 2, 4>(sa, na, s) : launch_pass_model<Model, 2, 3>(sa, na, s);
     }

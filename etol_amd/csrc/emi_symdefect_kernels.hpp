@@ -487,10 +487,16 @@ EMI_DEV void ring_epilogue(const SymDefectArgs& a, const d4 (&acc_a)[SW], const 
 // flight per stage.  A pass of a small batch (the 128-instance shard of config 4) is the MFMA role's dependency chain of K tiles, and
 // with one state per workgroup a tile holds only four MFMAs (256 matrix-pipe cycles) against several hundred cycles of per-tile
 // work (profiles/r03_notes.md section 7: ~0.3 us per tile); the deep form halves the number of tiles.
-template <class Model, int SW, int NST = 3, int BK = 8>
+// CT = 2 (round 4): two 64-column sub-tiles per workgroup (wave w owns half-indices 16 w .. 16 w + 15 of each): an X tile is then read
+// by M / 256 column tiles instead of M / 128 -- the X operand tiles are the largest part of what the MFMA role fetches (X is read
+// ntiles times per pass: 384 of ~1550 HBM bytes per node-eval once the inputs of a large batch no longer sit in the Infinity Cache,
+// profiles/r03_notes.md section 2) -- and the A fragments (sums / differences of x) are shared by the MFMAs of both sub-tiles: 16
+// MFMAs per wave and K tile against 8 fragment reads and 5 DMA instructions (CT = 1, SW = 2: 8 against 6 and 3).
+template <class Model, int SW, int NST = 3, int BK = 8, int CT = 1>
 EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-slice id, XCD-local runs */) {
     constexpr int NS = Model::NS;
-    constexpr int TI = FUSED_TI, TM = SW * TI, TN = 64, CH = BK / 2, NSG = NS / SW;
+    constexpr int TI = FUSED_TI, TM = SW * TI, TN = 64 * CT, CH = BK / 2, NSG = NS / SW;
+    static_assert(CT == 1 || CT == 2, "one or two column sub-tiles per wave");
     constexpr int KH = BK / 8;                           // 16-byte fragment reads per operand row and K tile (each: two k-steps)
     constexpr int RPI = 64 / CH;                         // rows one DMA wave instruction moves (1 KB)
     static_assert(BK == 8 || BK == 16, "K tiles of 8 or 16");
@@ -589,12 +595,14 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         for (int t = 0; t < L; ++t) issue_one(t);
     };
 
-    d4 acc_a[SW], acc_b[SW];
+    d4 acc_a[SW][CT], acc_b[SW][CT];
 #pragma unroll
-    for (int s = 0; s < SW; ++s) {
-        acc_a[s] = d4{0.0, 0.0, 0.0, 0.0};
-        acc_b[s] = d4{0.0, 0.0, 0.0, 0.0};
-    }
+    for (int s = 0; s < SW; ++s)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            acc_a[s][c] = d4{0.0, 0.0, 0.0, 0.0};
+            acc_b[s][c] = d4{0.0, 0.0, 0.0, 0.0};
+        }
 
 #pragma unroll
     for (int t = 0; t < LOOK; ++t)
@@ -602,10 +610,13 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     // fragment addresses (doubles within a stage): B rows of this wave, A rows of every state
     // (half h of a deep tile: chunk kq + 4 h forward, k = 8 h + 2 kq, + 1; its mirror sits at position BK - 1 - k of the mirrored
     // tile, i.e. in chunk CH - 1 - kq - 4 h)
-    const int rb = wid * 16 + r16;
-    int off_b[KH], off_f[SW][KH], off_m[SW][KH];
+    int off_b[CT][KH], off_f[SW][KH], off_m[SW][KH];
 #pragma unroll
-    for (int h = 0; h < KH; ++h) off_b[h] = rb * BK + (((kq + 4 * h) ^ ring_swz_k<BK>(rb)) << 1);
+    for (int c = 0; c < CT; ++c) {
+        const int rb = c * 64 + wid * 16 + r16;        // row of De / Do within the tile: sub-tile c, this wave's sixteen half-indices
+#pragma unroll
+        for (int h = 0; h < KH; ++h) off_b[c][h] = rb * BK + (((kq + 4 * h) ^ ring_swz_k<BK>(rb)) << 1);
+    }
 #pragma unroll
     for (int s = 0; s < SW; ++s) {
         const int r = s * 16 + r16;
@@ -620,17 +631,19 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     // arrived (in the gaps of the PREVIOUS tile's MFMAs), not in front of the MFMA that consumes them: a v_add_f64 directly ahead of
     // its MFMA holds the matrix pipe for the result (the same finding as the shift subtractions of the fp32 kernel, r03_notes.md).
     struct Frag {
-        double2 be[KH], bo[KH], sp[SW][KH], dm[SW][KH];
+        double2 be[CT][KH], bo[CT][KH], sp[SW][KH], dm[SW][KH];
     };
     double2 txf[SW][KH], txm[SW][KH];                   // x fragments between their read and their sums
-    constexpr int NR = (2 + 2 * SW) * KH, NM = 4 * SW * KH;     // fragment reads / MFMAs per wave and K tile
-    // read r of a tile: half h = r / (2 + 2 SW), then De, Do, and (forward, mirrored) x of every state
+    constexpr int NRH = 2 * CT + 2 * SW;                // fragment reads per half of a tile
+    constexpr int NR = NRH * KH, NM = 4 * SW * CT * KH; // fragment reads / MFMAs per wave and K tile
+    // read r of a tile: half h = r / NRH, then (De, Do) of every sub-tile and (forward, mirrored) x of every state
     auto read_one = [&](Frag& f, const double* S, int r) {
-        const int h = r / (2 + 2 * SW), q = r % (2 + 2 * SW);
-        if (q == 0) f.be[h] = *reinterpret_cast<const double2*>(S + 2 * TM * BK + off_b[h]);
-        else if (q == 1) f.bo[h] = *reinterpret_cast<const double2*>(S + (2 * TM + TN) * BK + off_b[h]);
-        else if (q & 1) txm[(q - 2) >> 1][h] = *reinterpret_cast<const double2*>(S + off_m[(q - 2) >> 1][h]);
-        else txf[(q - 2) >> 1][h] = *reinterpret_cast<const double2*>(S + off_f[(q - 2) >> 1][h]);
+        const int h = r / NRH, q = r % NRH;
+        if (q < 2 * CT) {
+            if (q & 1) f.bo[q >> 1][h] = *reinterpret_cast<const double2*>(S + (2 * TM + TN) * BK + off_b[q >> 1][h]);
+            else f.be[q >> 1][h] = *reinterpret_cast<const double2*>(S + 2 * TM * BK + off_b[q >> 1][h]);
+        } else if (q & 1) txm[(q - 2 * CT) >> 1][h] = *reinterpret_cast<const double2*>(S + off_m[(q - 2 * CT) >> 1][h]);
+        else txf[(q - 2 * CT) >> 1][h] = *reinterpret_cast<const double2*>(S + off_f[(q - 2 * CT) >> 1][h]);
     };
     // k = 8h + 2kq (+1): forward x_k in xf.x (.y), its mirror x_(N-k) at position BK-1-k of the mirrored tile: xm.y (.x)
     auto sums_one = [&](Frag& f, int s) {
@@ -654,11 +667,13 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     };
     // MFMA i of a tile: the 2 SW MFMAs of the tile's first k-step, then those of the second, ... (2 KH k-steps; k-step j uses half
     // j / 2 of the fragments, element j % 2)
+    // (within a k-step: state, then sub-tile, then even / odd product)
     auto mfma_one = [&](const Frag& f, int i) {
-        const int s = (i % (2 * SW)) >> 1, j = i / (2 * SW), h = j >> 1;
-        const bool second = j & 1, odd = i & 1;
-        if (!odd) acc_a[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(second ? f.sp[s][h].y : f.sp[s][h].x, second ? f.be[h].y : f.be[h].x, acc_a[s], 0, 0, 0);
-        else      acc_b[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(second ? f.dm[s][h].y : f.dm[s][h].x, second ? f.bo[h].y : f.bo[h].x, acc_b[s], 0, 0, 0);
+        const int per = 2 * SW * CT, q = i % per, j = i / per, h = j >> 1;
+        const int s = q / (2 * CT), c = (q >> 1) % CT;
+        const bool second = j & 1, odd = q & 1;
+        if (!odd) acc_a[s][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(second ? f.sp[s][h].y : f.sp[s][h].x, second ? f.be[c][h].y : f.be[c][h].x, acc_a[s][c], 0, 0, 0);
+        else      acc_b[s][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(second ? f.dm[s][h].y : f.dm[s][h].x, second ? f.bo[c][h].y : f.bo[c][h].x, acc_b[s][c], 0, 0, 0);
     };
     auto multiply = [&](const Frag& f) {
 #pragma unroll
@@ -728,15 +743,15 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         }
     }
 
-    if (KS > 1) {       // partial sums of this K slice -> slab (coalesced: one 2 KB row per register)
+    if (CT == 1 && KS > 1) {       // (K slices: single sub-tile form only) partial sums of this K slice -> slab (coalesced: one 2 KB row per register)
         double* sl = a.slab + ((size_t)tile * KS + kslice) * (2 * SW * 4) * 256 + tid;
         if (a.tile_ticket == nullptr) {                 // emi_symdefect_combine_kernel adds the slices
 #pragma unroll
             for (int s = 0; s < SW; ++s)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    sl[(size_t)((2 * s) * 4 + i) * 256] = acc_a[s][i];
-                    sl[(size_t)((2 * s + 1) * 4 + i) * 256] = acc_b[s][i];
+                    sl[(size_t)((2 * s) * 4 + i) * 256] = acc_a[s][0][i];
+                    sl[(size_t)((2 * s + 1) * 4 + i) * 256] = acc_b[s][0][i];
                 }
             return;
         }
@@ -748,8 +763,8 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         for (int s = 0; s < SW; ++s)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                __hip_atomic_store(sl + (size_t)((2 * s) * 4 + i) * 256, acc_a[s][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(sl + (size_t)((2 * s + 1) * 4 + i) * 256, acc_b[s][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sl + (size_t)((2 * s) * 4 + i) * 256, acc_a[s][0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sl + (size_t)((2 * s + 1) * 4 + i) * 256, acc_b[s][0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                // every thread's partial sums are out (and the ring is no longer read)
@@ -759,8 +774,8 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         if (*flag != (unsigned)KS - 1u) return;
 #pragma unroll
         for (int s = 0; s < SW; ++s) {
-            acc_a[s] = d4{0.0, 0.0, 0.0, 0.0};
-            acc_b[s] = d4{0.0, 0.0, 0.0, 0.0};
+            acc_a[s][0] = d4{0.0, 0.0, 0.0, 0.0};
+            acc_b[s][0] = d4{0.0, 0.0, 0.0, 0.0};
         }
         for (int k = 0; k < KS; ++k) {                  // fixed order
             const double* sk = a.slab + ((size_t)tile * KS + k) * (2 * SW * 4) * 256 + tid;
@@ -768,14 +783,21 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
             for (int s = 0; s < SW; ++s)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    acc_a[s][i] += __hip_atomic_load(sk + (size_t)((2 * s) * 4 + i) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    acc_b[s][i] += __hip_atomic_load(sk + (size_t)((2 * s + 1) * 4 + i) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc_a[s][0][i] += __hip_atomic_load(sk + (size_t)((2 * s) * 4 + i) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc_b[s][0][i] += __hip_atomic_load(sk + (size_t)((2 * s + 1) * 4 + i) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
         }
         if (tid == 0) __hip_atomic_store(a.tile_ticket + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_s_setprio(0);      // the epilogue gives the instruction arbiter back to the waves still in their K loops (0.5 - 1 % of the pass)
-    ring_epilogue<Model, SW>(a, acc_a, acc_b, inst0, i0, s0, wid, r16, kq);
+    // one sub-tile after the other: its accumulators, its 64 output half-indices
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        d4 ea[SW], eb[SW];
+#pragma unroll
+        for (int s2 = 0; s2 < SW; ++s2) { ea[s2] = acc_a[s2][c]; eb[s2] = acc_b[s2][c]; }
+        ring_epilogue<Model, SW>(a, ea, eb, inst0, i0 + 64 * c, s0, wid, r16, kq);
+    }
 }
 
 template <class Model, int SW>
@@ -839,7 +861,7 @@ __global__ __launch_bounds__(256) void emi_symdefect_combine_kernel(SymDefectArg
 #else
 #define EMI_PASS_OCC
 #endif
-template <class Model, int SW, int VEC, int ST, int NST = 3, int BK = 8>
+template <class Model, int SW, int VEC, int ST, int NST = 3, int BK = 8, int CT = 1>
 __global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs a) {
 #ifdef EMI_ENTRY_PAD_NOPS      // build-time experiment (tools/ab_build.sh): shift the whole instruction stream by 4-byte steps
     asm volatile(".rept " EMI_STR(EMI_ENTRY_PAD_NOPS) "\n\ts_nop 0\n\t.endr" ::: "memory");
@@ -853,7 +875,7 @@ __global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs
         // the MFMA role is the latency chain of a small pass (64 dependent K tiles); the streaming role beside it on the
         // same SIMDs waits on memory most of the time: instruction arbitration goes to the MFMA waves first
         __builtin_amdgcn_s_setprio(3);
-        emi_ring2_body<Model, SW, NST, BK>(a.s, tid);
+        emi_ring2_body<Model, SW, NST, BK, CT>(a.s, tid);
     } else {
         const int nid = xcd * a.nn8 + role.index;
         if (nid >= a.nn) return;

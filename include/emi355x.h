@@ -301,6 +301,7 @@ typedef struct emi_pass_plan {
   int tiles16;         /* 16-instance x 128-node tiles of the (first) launch */
   int piece, tail;     /* > 0: the batch goes out in launches of `piece` instances and a last one of `tail` (0: none) */
   int k_tile;          /* depth of a K tile of the MFMA role: 8 or 16 */
+  int column_tiles;    /* 64-column sub-tiles per MFMA workgroup: 1 or 2 */
 } emi_pass_plan_t;
 int emi_plan_pass(emi_ctx_t ctx, int B, emi_pass_plan_t* out);
 

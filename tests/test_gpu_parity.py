@@ -658,7 +658,7 @@ def test_every_mfma_defect_kernel_variant_matches_the_oracle(built, sym_ct, shap
     ev.close()
 
 
-@pytest.mark.parametrize("shape", [(1024, 128), (1024, 19), (128, 40), (384, 33), (2048, 16), (1024, 512)])
+@pytest.mark.parametrize("shape", [(1024, 128), (1024, 19), (128, 40), (384, 33), (2048, 16), (1024, 512), (256, 48), (768, 256)])
 def test_deep_k_tiles_of_the_mfma_role_match_the_oracle(built, shape):
     """"sym_bk" 16: K tiles of 16 instead of 8 in the MFMA role of the one-launch pass (half as many barriers and counted waits per
     flop; 128-byte operand rows, eight chunks, their own swizzle; two ds_read_b128 per operand row and tile; mirrored chunks 7 - kq
@@ -701,6 +701,30 @@ def test_deep_k_tiles_of_the_mfma_role_match_the_oracle(built, shape):
         ev.set_option("node_store", -1)
         ev.set_option("sym_cpart", 0)
         ev.set_option("sym_gblk", 0)
+        if sym_ct == 6 and M % 256 == 0:
+            # "sym_ctc" 2: two 64-column sub-tiles per MFMA workgroup (an X tile read by half as many workgroups, the x fragments shared by
+            # the MFMAs of both sub-tiles), with 8- and 16-deep K tiles, every store flavour and tile order: the same additions per
+            # output element in the same order, so again the bits of the base form
+            ev.set_option("sym_ctc", 2)
+            for bk in (8, 16):
+                ev.set_option("sym_bk", bk)
+                assert ev.plan(B)["column_tiles"] == 2 and ev.plan(B)["k_tile"] == bk
+                for store in (0, 2):
+                    ev.set_option("node_store", store)
+                    for cpart, gblk in ((0, 0), (-1, 0), (2, 0), (0, 2), (0, 1)):
+                        ev.set_option("sym_cpart", cpart)
+                        ev.set_option("sym_gblk", gblk)
+                        poison = ev.eval_host(X + 1.0, U)
+                        got = ev.eval_host(X, U)
+                        assert "128-column tiles" in ev.last_defect_kernel, ev.last_defect_kernel
+                        check(c, ev, got, ref)
+                        assert not np.array_equal(poison[0], got[0])
+                        assert np.array_equal(got[0], base[0]), (bk, store, cpart, gblk)
+            ev.set_option("sym_ctc", 0)
+            ev.set_option("sym_bk", 0)
+            ev.set_option("node_store", -1)
+            ev.set_option("sym_cpart", 0)
+            ev.set_option("sym_gblk", 0)
     ev.close()
 
 
