@@ -38,7 +38,7 @@ class Layout(C.Structure):
 class PassPlan(C.Structure):
     """emi_pass_plan_t: what the default dispatch does with a batch (include/emi355x.h, emi_plan_pass)"""
     _fields_ = [(n, C.c_int) for n in ("one_launch", "sw", "ksplit", "ring_stages", "cpart", "cx", "mfma_workgroups", "store_mode",
-                                       "block_order", "tiles16", "piece", "tail", "k_tile", "column_tiles")]
+                                       "block_order", "tiles16", "piece", "tail", "k_tile", "column_tiles", "k_halves")]
 
 
 _P = C.c_void_p

@@ -83,6 +83,7 @@ struct emi_ctx_s {
     DevBuf d_ticket;            // [B] arrival counters of the in-kernel COST finish (zeroed once, self-resetting)
     bool cost_in_kernel = true; // "cost_in_kernel": the node kernel of the overlapped pass finishes COST itself (ticket), no emi_cost_finish_kernel
     int sym_nst = 3;            // "sym_nst": ring stages of the one-launch pass (3 or 4)
+    int sym_hs = 0;             // "sym_hs": 2: K range of a tile in two halves inside the workgroup (512 threads); 1: undivided; 0: by batch size
     int sym_ctc = 0;            // "sym_ctc": 64-column sub-tiles per MFMA workgroup of the one-launch pass (1 or 2; 0: by batch size, plan_pass)
     int sym_bk = 0;             // "sym_bk": depth of a K tile of the one-launch pass (8 or 16; 0: by batch size, plan_pass)
     // delayed values (emi_set_delays): x_horizon - 1 delayed copies of every state and u_horizon of every control, appended to the
@@ -305,6 +306,11 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
         plan.nst = 3;
         plan.bk = bk_keep;
     }
+    // the K range in two halves inside the workgroup ("sym_hs" 2; built-in models, SW 1 or 2, unsplit, one sub-tile, three stages)
+    const int hs_want = c->sym_hs ? c->sym_hs : 1;
+    if (hs_want == 2 && !c->rtc && plan.ks == 1 && plan.ct == 1 && (plan.sw == 1 || plan.sw == 2) && plan.nst == 3 &&
+        ((c->M / 2) / plan.bk) % 4 == 0)
+        plan.hs = 2;
     p.sym = plan;
     p.mfma_first = c->pass_order >= 0 ? c->pass_order
                                       : (p.tiles16 < 208 ? 1 : (p.tiles16 < 384 ? 125 : (p.tiles16 < 768 ? 110 : 0)));
@@ -987,7 +993,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
             if (pe) pe->level = -1;                 // one bracket: the pass kernel
             c->last_defect_kernel = "emi_pass_f64_kernel<SW=" + std::to_string(plan.sw) + "> (MFMA + node roles, one launch" +
                                     (plan.ks > 1 ? ", " + std::to_string(plan.ks) + " K slices per tile" : "") + ")" +
-                                    (plan.bk == 16 ? " [K tiles of 16]" : "") + (plan.ct == 2 ? " [128-column tiles]" : "");
+                                    (plan.bk == 16 ? " [K tiles of 16]" : "") + (plan.ct == 2 ? " [128-column tiles]" : "") + (plan.hs == 2 ? " [K range in two halves per workgroup]" : "");
             return EMI_OK;
         }
         const bool two = c->overlap_mode != 1;
@@ -1514,6 +1520,11 @@ int emi_set_option(emi_ctx_t c, const char* name, int value) {
         c->sym_nst = value;
         return EMI_OK;
     }
+    if (strcmp(name, "sym_hs") == 0) {
+        if (value < 0 || value > 2) return fail(c, EMI_ERR_ARG, "sym_hs must be 0 (by batch size), 1 or 2");
+        c->sym_hs = value;
+        return EMI_OK;
+    }
     if (strcmp(name, "sym_ctc") == 0) {
         if (value < 0 || value > 2) return fail(c, EMI_ERR_ARG, "sym_ctc must be 0 (by batch size), 1 or 2");
         c->sym_ctc = value;
@@ -1576,6 +1587,7 @@ int emi_plan_pass(emi_ctx_t c, int B, emi_pass_plan_t* out) {
         out->ring_stages = p.sym.nst;
         out->k_tile = p.sym.bk;
         out->column_tiles = p.sym.ct;
+        out->k_halves = p.sym.hs;
         out->cpart = p.sym.cpart;
         out->cx = p.sym.cx;
         out->mfma_workgroups = p.sym.tiles * p.sym.ks;

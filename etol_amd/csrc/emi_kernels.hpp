@@ -39,6 +39,7 @@ struct SymPlan {
     int ks = 1;               // ... and K slices per tile (> 1: partial sums through a slab, combined in-kernel by ticket or by a second launch)
     int nst = 3;              // ring stages of the one-launch pass (3 or 4: K tiles in flight = nst - 1)
     int bk = 8;               // depth of a K tile of the one-launch pass (8, or 16: SW 1 / 2 with three stages)
+    int hs = 1;               // 2: the K range of a tile in two halves inside a 512-thread workgroup, combined through LDS (SW 1 / 2, unsplit, one sub-tile)
     int ct = 1;               // 64-column sub-tiles per MFMA workgroup of the one-launch pass (2: SW = 2, unsplit, M % 256 == 0)
     size_t slab_bytes = 0;
     int cpart = 0, cx = 0;    // tile order (SymDefectArgs::cpart, cx): 0 = plain, > 0 column partitions, < 0 grouped (-G)

@@ -164,7 +164,7 @@ static hipError_t launch_ring2_planned(const SymDefectArgs& a, hipStream_t s, co
 
 // ---------------------------------------------------------------------------------------------
 // the pass as one launch (emi_pass_f64_kernel): MFMA-role and node-role workgroups interleaved per XCD
-template <class Model, int SW, int NST, int BK = 8, int CT = 1>
+template <class Model, int SW, int NST, int BK = 8, int CT = 1, int HS = 1>
 static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<double>& na, hipStream_t s) {
     constexpr int NS = Model::NS;
     PassArgs a;
@@ -178,18 +178,18 @@ static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<doub
     a.nn = nn;
     a.nm8 = (nm + 7) / 8;
     a.nn8 = (nn + 7) / 8;
-    const size_t lds = (size_t)NST * ((2 * SW * FUSED_TI + 2 * 64 * CT + 63) / 64 * 64) * BK * sizeof(double);
+    const size_t lds = (size_t)HS * NST * ((2 * SW * FUSED_TI + 2 * 64 * CT + 63) / 64 * 64) * BK * sizeof(double);
     static bool attr_done[4] = {false, false, false, false};
     const int st = (na.store_mode >= 0 && na.store_mode <= 3) ? na.store_mode : 0;   // result stores: plain / sc1 (write-through) / non-temporal / nt sc1
-    auto kern = st == 2 ? emi_pass_f64_kernel<Model, SW, 2, 2, NST, BK, CT>
-              : (st == 1 ? emi_pass_f64_kernel<Model, SW, 2, 1, NST, BK, CT>
-                         : (st == 3 ? emi_pass_f64_kernel<Model, SW, 2, 3, NST, BK, CT> : emi_pass_f64_kernel<Model, SW, 2, 0, NST, BK, CT>));
+    auto kern = st == 2 ? emi_pass_f64_kernel<Model, SW, 2, 2, NST, BK, CT, HS>
+              : (st == 1 ? emi_pass_f64_kernel<Model, SW, 2, 1, NST, BK, CT, HS>
+                         : (st == 3 ? emi_pass_f64_kernel<Model, SW, 2, 3, NST, BK, CT, HS> : emi_pass_f64_kernel<Model, SW, 2, 0, NST, BK, CT, HS>));
     if (!attr_done[st]) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_done[st] = true;
     }
-    hipLaunchKernelGGL(kern, dim3(8 * (a.nm8 + a.nn8)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(8 * (a.nm8 + a.nn8)), dim3(256 * HS), lds, s, a);
     return hipGetLastError();
 }
 
@@ -198,6 +198,7 @@ static hipError_t launch_pass_planned(const SymDefectArgs& sa, const NodeArgs<do
     constexpr int NS = Model::NS;
     if (p.sw == NS) return launch_pass_model<Model, NS, 3>(sa, na, s);
     if constexpr (NS > 2 && NS % 2 == 0) {
+        if (p.sw == 2 && p.hs == 2 && p.ct == 1) return p.bk == 16 ? launch_pass_model<Model, 2, 3, 16, 1, 2>(sa, na, s) : launch_pass_model<Model, 2, 3, 8, 1, 2>(sa, na, s);
         if (p.sw == 2 && p.ct == 2) return p.bk == 16 ? launch_pass_model<Model, 2, 3, 16, 2>(sa, na, s) : launch_pass_model<Model, 2, 3, 8, 2>(sa, na, s);
         if (p.sw == 2 && p.bk == 16) return launch_pass_model<Model, 2, 3, 16>(sa, na, s);
         if (p.sw == 2) return p.nst > 3 ? launch_pass_model<Model, 2, 4>(sa, na, s) : launch_pass_model<Model, 2, 3>(sa, na, s);
@@ -205,6 +206,7 @@ static hipError_t launch_pass_planned(const SymDefectArgs& sa, const NodeArgs<do
     if constexpr (NS > 3 && NS % 3 == 0) {
         if (p.sw == 3) return launch_pass_model<Model, 3, 3>(sa, na, s);
     }
+    if (p.hs == 2) return p.bk == 16 ? launch_pass_model<Model, 1, 3, 16, 1, 2>(sa, na, s) : launch_pass_model<Model, 1, 3, 8, 1, 2>(sa, na, s);
     if (p.bk == 16) return launch_pass_model<Model, 1, 3, 16>(sa, na, s);
     return p.nst > 3 ? launch_pass_model<Model, 1, 4>(sa, na, s) : launch_pass_model<Model, 1, 3>(sa, na, s);
 }

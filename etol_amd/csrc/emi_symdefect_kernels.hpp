@@ -492,7 +492,12 @@ EMI_DEV void ring_epilogue(const SymDefectArgs& a, const d4 (&acc_a)[SW], const 
 // ntiles times per pass: 384 of ~1550 HBM bytes per node-eval once the inputs of a large batch no longer sit in the Infinity Cache,
 // profiles/r03_notes.md section 2) -- and the A fragments (sums / differences of x) are shared by the MFMAs of both sub-tiles: 16
 // MFMAs per wave and K tile against 8 fragment reads and 5 DMA instructions (CT = 1, SW = 2: 8 against 6 and 3).
-template <class Model, int SW, int NST = 3, int BK = 8, int CT = 1>
+// HS = 2 (round 4): the K range of a tile cut in two INSIDE the workgroup -- 512 threads, waves 0 - 3 take the first half of the K tiles,
+// waves 4 - 7 the second, each half with its own operand ring; the halves meet once, at the end, where the second leaves its partial sums
+// in LDS (in the ring it no longer needs) and the first adds them and runs the epilogue.  What K slices through the slab do for small
+// batches (a shorter dependency chain, two MFMA waves per SIMD filling each other's gaps) without a second workgroup, global partial
+// sums or a ticket.  The sums of the two halves are added once: not the bits of the unsplit form, the same values to rounding.
+template <class Model, int SW, int NST = 3, int BK = 8, int CT = 1, int HS = 1>
 EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-slice id, XCD-local runs */) {
     constexpr int NS = Model::NS;
     constexpr int TI = FUSED_TI, TM = SW * TI, TN = 64 * CT, CH = BK / 2, NSG = NS / SW;
@@ -507,11 +512,14 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     constexpr int L = ROWS_PAD * CH / 256;               // LDS-DMA instructions per wave and stage (1 KB each)
     static_assert(NS % SW == 0, "states split evenly over workgroups");
 
-    extern __shared__ __attribute__((aligned(16))) double smem[];   // [NST][STAGE]: XF, XM, De, Do (, padding)
+    extern __shared__ __attribute__((aligned(16))) double smem_all[];   // [HS][NST][STAGE]: XF, XM, De, Do (, padding)
+    static_assert(HS == 1 || HS == 2, "the K range whole or in two halves");
+    const int half = HS > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+    double* const smem = smem_all + (size_t)half * NST * STAGE;          // this half's ring
 
     const int M = a.M, Hh = M >> 1, B = a.B;
     const int ntiles = Hh / TN;
-    const int KS = a.ksplit > 1 ? a.ksplit : 1;
+    const int KS = (HS == 1 && a.ksplit > 1) ? a.ksplit : 1;            // (slices through the slab: the undivided workgroup only)
     const int kslice = bid % KS;
     // Which tile.  bid / KS counts tiles in XCD-local runs (an XCD gets a contiguous range).  Plain order: the ntiles
     // column tiles of an X tile (same instance group, same states) are neighbours, so an XCD's L2 sees each X tile once --
@@ -526,7 +534,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     const int sg = grp % NSG, mtile = grp / NSG;
     const int inst0 = mtile * TI, i0 = ntile * TN, s0 = sg * SW;
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x & 255, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
 
@@ -575,7 +583,7 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
     const unsigned lds0 = (unsigned)(unsigned long)(emi_lds_ptr_t)smem;          // LDS byte address of the ring
     // running state of the ring, all wave-uniform (SALU): next tile to request, where it goes, where the next fragment
     // reads come from -- an add per DMA instruction instead of a 64-bit multiply by the tile index and a modulo
-    const int nkt = (Hh / BK) / KS, kt0 = kslice * nkt;       // this slice's K tiles: kt0 .. kt0 + nkt - 1
+    const int nkt = (Hh / BK) / KS / HS, kt0 = (kslice * HS + half) * nkt;       // this slice's (half's) K tiles: kt0 .. kt0 + nkt - 1
     unsigned long long gnext[L];
 #pragma unroll
     for (int t = 0; t < L; ++t) gnext[t] = gbase[t] + (long long)gstep[t] * kt0;
@@ -790,6 +798,34 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         if (tid == 0) __hip_atomic_store(a.tile_ticket + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __builtin_amdgcn_s_setprio(0);      // the epilogue gives the instruction arbiter back to the waves still in their K loops (0.5 - 1 % of the pass)
+    if constexpr (HS == 2) {
+        // the halves meet: the second half's partial sums through LDS (every wave is past its last fragment read: barrier), [register][thread]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        double* cb = smem_all + tid;
+        if (half == 1) {
+#pragma unroll
+            for (int s2 = 0; s2 < SW; ++s2)
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        cb[(size_t)(((2 * s2) * CT + c) * 4 + i) * 256] = acc_a[s2][c][i];
+                        cb[(size_t)(((2 * s2 + 1) * CT + c) * 4 + i) * 256] = acc_b[s2][c][i];
+                    }
+        }
+        __syncthreads();
+        if (half == 1) return;
+#pragma unroll
+        for (int s2 = 0; s2 < SW; ++s2)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc_a[s2][c][i] += cb[(size_t)(((2 * s2) * CT + c) * 4 + i) * 256];
+                    acc_b[s2][c][i] += cb[(size_t)(((2 * s2 + 1) * CT + c) * 4 + i) * 256];
+                }
+    }
     // one sub-tile after the other: its accumulators, its 64 output half-indices
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -861,8 +897,8 @@ __global__ __launch_bounds__(256) void emi_symdefect_combine_kernel(SymDefectArg
 #else
 #define EMI_PASS_OCC
 #endif
-template <class Model, int SW, int VEC, int ST, int NST = 3, int BK = 8, int CT = 1>
-__global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs a) {
+template <class Model, int SW, int VEC, int ST, int NST = 3, int BK = 8, int CT = 1, int HS = 1>
+__global__ __launch_bounds__(256 * HS) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs a) {
 #ifdef EMI_ENTRY_PAD_NOPS      // build-time experiment (tools/ab_build.sh): shift the whole instruction stream by 4-byte steps
     asm volatile(".rept " EMI_STR(EMI_ENTRY_PAD_NOPS) "\n\ts_nop 0\n\t.endr" ::: "memory");
 #endif
@@ -875,10 +911,11 @@ __global__ __launch_bounds__(256) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs
         // the MFMA role is the latency chain of a small pass (64 dependent K tiles); the streaming role beside it on the
         // same SIMDs waits on memory most of the time: instruction arbitration goes to the MFMA waves first
         __builtin_amdgcn_s_setprio(3);
-        emi_ring2_body<Model, SW, NST, BK, CT>(a.s, tid);
+        emi_ring2_body<Model, SW, NST, BK, CT, HS>(a.s, tid);
     } else {
         const int nid = xcd * a.nn8 + role.index;
         if (nid >= a.nn) return;
+        if (HS > 1 && threadIdx.x >= 256) return;      // (the node role is written for 256 threads; the waves beyond them leave at once)
         emi_nodes_body<double, Model, VEC, true, false, ST>(a.n, nid % a.nbx, nid / a.nbx, a.nbx);
     }
 }

@@ -302,6 +302,7 @@ typedef struct emi_pass_plan {
   int piece, tail;     /* > 0: the batch goes out in launches of `piece` instances and a last one of `tail` (0: none) */
   int k_tile;          /* depth of a K tile of the MFMA role: 8 or 16 */
   int column_tiles;    /* 64-column sub-tiles per MFMA workgroup: 1 or 2 */
+  int k_halves;        /* 2: the K range of a tile in two halves inside a 512-thread workgroup */
 } emi_pass_plan_t;
 int emi_plan_pass(emi_ctx_t ctx, int B, emi_pass_plan_t* out);
 

@@ -725,6 +725,28 @@ def test_deep_k_tiles_of_the_mfma_role_match_the_oracle(built, shape):
             ev.set_option("node_store", -1)
             ev.set_option("sym_cpart", 0)
             ev.set_option("sym_gblk", 0)
+        # "sym_hs" 2: the K range of a tile in two halves inside a 512-thread workgroup, partial sums of the second half through LDS: the two
+        # halves are added once, so the values (not the bits) of the base form; reproducible from call to call
+        ev.set_option("sym_hs", 2)
+        for bk in (8, 16):
+            if (M // 2 // bk) % 4:
+                continue
+            ev.set_option("sym_bk", bk)
+            assert ev.plan(B)["k_halves"] == 2, ev.plan(B)
+            for store in (0, 2):
+                ev.set_option("node_store", store)
+                for cpart in (0, -1, 2):
+                    ev.set_option("sym_cpart", cpart)
+                    poison = ev.eval_host(X + 1.0, U)
+                    got = ev.eval_host(X, U)
+                    assert "two halves" in ev.last_defect_kernel, ev.last_defect_kernel
+                    check(c, ev, got, ref)
+                    assert not np.array_equal(poison[0], got[0])
+                    assert np.array_equal(ev.eval_host(X, U)[0], got[0])
+        ev.set_option("sym_hs", 0)
+        ev.set_option("sym_bk", 0)
+        ev.set_option("node_store", -1)
+        ev.set_option("sym_cpart", 0)
     ev.close()
 
 

@@ -104,6 +104,14 @@ FORMS = {
     "abl_node_off": dict(overlap_mode=3, sym_ct=6, sym_ablate=32),
     "one_sw2_nst4": dict(overlap_mode=3, sym_ct=6, sym_nst=4),
     "bk16": dict(sym_bk=16),
+    "hs2": dict(sym_hs=2),
+    "sw1_hs2": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1, sym_hs=2, sym_bk=8),
+    "sw1_hs2_bk16": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1, sym_hs=2, sym_bk=16),
+    "sw2_hs2": dict(overlap_mode=3, sym_ct=6, sym_ksplit=1, sym_hs=2, sym_bk=8),
+    "sw2_hs2_bk16": dict(overlap_mode=3, sym_ct=6, sym_ksplit=1, sym_hs=2, sym_bk=16),
+    "sw2_hs2_bk16_node_off": dict(overlap_mode=3, sym_ct=6, sym_ksplit=1, sym_hs=2, sym_bk=16, sym_ablate=32),
+    "sw1_hs2_node_off": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1, sym_hs=2, sym_bk=8, sym_ablate=32),
+    "sw2_hs2_node_off": dict(overlap_mode=3, sym_ct=6, sym_ksplit=1, sym_hs=2, sym_bk=8, sym_ablate=32),
     "ct2": dict(sym_ctc=2),
     "ct2_bk16": dict(sym_ctc=2, sym_bk=16),
     "ct2_bk8": dict(sym_ctc=2, sym_bk=8),
@@ -153,7 +161,7 @@ FORMS = {
     "one_sw1_g4c4": dict(overlap_mode=3, sym_ct=7, sym_gblk=4, sym_cx=4),
     "one_sw3_cp4": dict(overlap_mode=3, sym_ct=8, sym_cpart=4),
 }
-RESET = dict(small_rows=24, overlap_mode=0, sym_ct=0, pass_order=-1, slice=0, node_store=-1, sym_cpart=0, sym_gblk=0, sym_cx=0, sym_nst=3, sym_ksplit=0, sym_ablate=0, sym_bk=0, sym_ctc=0)
+RESET = dict(small_rows=24, overlap_mode=0, sym_ct=0, pass_order=-1, slice=0, node_store=-1, sym_cpart=0, sym_gblk=0, sym_cx=0, sym_nst=3, sym_ksplit=0, sym_ablate=0, sym_bk=0, sym_ctc=0, sym_hs=0)
 
 
 def main():
