@@ -298,10 +298,15 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
     if (bk_want == 16 && !c->rtc && plan.ks == 1 && (plan.sw == 1 || plan.sw == 2) && plan.nst == 3) plan.bk = 16;
     // two column sub-tiles per MFMA workgroup ("sym_ctc" 2; built-in models, SW = 2, unsplit, three stages): the plan is made again with
     // the wider tiles (tile counts and tile order change with the column width)
-    const int ctc_want = c->sym_ctc ? c->sym_ctc : 1;
+    // By itself for launches of more than 2048 instances (the grouped tile order; inputs beyond the Infinity Cache, where every operand
+    // read is an HBM read): one box, ms per pass one / two sub-tiles, 4096 instances 1.181 / 1.101, 16384: 4.407 / 4.044 (3.81e9 -> 4.15e9
+    // node-evals/s) with column blocks of one 128-column tile; at 2048 instances 0.4736 / 0.4636, at 1024 and below the narrow form is ahead
+    // (0.2222 / 0.2425: the wide workgroups need 60 KB of LDS and 160 registers) (profiles/r04_mid_sweep.jsonl)
+    const bool wide_large = auto_ct && c->sym_ctc == 0 && B > 2048 && B % 256 == 0 && c->sym_cpart == 0;
+    const int ctc_want = c->sym_ctc ? c->sym_ctc : (wide_large ? 2 : 1);
     if (ctc_want == 2 && !c->rtc && plan.ks == 1 && plan.sw == 2 && plan.nst == 3 && c->M % 256 == 0) {
         const int bk_keep = plan.bk;
-        plan = emi::plan_symdefect(c->ns, B, c->M, 6, 1, c->sym_cpart, gblk_first, c->sym_cx, bk_keep, 2);
+        plan = emi::plan_symdefect(c->ns, B, c->M, 6, 1, c->sym_cpart, gblk_first, (wide_large && c->sym_cx == 0) ? 1 : c->sym_cx, bk_keep, 2);
         plan.ks = 1;
         plan.nst = 3;
         plan.bk = bk_keep;

@@ -192,7 +192,9 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced, co
     if (getenv("EMI_MC_SCALING")) solver.getAlgorithm()->scaling = getenv("EMI_MC_SCALING");                 // "none" (default) / "automatic"
     if (getenv("EMI_MC_RUNG_TOL")) solver.getAlgorithm()->rung_tolerance = atof(getenv("EMI_MC_RUNG_TOL"));
     if (getenv("EMI_MC_RUNG_PATIENCE")) solver.getAlgorithm()->rung_patience = env_int("EMI_MC_RUNG_PATIENCE", 0);                                   // iterations a ladder rung may take (0: nlp_iter_max)
-    solver.getAlgorithm()->nlp_iter_budget = env_int("EMI_MC_BUDGET", 0);                                       // iterations per scenario over all meshes (0: no limit)
+    // iterations per scenario over all its meshes, rungs and restarts (0: no limit).  1000 by default here: in the 1024-scenario run of
+    // config 4 one scenario spent 3287 iterations (91 of the run's 394 s) to end "locally infeasible" (profiles/r04_notes.md section 7)
+    solver.getAlgorithm()->nlp_iter_budget = env_int("EMI_MC_BUDGET", 1000);
     if (getenv("EMI_MC_DEFECT_SCALING")) solver.getAlgorithm()->defect_scaling = getenv("EMI_MC_DEFECT_SCALING");   // "state-based" (default) / "jacobian-based"
     if (getenv("EMI_MC_WARM_MU")) solver.getAlgorithm()->warm_mu_init = atof(getenv("EMI_MC_WARM_MU"));      // experiments
     if (getenv("EMI_MC_WARM_PATIENCE")) solver.getAlgorithm()->warm_patience = atoi(getenv("EMI_MC_WARM_PATIENCE"));

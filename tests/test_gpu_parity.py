@@ -878,7 +878,7 @@ def _expected_default_form(ev, B):
 
 # the shapes the benchmark lines and the profiles quote, pinned: a policy change has to be made here as well as in plan_pass
 PINNED_PLANS = {128: dict(sw=2, ksplit=1, k_tile=16, store_mode=0, block_order=1, piece=0), 1024: dict(sw=2, ksplit=1, k_tile=16, store_mode=2, piece=0),
-                16: dict(sw=1, ksplit=4), 64: dict(sw=1, ksplit=2), 4096: dict(sw=2, k_tile=8, store_mode=2, piece=0), 256: dict(sw=2, k_tile=8), 512: dict(sw=2, k_tile=16)}
+                16: dict(sw=1, ksplit=4), 64: dict(sw=1, ksplit=2), 4096: dict(sw=2, k_tile=8, column_tiles=2, store_mode=2, piece=0), 256: dict(sw=2, k_tile=8), 512: dict(sw=2, k_tile=16)}
 
 
 @pytest.mark.parametrize("B", [1, 3, 5, 16, 64, 128, 256, 512, 1024, 2064, 2560, 4096])
