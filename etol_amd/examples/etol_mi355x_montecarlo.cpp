@@ -190,6 +190,7 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced, co
     solver.getAlgorithm()->nlp_iter_max = 400;
     solver.getAlgorithm()->mesh_refinement = "none";
     if (getenv("EMI_MC_SCALING")) solver.getAlgorithm()->scaling = getenv("EMI_MC_SCALING");                 // "none" (default) / "automatic"
+    if (getenv("EMI_MC_LADDER_RATIO")) solver.getAlgorithm()->ladder_ratio = env_int("EMI_MC_LADDER_RATIO", 2);
     if (getenv("EMI_MC_RUNG_TOL")) solver.getAlgorithm()->rung_tolerance = atof(getenv("EMI_MC_RUNG_TOL"));
     if (getenv("EMI_MC_RUNG_PATIENCE")) solver.getAlgorithm()->rung_patience = env_int("EMI_MC_RUNG_PATIENCE", 0);                                   // iterations a ladder rung may take (0: nlp_iter_max)
     // iterations per scenario over all its meshes, rungs and restarts (0: no limit).  1000 by default here: in the 1024-scenario run of

@@ -1138,7 +1138,8 @@ void eMI355X::solve() {
     const std::vector<double> true_records = P.path_records;
     double span = 0;
     if (_algorithm.mesh_sequencing && P.nodes > 80 && P.guess_states.empty() && !P.lifted) {
-        for (size_t m = 33; m < target; m = 2 * m - 1) ladder.push_back(m);
+        const size_t lr = (size_t)std::max(2, _algorithm.ladder_ratio);
+        for (size_t m = 33; m < target; m = lr * m - (lr - 1)) ladder.push_back(m);
         // Constraints hold at the nodes only, so a coarse mesh can step over a thin keep-out ("tunnelling") and leave
         // the finer meshes a start on the wrong side of it.  On the ladder the keep-outs of the record table are
         // therefore inflated by half the largest node spacing of the straight line between the boundary positions

@@ -80,6 +80,7 @@ struct Alg {
                                                    // (against stepping over thin obstacles; measured: no gain on the
                                                    // Monte-Carlo sets, off by default)
     bool mesh_sequencing = true;                   // meshes above 80 nodes are reached through 33, 65, 129, ... nodes
+    int ladder_ratio = 2;                          // ... each rung (ratio x nodes - (ratio - 1)): 2 gives 33, 65, 129, 257, 513; 4 gives 33, 129, 513
     int guess_retries = 4;                         // a locally infeasible cold start is repeated from up to this many bent lines
     double rung_tolerance = 1e-4;                  // NLP tolerance of the intermediate rungs of the mesh ladder: they only feed the next guess (the
                                                    // requested mesh is solved to nlp_tolerance).  1e-6 until round 4; 64 x 1024-node Monte-Carlo set, 8
