@@ -508,3 +508,62 @@ def test_refined_solves_on_the_device_reach_round_off_in_the_nominal_matrix(buil
     assert lib.emi_kkt_solve_refined(evs[0].ctx, dp(w1), 1e-9, 8, C.byref(r1), C.byref(n1), C.byref(v1), C.byref(s1)) == 5
     for ev in evs:
         ev.close()
+
+
+def test_primal_regularisation_levels_are_reported_and_refined_out(built):
+    """The Schur path's ladder beyond its dual levels (csrc/emi_kkt.hip: dc x 1e3 + dw 1e-7 | 1e-5 | dc x 1e6 + dw 1e-3 on the free STATE
+    diagonals): a matrix whose state variables carry next to no curvature (P = Q^-1 ~ 1 / curv, S = J P J^T beyond what a Cholesky
+    in double precision resolves on a 512-node mesh) must (a) still be factorised, (b) REPORT what was really factorised
+    (emi_kkt_last_regularisation: the iteration treats the shift like its own delta_w), and (c) give, through the refinement against
+    the NOMINAL matrix, a step whose reported residual is the residual numpy sees -- small when the refinement contracts, honestly
+    large when it does not (the advisor's round-3 finding: the shifted factorisation used to be handed back as if it were exact)."""
+    import ctypes as C
+    import etol_amd as E
+    from etol_amd import _lib as L
+    from etol_amd import workloads as W
+    lib = L.load()
+    M, ns, nv = 512, 6, 8
+    nh, N = nv * (nv + 1) // 2, (2 * ns + 2) * M
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, 4.0)
+    ev.set_model(1, W.QUAD_PARAMS)
+    ev.set_batch(1)
+    rng = np.random.default_rng(77)
+    D = C.POINTER(C.c_double)
+    dp = lambda a: a.ctypes.data_as(D)
+    Jblk = 0.01 * rng.standard_normal((ns * nv, M))
+    for i in range(ns):
+        Jblk[i * nv + i] += np.diag(ev.D)
+    fixed = np.zeros(nv * M, dtype=np.uint8)
+    fixed[np.arange(ns) * M] = 1
+    reached = None
+    for curv in (1e-8, 1e-10, 1e-12, 1e-14):
+        Qblk = np.zeros((nh, M))
+        for v in range(nv):
+            Qblk[v * (v + 1) // 2 + v] = curv if v < ns else 1.0          # diagonal node blocks: states ~ flat, controls curved
+        assert ev.kkt_factor(Qblk, Jblk, fixed, 0.0) == 0
+        dc, dw = C.c_double(), C.c_double()
+        assert lib.emi_kkt_last_regularisation(ev.ctx, C.byref(dc), C.byref(dw)) == 0
+        assert dc.value >= 1e-9 and dw.value >= 0.0
+        print(f"state curvature {curv:.0e}: factorised with dc {dc.value:.1e}, dw {dw.value:.1e}, Schur path {lib.emi_kkt_is_schur(ev.ctx)}")
+        if dw.value > 0.0 and lib.emi_kkt_is_schur(ev.ctx):
+            reached = (curv, Qblk, dc.value, dw.value)
+            break
+    if reached is None:
+        pytest.skip("no primal level of the ladder was needed on this mesh")
+    curv, Qblk, dca, dwa = reached
+    K = dense_kkt(ev.D, Qblk, Jblk, fixed, 0.0, M, ns, nv)                 # the NOMINAL matrix (dc = 0, no shift)
+    b = rng.standard_normal(N)
+    ref = b.copy()
+    ref[np.nonzero(fixed)[0]] = 0
+    x = b.copy()
+    rel, nsv, rev, stat = C.c_double(), C.c_int(), C.c_int(), C.c_int()
+    assert lib.emi_kkt_solve_refined(ev.ctx, dp(x), 0.0, 8, C.byref(rel), C.byref(nsv), C.byref(rev), C.byref(stat)) == 0
+    assert stat.value == 0
+    res = np.abs(K @ x - ref).max() / max(1.0, np.abs(ref).max())
+    print(f"  shift dw {dwa:.1e}: {nsv.value} solves, reverted {rev.value}, residual reported {rel.value:.2e}, numpy {res:.2e}")
+    assert abs(res - rel.value) <= 1e-6 * max(res, rel.value) + 1e-13         # the report is what numpy sees
+    plain = ev.kkt_solve(b)                                                    # one solve with the shifted factors, no refinement
+    res0 = np.abs(K @ plain - ref).max() / max(1.0, np.abs(ref).max())
+    assert res <= res0 * (1 + 1e-9)                                             # refinement never hands back something worse
+    ev.close()
