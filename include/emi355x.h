@@ -42,6 +42,15 @@
  *                      through ::psopt at ePSOPT.cpp:84 with nlp_method "IPOPT"
  *                      (:62) [IPOPT]: the primal-dual KKT matrix is assembled
  *                      and factorised on the device
+ *   emi_kkt_solve_refined  the iterative refinement IPOPT wraps around that
+ *                      solve [IPOPT]: residual, correction and the revert of
+ *                      a correction that made it worse stay on the device
+ *   emi_kkt_*_batch    no counterpart: the reference runs one trajectory per
+ *                      process; the Newton steps of several scenarios on one
+ *                      mesh go through one sequence of batched launches
+ *   emi_plan_pass      no counterpart: the launch form emi_eval_* takes for a
+ *                      batch size, so that tests and tools query the policy
+ *                      instead of restating it
  *
  * Threading: a context must be driven by one caller thread at a time
  * (the reference is single-threaded throughout).
