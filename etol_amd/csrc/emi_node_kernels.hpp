@@ -118,7 +118,10 @@ template <typename T, class Model, int VEC, bool JAC, bool DEFROWS, int ST, bool
 EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, const int nbx) {
     constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
     const int M = a.M;
-    const int k0 = (bx * EMI_NODE_THREADS + threadIdx.x) * VEC;
+    // a workgroup of 2 x EMI_NODE_THREADS threads (the one-launch pass with its K range in two halves) runs two of these
+    // bodies side by side, one per half, each on its own (bx, b): tix is the thread's index within its half
+    const int tix = threadIdx.x % EMI_NODE_THREADS, half = threadIdx.x / EMI_NODE_THREADS;
+    const int k0 = (bx * EMI_NODE_THREADS + tix) * VEC;
     const bool active = k0 < M;  // M % VEC == 0 by dispatch, so the pack is whole
 
     T lsum = T(0);
@@ -289,15 +292,15 @@ EMI_DEV void emi_nodes_body(const NodeArgs<T>& a, const int bx, const int b, con
         }
     }
     // ---- K3 cost quadrature: wave reduction, then across the block's waves --
-    __shared__ T wsum[EMI_NODE_THREADS / 64];
+    __shared__ T wsum[2][EMI_NODE_THREADS / 64];
     const T ws = wave_sum(lsum);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (lane == 0) wsum[wid] = ws;
+    const int lane = tix & 63, wid = tix >> 6;
+    if (lane == 0) wsum[half][wid] = ws;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tix == 0) {
         T s = T(0);
 #pragma unroll
-        for (int i = 0; i < EMI_NODE_THREADS / 64; ++i) s += wsum[i];
+        for (int i = 0; i < EMI_NODE_THREADS / 64; ++i) s += wsum[half][i];
         T* part = a.cost_part + (size_t)b * nbx;
         if (a.cost_ticket == nullptr) {
             part[bx] = s;                                  // emi_cost_finish_kernel sums the partials

@@ -177,7 +177,7 @@ static hipError_t launch_pass_model(const SymDefectArgs& sa, const NodeArgs<doub
     a.nm = nm;
     a.nn = nn;
     a.nm8 = (nm + 7) / 8;
-    a.nn8 = (nn + 7) / 8;
+    a.nn8 = ((nn + HS - 1) / HS + 7) / 8;          // node-role WORKGROUPS per XCD: one takes HS chunks
     const size_t lds = (size_t)HS * NST * ((2 * SW * FUSED_TI + 2 * 64 * CT + 63) / 64 * 64) * BK * sizeof(double);
     static bool attr_done[4] = {false, false, false, false};
     const int st = (na.store_mode >= 0 && na.store_mode <= 3) ? na.store_mode : 0;   // result stores: plain / sc1 (write-through) / non-temporal / nt sc1

@@ -913,9 +913,10 @@ __global__ __launch_bounds__(256 * HS) EMI_PASS_OCC void emi_pass_f64_kernel(Pas
         __builtin_amdgcn_s_setprio(3);
         emi_ring2_body<Model, SW, NST, BK, CT, HS>(a.s, tid);
     } else {
-        const int nid = xcd * a.nn8 + role.index;
+        // a.nn counts node chunks; a workgroup of HS x 256 threads takes HS neighbouring ones (a half that has none leaves:
+        // barriers only count the waves still running)
+        const int nid = (xcd * a.nn8 + role.index) * HS + (HS > 1 ? (int)(threadIdx.x >> 8) : 0);
         if (nid >= a.nn) return;
-        if (HS > 1 && threadIdx.x >= 256) return;      // (the node role is written for 256 threads; the waves beyond them leave at once)
         emi_nodes_body<double, Model, VEC, true, false, ST>(a.n, nid % a.nbx, nid / a.nbx, a.nbx);
     }
 }
