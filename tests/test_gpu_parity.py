@@ -922,6 +922,58 @@ def test_default_dispatch_at_the_benchmarked_shapes_matches_the_oracle(built, B)
     ev.close()
 
 
+def test_full_report_size_16384_instances_against_the_oracle_and_by_reordering(built):
+    """SURVEY section 8(d)'s largest report size, B = 16384 at M = 1024 with 20 per-instance keep-outs (17 GB of results: inputs of
+    this size never stay in the Infinity Cache between the roles, a different regime from 1024 instances), through the default
+    dispatch.  Two checks: (1) sampled instances on every tile / slice edge against the CPU oracle; (2) a size-independent property
+    over ALL instances -- the same batch in REVERSED instance order must give the same bits per instance (an instance's rows depend on
+    nothing but its own inputs; every instance then sits in another tile, another XCD share and another launch position)."""
+    import torch
+    import etol_amd as E
+    M, B = 1024, 16384
+    if torch.cuda.get_device_properties(0).total_memory < 60e9:
+        pytest.skip("needs 40 GB of device memory")
+    ev = E.Evaluator(0)
+    ev.set_mesh(M, 0.0, cases.W.TF)
+    ev.set_model(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS)
+    ev.set_batch(B)
+    X, U, recs = cases.W.quadrotor_batch(11, B, M, 20)
+    recs = np.asarray(recs)
+    assert recs.ndim == 3 and recs.shape[0] == B
+    ev.set_path(recs, 0, 1)
+    dX, dU = torch.from_numpy(X).cuda(), torch.from_numpy(U).cuda()
+    outs = ev.alloc_outputs()
+    for t in outs:
+        t.fill_(float("nan"))
+    torch.cuda.synchronize()
+    ev.eval_dev(dX, dU, *outs)
+    ev.synchronize()
+    expected, plan = _expected_default_form(ev, B)
+    assert expected in ev.last_defect_kernel, (ev.last_defect_kernel, plan)
+    assert plan["column_tiles"] == 2 and plan["piece"] == 0, plan
+    for t in outs:
+        assert not torch.isnan(t).any().item()
+    sample = [0, 15, 16, 255, 256, 2047, 2048, 4095, 4096, 8191, 8192, 12287, 16367, 16368, 16383]
+    e = O.sampled_errors(E.MODEL_QUADROTOR2D, cases.W.QUAD_PARAMS, M, (ev.tau, ev.w, ev.D), 0.0, cases.W.TF, X, U, recs, outs, sample)
+    print(f"B={B}: {ev.last_defect_kernel}: {e}")
+    assert e["defect"] < TOL_DEFECT and e["path"] < TOL_NODE and e["vals"] < TOL_NODE and e["cost"] < 1e-13, e
+    # the same instances in reversed order
+    ev.set_path(np.ascontiguousarray(recs[::-1]), 0, 1)
+    rX, rU = dX.flip(0).contiguous(), dU.flip(0).contiguous()
+    outs2 = ev.alloc_outputs()
+    for t in outs2:
+        t.fill_(float("nan"))
+    torch.cuda.synchronize()
+    ev.eval_dev(rX, rU, *outs2)
+    ev.synchronize()
+    torch.cuda.synchronize()
+    for a, b in zip(outs, outs2):
+        # compared in slabs: a flipped copy of the 13 GB VALS array beside both result sets is not needed
+        for i0 in range(0, B, 2048):
+            assert torch.equal(a[i0:i0 + 2048], b[B - i0 - 2048:B - i0].flip(0)), i0
+    ev.close()
+
+
 @pytest.mark.parametrize("B", [256, 1024])
 def test_front_loaded_pass_orders_match_the_oracle(built, B):
     """"pass_order" >= 100 (MFMA workgroups at 1.25 x / 4 x / far beyond the even density, node workgroups at the tail: the

@@ -47,6 +47,21 @@ H.harness_set_linear_solver(b"device")
 X, U = np.zeros(12 * 32), np.zeros(4 * 32); cost, M, it = C.c_double(), C.c_int(), C.c_int()
 rc = H.harness_solve_fixedwing_oracle(orc, 16, 6.0, 6.0, 1e-7, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D), 32, C.byref(it))
 print("fixedwing (inertia search)", rc, cost.value, it.value, H.harness_last_message().decode())
+# delayed states / controls solved through coupling rows (NlpLink), with and without bound scaling; Jacobian-based defect row weights
+H.harness_solve_delay_demo_oracle.argtypes = [C.c_char_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, D, D, C.POINTER(C.c_int)]
+for sc in (0, 1):
+    for r in (0.0, 0.9):
+        Z = np.zeros(10 * 25); cost, it = C.c_double(), C.c_int()
+        rc = H.harness_solve_delay_demo_oracle(orc, 24, 0.25, r, 1e-10, 0, sc, C.byref(cost), Z.ctypes.data_as(D), C.byref(it))
+        print("delayed", sc, r, rc, cost.value, it.value, H.harness_last_message().decode())
+H.harness_set_defect_scaling.argtypes = [C.c_int]
+H.harness_set_defect_scaling(1)
+H.harness_set_linear_solver(b"host")
+for nd in (0, 5):
+    X, U = np.zeros(6 * 64), np.zeros(2 * 64); cost, M, it = C.c_double(), C.c_int(), C.c_int()
+    rc = H.harness_solve_quadrotor_oracle(orc, 24, 0.16, nd, 1e-8, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D), 64, C.byref(it))
+    print("quadrotor, jacobian-based defect scaling", nd, rc, cost.value, it.value, H.harness_last_message().decode())
+H.harness_set_defect_scaling(0)
 print("asan run complete")
 PY
 cd $OUT && ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python run.py
