@@ -358,6 +358,9 @@ __global__ __launch_bounds__(256, 2) void emi_symdefect_ring_f64_kernel(SymDefec
 // 16-lane groups of a ds_read_b128 then covers a 256-byte bank row exactly once (MI355X_MICROARCH.md, LDS).
 // ---------------------------------------------------------------------------------------------
 EMI_DEV constexpr int ring_swz(int r) { return (0 - (r >> 2)) & 3; }
+#ifndef EMI_EPILOGUE_PREFETCH
+#define EMI_EPILOGUE_PREFETCH 0         // build-time A/B switch (tools/ab_build.sh): the epilogue's first loads ahead of the K loop.
+#endif                                  // Measured (profiles/r04_notes.md section 13): no gain at any batch size, off.
 // The same for K tiles of depth BK (rows of BK doubles = BK / 2 sixteen-byte chunks): the sixteen rows r .. r + 15 a lane group of a
 // ds_read_b128 touches at one logical chunk must land on sixteen different 16-byte bank slots of a 256-byte bank row.  BK = 8 (64-byte
 // rows, four to a bank row): the chunk position changes every four rows, ring_swz above.  BK = 16 (128-byte rows, two to a bank row):
@@ -370,9 +373,29 @@ template <int BK> EMI_DEV constexpr int ring_swz_k(int r) { return BK == 8 ? rin
 // writes are computed and only the variables they depend on are loaded (6-state quadrotor, SW = 2: the group (x, y)
 // needs v_x, v_y and no sine / cosine at all; measured with the epilogue switched off, it was 13 % of the pass at 1024
 // instances when every group evaluated all of f: tools/diag/x_traffic_probe.py).
-template <class Model, int SW, int S0>
+// the node variables of instance `inst` at a lane's two output nodes (forward node_f and its mirror): what f is evaluated on
+template <class Model>
+EMI_DEV void ring_epilogue_load(const SymDefectArgs& a, double (&z)[2][Model::NV], int inst, int node_f) {
+    constexpr int NS = Model::NS, NC = Model::NC;
+    const int M = a.M, node_m = M - 1 - node_f;
+    inst = inst < a.B ? inst : a.B - 1;                    // (rows past the batch: loaded from the last instance, never stored)
+    const double* __restrict__ Xb = a.X + (size_t)inst * NS * M;
+    const double* __restrict__ Ub = a.U + (size_t)inst * NC * M;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int node = side == 0 ? node_f : node_m;
+#pragma unroll
+        for (int v = 0; v < NS; ++v) z[side][v] = Xb[(size_t)v * M + node];
+#pragma unroll
+        for (int v = 0; v < NC; ++v) z[side][NS + v] = Ub[(size_t)v * M + node];
+    }
+}
+// zpre (SW > 1, PRE): the variables of the lane's FIRST instance, already requested by the caller (emi_ring2_body asks for them
+// ahead of its K loop: the epilogue's first memory round trip is then over when the last MFMA retires); otherwise loaded here.
+// (A compile-time choice and an array reference: with a pointer that may be null, or a run-time flag, the array went to scratch.)
+template <class Model, int SW, int S0, bool PRE>
 EMI_DEV void ring_epilogue_s0(const SymDefectArgs& a, const d4 (&acc_a)[SW], const d4 (&acc_b)[SW], int inst0, int i0,
-                              int wid, int r16, int kq) {
+                              int wid, int r16, int kq, const double (&zpre)[2][Model::NV]) {
     constexpr int NS = Model::NS, NC = Model::NC, NV = Model::NV;
     const int M = a.M, B = a.B;
     const int col = wid * 16 + r16;
@@ -438,7 +461,14 @@ EMI_DEV void ring_epilogue_s0(const SymDefectArgs& a, const d4 (&acc_a)[SW], con
         }
     };
     double zc[2][NV], zn[2][NV];
-    load_z(zc, 0);
+    if constexpr (PRE) {
+#pragma unroll
+        for (int side = 0; side < 2; ++side)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) zc[side][v] = zpre[side][v];
+    } else {
+        load_z(zc, 0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (i < 3) load_z(zn, i + 1);
@@ -471,13 +501,19 @@ EMI_DEV void ring_epilogue_s0(const SymDefectArgs& a, const d4 (&acc_a)[SW], con
         }
     }
 }
-template <class Model, int SW, int SG = 0>
+template <class Model, int SW, bool PRE, int SG = 0>
+EMI_DEV void ring_epilogue_pre(const SymDefectArgs& a, const d4 (&acc_a)[SW], const d4 (&acc_b)[SW], int inst0, int i0,
+                               int s0, int wid, int r16, int kq, const double (&zpre)[2][Model::NV]) {
+    if constexpr (SG * SW < Model::NS) {
+        if (s0 == SG * SW) ring_epilogue_s0<Model, SW, SG * SW, PRE>(a, acc_a, acc_b, inst0, i0, wid, r16, kq, zpre);
+        else ring_epilogue_pre<Model, SW, PRE, SG + 1>(a, acc_a, acc_b, inst0, i0, s0, wid, r16, kq, zpre);
+    }
+}
+template <class Model, int SW>
 EMI_DEV void ring_epilogue(const SymDefectArgs& a, const d4 (&acc_a)[SW], const d4 (&acc_b)[SW], int inst0, int i0,
                            int s0, int wid, int r16, int kq) {
-    if constexpr (SG * SW < Model::NS) {
-        if (s0 == SG * SW) ring_epilogue_s0<Model, SW, SG * SW>(a, acc_a, acc_b, inst0, i0, wid, r16, kq);
-        else ring_epilogue<Model, SW, SG + 1>(a, acc_a, acc_b, inst0, i0, s0, wid, r16, kq);
-    }
+    const double none[2][Model::NV] = {};
+    ring_epilogue_pre<Model, SW, false>(a, acc_a, acc_b, inst0, i0, s0, wid, r16, kq, none);
 }
 
 // a.ksplit > 1: the K range of a tile is cut into ksplit slices, one workgroup each (a shard of config 4 has 64
@@ -611,6 +647,15 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
             acc_a[s][c] = d4{0.0, 0.0, 0.0, 0.0};
             acc_b[s][c] = d4{0.0, 0.0, 0.0, 0.0};
         }
+
+    // Build-time option (EMI_EPILOGUE_PREFETCH, off): the epilogue's first memory round trip started HERE -- the node variables of the
+    // lane's first instance at its two output nodes requested before the ring's first DMA instruction (older than every DMA instruction,
+    // so the counted vmcnt waits of the K loop mean what they meant), held in 2 NV registers through the loop.  It takes one exposed round
+    // trip off a workgroup's dependency chain on paper; measured on one box against the same build without it: 128 instances 0.0296
+    // against 0.0293 ms, 1024: 0.2121 - 0.2135 against 0.2110 - 0.2112 -- the epilogue's loads are not what a chain waits for.
+    constexpr bool EPI_PRE = EMI_EPILOGUE_PREFETCH && SW >= 2 && SW <= 3 && HS == 1 && CT == 1;   // (the wide and the all-states forms have no registers to spare)
+    double zpre[2][Model::NV] = {};
+    if constexpr (EPI_PRE) ring_epilogue_load<Model>(a, zpre, inst0 + kq, i0 + wid * 16 + r16);
 
 #pragma unroll
     for (int t = 0; t < LOOK; ++t)
@@ -832,7 +877,8 @@ EMI_DEV void emi_ring2_body(const SymDefectArgs& a, const int bid /* tile-and-sl
         d4 ea[SW], eb[SW];
 #pragma unroll
         for (int s2 = 0; s2 < SW; ++s2) { ea[s2] = acc_a[s2][c]; eb[s2] = acc_b[s2][c]; }
-        ring_epilogue<Model, SW>(a, ea, eb, inst0, i0 + 64 * c, s0, wid, r16, kq);
+        if (c == 0) ring_epilogue_pre<Model, SW, EPI_PRE>(a, ea, eb, inst0, i0, s0, wid, r16, kq, zpre);
+        else ring_epilogue<Model, SW>(a, ea, eb, inst0, i0 + 64 * c, s0, wid, r16, kq);
     }
 }
 
@@ -894,8 +940,14 @@ __global__ __launch_bounds__(256) void emi_symdefect_combine_kernel(SymDefectArg
 #endif
 #if EMI_PASS_WAVES_PER_EU > 0
 #define EMI_PASS_OCC __attribute__((amdgpu_waves_per_eu(EMI_PASS_WAVES_PER_EU, EMI_PASS_WAVES_PER_EU)))
+#elif EMI_PASS_WAVES_PER_EU < 0
+#define EMI_PASS_OCC                    // (A/B: whatever the compiler arrives at)
 #else
-#define EMI_PASS_OCC
+// Two waves per SIMD, stated: the ring's LDS admits two workgroups per CU and both roles want to be resident, but the register
+// count of this kernel swings with details of the source (the 128-column form came out at 224 or at 280 registers for the same
+// arithmetic) -- beyond 256 only ONE workgroup fits a CU and the roles no longer overlap.
+// (The all-states form, SW > 3, holds 96 accumulator registers and has always run one workgroup per CU.)
+#define EMI_PASS_OCC __attribute__((amdgpu_waves_per_eu(SW > 3 ? 1 : 2, 2)))
 #endif
 template <class Model, int SW, int VEC, int ST, int NST = 3, int BK = 8, int CT = 1, int HS = 1>
 __global__ __launch_bounds__(256 * HS) EMI_PASS_OCC void emi_pass_f64_kernel(PassArgs a) {
