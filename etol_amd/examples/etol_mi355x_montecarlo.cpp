@@ -21,7 +21,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
+#include <map>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -70,6 +72,7 @@ struct Result {
     double cost = 0, seconds = 0;
     std::string message;
     std::vector<double> states, controls, time;   // [6][nodes], [2][nodes], [nodes] of a solved scenario
+    std::vector<mx::Sol::NlpRun> runs;            // the NLP solves of this scenario (ladder rungs, restarts), in order
 };
 
 // one gathered record per scenario: header {scenario, rc, nodes, iterations, cost} then X[6][M], U[2][M], t[M]
@@ -209,6 +212,7 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced, co
     R.message = sol->error_msg;
     R.nodes = (int)sol->nodes;
     R.iterations = sol->nlp_iterations_total;
+    R.runs = sol->nlp_runs;
     R.cost = sol->error_flag ? 0.0 : t->getScore();
     if (!sol->error_flag) { R.states = sol->states; R.controls = sol->controls; R.time = sol->time; }
     t->close();
@@ -291,7 +295,29 @@ int main(int argc, char** argv) {
         ok += r.rc == 0;
         iters += r.iterations;
     }
-    printf("{\"rank\": %d, \"world\": %d, \"scenarios\": %d, \"solved\": %d, \"nodes\": %d, \"keepouts\": %d, \"threads\": %d, "
+    // where the iterations (and the solver's time) went: per mesh size, over all scenarios of this rank
+    std::map<size_t, std::array<double, 14>> by_mesh;     // nodes -> NLP solves, iterations, seconds, not converged, the phases of Sol::NlpRun
+    for (const Result& r : results)
+        for (const auto& u : r.runs) {
+            auto& a = by_mesh[u.nodes];
+            const double v[14] = {1.0, (double)u.iterations, u.seconds, u.converged ? 0.0 : 1.0, u.t_eval, u.t_hess, u.t_factor, u.t_solve,
+                                  u.t_lowrank, u.t_blocks, u.t_jt, u.t_matvec, (double)u.factorisations, (double)u.solves};
+            for (int i = 0; i < 14; ++i) a[i] += v[i];
+        }
+    std::string mesh_json = "{";
+    for (const auto& kv : by_mesh) {
+        char buf[512];
+        const auto& a = kv.second;
+        snprintf(buf, sizeof buf,
+                 "%s\"%zu\": {\"nlp_solves\": %.0f, \"iterations\": %.0f, \"seconds\": %.2f, \"not_converged\": %.0f, \"eval_s\": %.2f, \"hess_s\": %.2f, "
+                 "\"factor_s\": %.2f, \"solve_s\": %.2f, \"lowrank_s\": %.2f, \"blocks_s\": %.2f, \"jt_s\": %.2f, \"matvec_s\": %.2f, "
+                 "\"factorisations\": %.0f, \"solves\": %.0f}",
+                 mesh_json.size() > 1 ? ", " : "", kv.first, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13]);
+        mesh_json += buf;
+    }
+    mesh_json += "}";
+    printf("{\"by_mesh\": %s, ", mesh_json.c_str());
+    printf("\"rank\": %d, \"world\": %d, \"scenarios\": %d, \"solved\": %d, \"nodes\": %d, \"keepouts\": %d, \"threads\": %d, "
            "\"model\": \"%s\", \"kkt_batch_groups\": %d, \"wall_s\": %.3f, \"solves_per_s\": %.3f, \"mean_iterations\": %.1f}\n",
            rank, world, hi - lo, ok, nsteps + 1, ndiscs, nthreads, traced ? "traced" : "built-in", groups, wall,
            (hi - lo) / wall, results.empty() ? 0.0 : iters / results.size());

@@ -1031,8 +1031,11 @@ void eMI355X::solve() {
             }
             ob.max_iter = std::min(ob.max_iter, left);
         }
+        const auto t_run = std::chrono::steady_clock::now();
         r = mi355x::solve_nlp(nlp, ob, mi355x::initial_guess(P));
         _solution.nlp_iterations_total += r.iterations;
+        _solution.nlp_runs.push_back({P.nodes, r.iterations, r.ok, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_run).count(),
+                                      r.t_eval, r.t_hess, r.t_factor, r.t_solve, r.t_lowrank, r.t_blocks, r.t_jt, r.t_matvec, r.n_factor, r.n_solve});
         if (!r.ok && _algorithm.nlp_iter_budget > 0 && _solution.nlp_iterations_total >= _algorithm.nlp_iter_budget)
             r.msg = "iteration budget exhausted (" + std::to_string(_solution.nlp_iterations_total) + " iterations over all meshes and restarts); last: " + r.msg;
     };
@@ -1120,6 +1123,7 @@ void eMI355X::solve() {
     warm.mu_restart = _algorithm.mu_restart;
     _solution.mesh_iterations = 0;
     _solution.nlp_iterations_total = 0;
+    _solution.nlp_runs.clear();
     _solution.ode_error = 0;
     bool sequenced = false;             // the requested mesh is started from the sequencing ladder's solution
     std::function<bool(double)> climb;  // the ladder from its coarsest mesh with the straight-line guess bent by so much: true if every rung converged

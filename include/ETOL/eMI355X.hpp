@@ -125,6 +125,14 @@ struct Sol {
     double kkt_error = 0, constraint_violation = 0;
     std::string linear_solver;      // what the last solve used for the Newton step
     int mesh_iterations = 0;        // NLP solves performed (1 = no refinement happened)
+    struct NlpRun {
+        size_t nodes; int iterations; bool converged; double seconds;
+        // of those seconds: evaluator calls, Hessian calls, Newton-step factorisations, solves, low-rank corrections, host node-block
+        // assembly + eigen-decompositions, host J^T lambda, host refinement matvecs (the remainder is the iteration's own host arithmetic)
+        double t_eval, t_hess, t_factor, t_solve, t_lowrank, t_blocks, t_jt, t_matvec;
+        int factorisations, solves;
+    };
+    std::vector<NlpRun> nlp_runs;   // every NLP solve of this solve(), in order (ladder rungs, restarts, refinement): where the iterations went
     double ode_error = 0;           // relative local ODE error of the last mesh (integral of the ODE residual between nodes)
     size_t nstates = 0, ncontrols = 0, nodes = 0;
     std::vector<double> states;     // [nstates][nodes]
