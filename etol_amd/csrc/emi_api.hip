@@ -244,7 +244,8 @@ struct PassPlan {
 //     96: 0.0288 / 0.0290 / 0.0407, 128: 0.0333 / 0.0387 / 0.0496 (from ~500 workgroups the split loses: three and more MFMA
 //     waves per SIMD share the matrix pipe and the node role starts behind them);
 //   * block order (pass_role_of): MFMA workgroups first below 208 tiles (their 64-tile dependency chains start at once, the
-//     streaming workgroups fill in behind), at 1.25 x the even density up to 384 tiles, at 1.1 x up to 768, evenly interleaved
+//     streaming workgroups fill in behind; since the end of round 4 only below 144 tiles: 1.5 x the even density from there, see
+//     deep_band below), at 1.25 x the even density up to 384 tiles, at 1.1 x up to 768, evenly interleaved
 //     from there (B >= 768, where "first" would hold the node role back: 0.288 against 0.222 at 1024).  (Round 2 measured
 //     "first" against "interleaved" WITH PLAIN STORES at 256 instances and found interleaved ahead, 0.0727 / 0.0748; with
 //     non-temporal stores "first" wins up to 448 instances: 256: 0.0581 against 0.0756 interleaved.  End of round 3, one box,
@@ -294,7 +295,14 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
     // 896: 0.1921 / 0.1896, 1024: 0.2164 / 0.2143; not at 256 .. 384 instances (MFMA workgroups first: 320: 0.0752 / 0.0924) nor from 2048
     // (0.4147 / 0.4205; 4096 in the grouped order 1.081 / 1.175)
     const bool deep_large = auto_ct && !c->rtc && c->sym_bk == 0 && c->sym_nst == 3 && c->pass_order < 0 && p.tiles16 >= 208 && p.tiles16 < 768;
-    const int bk_want = c->sym_bk ? c->sym_bk : ((deep_mid || deep_large) ? 16 : 8);
+    // ... and between 144 and 207 tiles (288 .. 415 instances) TOGETHER with the MFMA workgroups at 1.5 x the even density instead of all
+    // of them first: from ~300 instances the role's 3 x tiles workgroups no longer fit beside the node role (64 places per XCD), which then
+    // starts a workgroup generation late.  End of round 4, one box, ms per pass, first + 8-deep (the choice until then) / 1.5 x + 16-deep:
+    // 288 instances 0.0730 / 0.0699, 320: 0.0859 / 0.0754, 352: 0.1004 / 0.0820, 384: 0.1022 / 0.0875; 272: 0.0644 / 0.0698 (stays),
+    // 416 (1.25 x + 16-deep already): 0.0946 / 0.0951 (profiles/r04_mid_sweep_band_288_416.jsonl)
+    const bool deep_band = auto_ct && !c->rtc && c->sym_bk == 0 && c->sym_nst == 3 && c->pass_order < 0 && c->ns % 2 == 0 && c->ns > 2 &&
+                           p.tiles16 >= 144 && p.tiles16 < 208;
+    const int bk_want = c->sym_bk ? c->sym_bk : ((deep_mid || deep_large || deep_band) ? 16 : 8);
     if (bk_want == 16 && !c->rtc && plan.ks == 1 && (plan.sw == 1 || plan.sw == 2) && plan.nst == 3) plan.bk = 16;
     // two column sub-tiles per MFMA workgroup ("sym_ctc" 2; built-in models, SW = 2, unsplit, three stages): the plan is made again with
     // the wider tiles (tile counts and tile order change with the column width)
@@ -318,7 +326,7 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
         plan.hs = 2;
     p.sym = plan;
     p.mfma_first = c->pass_order >= 0 ? c->pass_order
-                                      : (p.tiles16 < 208 ? 1 : (p.tiles16 < 384 ? 125 : (p.tiles16 < 768 ? 110 : 0)));
+                                      : (deep_band ? 150 : (p.tiles16 < 208 ? 1 : (p.tiles16 < 384 ? 125 : (p.tiles16 < 768 ? 110 : 0))));
     p.one_launch = c->rtc ? emi::rtc_pass_supported(c->rtc, B, c->M, plan.sw, plan.ks, p.store_mode)
                           : emi::pass_supported(c->model, c->ns, B, c->M, plan);
     return p;
@@ -475,8 +483,9 @@ static int create_impl(int device_id, bool f32, emi_ctx_t* out) {
         return EMI_ERR_HIP;
     }
     c->own_stream = true;
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+    // (stream2 is created when a two-stream form first asks for it, need_stream2: every stream takes a share of one of the runtime's few
+    // hardware queues, and a Monte-Carlo run has a context per host thread)
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return EMI_ERR_HIP;
@@ -491,6 +500,16 @@ static int create_impl(int device_id, bool f32, emi_ctx_t* out) {
 
 int emi_create(int device_id, emi_ctx_t* out) { return create_impl(device_id, false, out); }
 int emi_create_f32(int device_id, emi_ctx_t* out) { return create_impl(device_id, true, out); }
+
+// the second stream of the two-stream forms (node kernel beside the MFMA defect kernel), created on first use
+static int need_stream2(emi_ctx_t c) {
+    if (c->stream2) return EMI_OK;
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) {
+        c->stream2 = nullptr;
+        return fail(c, EMI_ERR_HIP, "cannot create the second stream of the two-stream pass");
+    }
+    return EMI_OK;
+}
 
 int emi_destroy(emi_ctx_t c) {
     if (!c) return EMI_ERR_ARG;
@@ -1003,6 +1022,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         }
         const bool two = c->overlap_mode != 1;
         const bool split = two && c->cu_split > 0;
+        if (two && !split) { if (int st = need_stream2(c)) return st; }
         hipStream_t s1 = split ? c->s_mfma : c->stream;
         hipStream_t s2 = split ? c->s_node : (two ? c->stream2 : c->stream);
         const unsigned bit = 1u << c->sym_ct;
@@ -1104,6 +1124,7 @@ static int eval_dev_slice(emi_ctx_t c, const void* dX, const void* dU, void* dRE
         fill_node_args(c, full, dX, dU, dRES, dVALS, dCOST);
         int est = ensure(c, c->d_cost_part2, (size_t)c->B * emi::node_chunks(c->M) * 4);
         if (est) return est;
+        if (int st2 = need_stream2(c)) return st2;
         pre.cost_part = (float*)c->d_cost_part2.p;      // its cost partials go nowhere
         pre.np = 0;                                      // ... and it leaves the path rows to the full kernel
         // (round 4, "f32_ring_wgs" 1: the ring kernel at one workgroup per CU, which costs it nothing, leaves the node kernel's waves
@@ -1416,7 +1437,7 @@ int emi_profile_read(emi_ctx_t c, float* node_ms, int* node_launches, float* def
                      int* defect_launches, float* pass_ms, int* overlapped_passes) {
     if (!c) return EMI_ERR_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream2));
+    if (c->stream2) HIP_TRY(c, hipStreamSynchronize(c->stream2));
     float nm = 0, dm = 0, fm = 0;
     int nl = 0, dl = 0, fl = 0;
     for (size_t i = 0; i < c->prof_used; ++i) {

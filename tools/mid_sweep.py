@@ -104,6 +104,9 @@ FORMS = {
     "abl_node_off": dict(overlap_mode=3, sym_ct=6, sym_ablate=32),
     "one_sw2_nst4": dict(overlap_mode=3, sym_ct=6, sym_nst=4),
     "bk16": dict(sym_bk=16),
+    "order0": dict(pass_order=0), "order110": dict(pass_order=110), "order125": dict(pass_order=125), "order150": dict(pass_order=150), "order200": dict(pass_order=200),
+    "order0_bk16": dict(pass_order=0, sym_bk=16), "order125_bk16": dict(pass_order=125, sym_bk=16), "order150_bk16": dict(pass_order=150, sym_bk=16),
+    "order1_bk16": dict(pass_order=1, sym_bk=16),
     "hs2": dict(sym_hs=2),
     "sw1_hs2": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1, sym_hs=2, sym_bk=8),
     "sw1_hs2_bk16": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1, sym_hs=2, sym_bk=16),
