@@ -291,9 +291,15 @@ int main(int argc, char** argv) {
 
     int ok = 0;
     double iters = 0;
+    const bool show_runs = env_int("EMI_MC_RUNS", 0) != 0;
     for (const Result& r : results) {
-        printf("scenario %4d  rank %d  rc %d  nodes %d  iterations %4d  cost %.8f  %.2f s%s%s\n", r.scenario, rank, r.rc, r.nodes,
+        printf("scenario %4d  rank %d  rc %d  nodes %d  iterations %4d  cost %.8f  %.2f s%s%s", r.scenario, rank, r.rc, r.nodes,
                r.iterations, r.cost, r.seconds, r.rc ? "  " : "", r.rc ? r.message.c_str() : "");
+        if (show_runs) {                                  // EMI_MC_RUNS=1: every NLP solve of the scenario as nodes:iterations ('!' = did not converge)
+            printf("  runs");
+            for (const auto& u : r.runs) printf(" %zu:%d%s", u.nodes, u.iterations, u.converged ? "" : "!");
+        }
+        printf("\n");
         ok += r.rc == 0;
         iters += r.iterations;
     }

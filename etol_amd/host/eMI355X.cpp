@@ -1128,6 +1128,7 @@ void eMI355X::solve() {
     bool sequenced = false;             // the requested mesh is started from the sequencing ladder's solution
     std::function<bool(double)> climb;  // the ladder from its coarsest mesh with the straight-line guess bent by so much: true if every rung converged
     double ladder_span = 0;
+    int ladder_next_bend = 0;           // index into ladder_bends of the first bend no climb has used yet
     bool ladder_first_rung_failed = false;
     const double ladder_bends[4] = {0.15, -0.15, 0.35, -0.35};
 
@@ -1215,6 +1216,7 @@ void eMI355X::solve() {
                 printf("mesh sequencing: a rung failed (%s), ladder restarted from the line bent by %+.3f\n", r.msg.c_str(),
                        ladder_bends[ca - 1] * span);
             chain_ok = climb(ca > 0 ? ladder_bends[ca - 1] * span : 0.0);
+            ladder_next_bend = ca;                  // bends 0 .. ca - 1 have been used (the climb is deterministic: none is worth repeating)
         }
         P.path_records = true_records;
         if (chain_ok) {
@@ -1243,7 +1245,9 @@ void eMI355X::solve() {
             // the ladder led into a corner (typically an interpolant cutting through a keep-out the coarse meshes
             // did not see): start over on the requested mesh from the default guess
             const size_t target_nodes = P.nodes;
-            for (int ca = 0; climb && ca < 4 && ca < _algorithm.guess_retries && ladder_span > 0 && !r.ok && !ladder_first_rung_failed; ++ca) {
+            // (from the first bend the ladder has not been climbed with yet: a Monte-Carlo scenario whose climb from the +15 % bend ended
+            // in a failed warm start used to climb from +15 % AGAIN, to the same failure, 117 iterations later)
+            for (int ca = ladder_next_bend; climb && ca < 4 && ca < _algorithm.guess_retries && ladder_span > 0 && !r.ok && !ladder_first_rung_failed; ++ca) {
                 if (_algorithm.print_level >= 5)
                     printf("mesh sequencing: warm start on %zu nodes failed (%s), ladder restarted from the line bent by %+.3f\n",
                            target_nodes, r.msg.c_str(), ladder_bends[ca] * ladder_span);
