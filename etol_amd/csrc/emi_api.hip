@@ -274,14 +274,22 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
     // One box, ms per pass, SW = 1 / 8-deep (the round-3 choice) against SW = 2 / 16-deep (profiles/r04_mid_sweep.jsonl): 128 instances
     // 0.0320 / 0.0300, 192: 0.0482 / 0.0442; at 64 instances the sliced SW = 1 form stays ahead (0.0210 / 0.0269), from 256 the 8-deep
     // SW = 2 form (0.0548 / 0.0617).
-    const bool deep_mid = auto_ct && !c->rtc && c->sym_bk == 0 && c->sym_ksplit == 0 && c->sym_nst == 3 && c->ns % 2 == 0 && c->ns > 2 &&
-                          p.tiles16 >= 64 && p.tiles16 < 128;
+    // End of round 4 (profiles/r04_mid_sweep_small_72_120.jsonl, one box, ms per pass): the rule "2 K slices while the MFMA role stays within
+    // 512 workgroups" held up to 80 instances, where the finer sweep found 0.0324 ms against 0.0208 at 64 and 0.0277 at 96.  SW = 1 with 2
+    // slices / SW = 1 unsplit 8-deep / SW = 1 unsplit 16-deep / SW = 2 unsplit 16-deep: 72 instances 0.0323 / 0.0246 / 0.0231 / 0.0261, 80:
+    // 0.0324 / 0.0248 / 0.0234 / 0.0267, 96: 0.0363 / 0.0278 / 0.0266 / 0.0278, 112: 0.0411 / 0.0338 / 0.0335 / 0.0291.  So: above 32 tiles
+    // (64 instances) no slices any more; 33 .. 48 tiles one state per workgroup with 16-deep K tiles (deep_small), from 49 tiles two states
+    // (deep_mid, which began at 64 tiles).
+    const bool deep_base = auto_ct && !c->rtc && c->sym_bk == 0 && c->sym_ksplit == 0 && c->sym_nst == 3;
+    // (both for an even number of states above two, where they were measured: the 6-state quadrotor)
+    const bool deep_mid = deep_base && c->ns % 2 == 0 && c->ns > 2 && p.tiles16 >= 49 && p.tiles16 < 128;
+    const bool deep_small = deep_base && c->ns % 2 == 0 && c->ns > 2 && p.tiles16 >= 33 && p.tiles16 < 49;
     if (c->rtc) ct = (p.store_mode == 2 && emi::rtc_pass_sw_large(c->rtc) == 2) ? 6 : 7;
     else if (auto_ct) ct = (p.tiles16 < 128 && !deep_mid) ? 7 : 6;
     emi::SymPlan plan = emi::plan_symdefect(c->ns, B, c->M, ct, 1, c->sym_cpart, gblk_first, c->sym_cx);
     if (plan.ring1) plan = emi::plan_symdefect(c->ns, B, c->M, 5, 1, c->sym_cpart, c->sym_gblk, c->sym_cx);
     int ks_want = c->sym_ksplit;
-    if (ks_want == 0 && auto_ct && !deep_mid) ks_want = plan.tiles * 4 <= 256 ? 4 : (plan.tiles * 2 <= 512 ? 2 : 1);
+    if (ks_want == 0 && auto_ct && !deep_mid && !deep_small) ks_want = plan.tiles * 4 <= 256 ? 4 : (plan.tiles * 2 <= 512 ? 2 : 1);
     if (ks_want > 1) {
         const int ct_now = plan.sw == c->ns ? 5 : (plan.sw == 2 ? 6 : (plan.sw == 3 ? 8 : 7));
         plan = emi::plan_symdefect(c->ns, B, c->M, ct_now, ks_want, c->sym_cpart, c->rtc ? gblk : c->sym_gblk, c->sym_cx);
@@ -302,7 +310,7 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
     // 416 (1.25 x + 16-deep already): 0.0946 / 0.0951 (profiles/r04_mid_sweep_band_288_416.jsonl)
     const bool deep_band = auto_ct && !c->rtc && c->sym_bk == 0 && c->sym_nst == 3 && c->pass_order < 0 && c->ns % 2 == 0 && c->ns > 2 &&
                            p.tiles16 >= 144 && p.tiles16 < 208;
-    const int bk_want = c->sym_bk ? c->sym_bk : ((deep_mid || deep_large || deep_band) ? 16 : 8);
+    const int bk_want = c->sym_bk ? c->sym_bk : ((deep_mid || deep_small || deep_large || deep_band) ? 16 : 8);
     if (bk_want == 16 && !c->rtc && plan.ks == 1 && (plan.sw == 1 || plan.sw == 2) && plan.nst == 3) plan.bk = 16;
     // two column sub-tiles per MFMA workgroup ("sym_ctc" 2; built-in models, SW = 2, unsplit, three stages): the plan is made again with
     // the wider tiles (tile counts and tile order change with the column width)
