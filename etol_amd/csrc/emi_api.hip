@@ -214,9 +214,15 @@ int ready(emi_ctx_t c) {
 // (profiles/r03_mid_sweep.json): 256 instances (244 MiB) 0.0581 ms against 0.0720 with plain stores, 320: 0.0749 / 0.0973,
 // 384: 0.0879 / 0.1050; 224 instances (214 MiB): plain 0.0557 / nt 0.0606, 128: 0.0338 / 0.0354.  (Round 2 switched at 300 MB of
 // VALS, i.e. above 384 instances: the 256 .. 384 band ran 20 % slow.)
+// Below that: write-through (sc1) stores for the built-in fp64 models since the end of round 4 -- plain stores leave a small pass's results
+// dirty in L2 for the write-back at the end of the kernel, write-through streams them out while the kernel runs.  One box, ms per pass plain /
+// sc1 (profiles/r04_mid_sweep_sc1_stores.jsonl): 1 instance 0.0125 / 0.0105, 16: 0.0149 / 0.0128, 32: 0.0176 / 0.0172, 64: 0.0209 / 0.0215,
+// 80: 0.0233 / 0.0221, 112: 0.0290 / 0.0283, 128: 0.0291 / 0.0286, 144: 0.0305 / 0.0296, 192: 0.0434 / 0.0430, 224: 0.0532 / 0.0505.
+// (Run-time compiled models hold a plain and a non-temporal instantiation only.)
 int store_mode_for(emi_ctx_t c, int B) {
     if (c->node_store >= 0) return c->node_store;
-    return (size_t)B * (nvals_of(c) + nres_of(c)) * c->M * (c->f32 ? 4 : 8) > ((size_t)230 << 20) ? 2 : 0;
+    if ((size_t)B * (nvals_of(c) + nres_of(c)) * c->M * (c->f32 ? 4 : 8) > ((size_t)230 << 20)) return 2;
+    return (!c->rtc && !c->f32) ? 1 : 0;
 }
 
 // Everything the default dispatch decides about ONE launch of the evaluation pass as emi_pass_f64_kernel, in one place:

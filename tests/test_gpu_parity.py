@@ -877,7 +877,7 @@ def _expected_default_form(ev, B):
 
 
 # the shapes the benchmark lines and the profiles quote, pinned: a policy change has to be made here as well as in plan_pass
-PINNED_PLANS = {128: dict(sw=2, ksplit=1, k_tile=16, store_mode=0, block_order=1, piece=0), 1024: dict(sw=2, ksplit=1, k_tile=16, store_mode=2, piece=0),
+PINNED_PLANS = {128: dict(sw=2, ksplit=1, k_tile=16, store_mode=1, block_order=1, piece=0), 1024: dict(sw=2, ksplit=1, k_tile=16, store_mode=2, piece=0),
                 16: dict(sw=1, ksplit=4), 64: dict(sw=1, ksplit=2), 80: dict(sw=1, ksplit=1, k_tile=16), 112: dict(sw=2, ksplit=1, k_tile=16),
                 320: dict(sw=2, ksplit=1, k_tile=16, block_order=150), 4096: dict(sw=2, k_tile=8, column_tiles=2, store_mode=2, piece=0), 256: dict(sw=2, k_tile=8), 512: dict(sw=2, k_tile=16)}
 
@@ -888,7 +888,7 @@ def test_default_dispatch_at_the_benchmarked_shapes_matches_the_oracle(built, B)
     multiple of 8: the grid is padded with workgroups that return at once), 16 / 64 (SW = 1 with 4 / 2 K slices per tile, combined
     in-kernel by ticket), 80 / 112 (no slices any more above 64 instances: SW = 1 / SW = 2 with 16-deep K tiles), 320 (MFMA workgroups at 1.5 x the
     even density, 16-deep), 128 (the shard of config 4:
-    one launch, SW = 1, MFMA workgroups first, plain stores), 256 (SW = 2, MFMA workgroups first, non-temporal stores), 512 (SW = 2, MFMA
+    one launch, SW = 2 with 16-deep K tiles, MFMA workgroups first, write-through stores), 256 (SW = 2, MFMA workgroups first, non-temporal stores), 512 (SW = 2, MFMA
     workgroups at 1.25 x the even density), 1024 (the headline: SW = 2, MFMA workgroups at 1.1 x the even density, 2 column partitions), 2064 (one launch of
     2048 instances + a 16-instance tail), 2560 (one launch in the grouped tile order) -- through the DEFAULT dispatch (no option
     set), device-pointer form as bench.py calls it, against the CPU oracle on sampled instances that sit on every tile

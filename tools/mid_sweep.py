@@ -104,6 +104,8 @@ FORMS = {
     "abl_node_off": dict(overlap_mode=3, sym_ct=6, sym_ablate=32),
     "one_sw2_nst4": dict(overlap_mode=3, sym_ct=6, sym_nst=4),
     "bk16": dict(sym_bk=16),
+    "nt": dict(node_store=2), "plain": dict(node_store=0), "sc1": dict(node_store=1), "ntsc1": dict(node_store=3), "cp1": dict(sym_cpart=1), "cpm1": dict(sym_cpart=-1), "cp4": dict(sym_cpart=4),
+    "nt_order150": dict(node_store=2, pass_order=150), "order150_only": dict(pass_order=150, sym_bk=16), "order0_only": dict(pass_order=0, sym_bk=16),
     "sw1_ks1": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1), "sw1_ks2": dict(overlap_mode=3, sym_ct=7, sym_ksplit=2), "sw2_ks1": dict(overlap_mode=3, sym_ct=6, sym_ksplit=1),
     "slice1280": dict(slice=1280), "slice1536": dict(slice=1536), "ct1": dict(sym_ctc=1), "cp2_ct1": dict(sym_cpart=2, sym_ctc=1), "cp2": dict(sym_cpart=2),
     "order0": dict(pass_order=0), "order110": dict(pass_order=110), "order125": dict(pass_order=125), "order150": dict(pass_order=150), "order200": dict(pass_order=200),
