@@ -60,6 +60,11 @@ struct KktTuning {
                                               // rocblas_dsyrk_batched takes 121 ms where dsyrk takes a few: profiles/r04_kkt_times.jsonl)
     std::atomic<int> batch_syrk_rows{3072};   // "kkt_batch_syrk_rows"
     std::atomic<int> batch_trtri_rows{3072};  // "kkt_batch_trtri_rows"
+    // "kkt_refine_exp": the device refinement of a Newton step stops once its residual is below 10^-this of the right-hand side (largest
+    // entry, at least 1).  10 is IPOPT's residual_ratio_max; rounds 2 - 4 refined to 1e-14, i.e. to round-off.  64 x 1024-node Monte-Carlo
+    // set, solves per iteration on the 1024-node rung / solves per second (profiles/r04_montecarlo_refinement_depth.jsonl): 14: 4.51 / 3.32,
+    // 12: 4.40 / 3.31, 10: 3.78 / 3.43, 8: 3.02 / 3.91 -- with 129 - 131 iterations per scenario and all 64 solved at every depth
+    std::atomic<int> refine_exp{10};
 };
 static KktTuning g_tune;
 bool kkt_set_option(const char* name, int value) {
@@ -76,6 +81,7 @@ bool kkt_set_option(const char* name, int value) {
     if (!strcmp(name, "kkt_batch_gemm_rows")) { g_tune.batch_gemm_rows = value; return true; }
     if (!strcmp(name, "kkt_batch_syrk_rows")) { g_tune.batch_syrk_rows = value; return true; }
     if (!strcmp(name, "kkt_batch_trtri_rows")) { g_tune.batch_trtri_rows = value; return true; }
+    if (!strcmp(name, "kkt_refine_exp")) { g_tune.refine_exp = value < 6 ? 6 : (value > 16 ? 16 : value); return true; }
     return false;
 }
 
@@ -2265,6 +2271,7 @@ int kkt_solve_refined_batch(int n, KktWorkspace* const* ws, hipStream_t stream, 
     if (int st = solve_shape(n, ws, &sh, err)) return st;
     KktWorkspace* L = ws[0];
     const int N = sh.N;
+    const double refine_rel = std::pow(10.0, -(double)g_tune.refine_exp.load());
     for (int b = 0; b < n; ++b) {
         if (int st = solve_buffers(ws[b], sh.N, sh.nz, sh.md, true, err)) return st;
         KKT_HIP(hipMemcpyAsync(ws[b]->ref_b, rhs[b], (size_t)N * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -2324,7 +2331,7 @@ int kkt_solve_refined_batch(int n, KktWorkspace* const* ws, hipStream_t stream, 
                 continue;
             }
             rlast[b] = rmax;
-            if (ir == max_steps || !(rmax > 1e-14 * std::max(1.0, bmax[b])) || !(rmax < 0.5 * prev[b])) continue;
+            if (ir == max_steps || !(rmax > refine_rel * std::max(1.0, bmax[b])) || !(rmax < 0.5 * prev[b])) continue;
             prev[b] = rmax;
             next.push_back(act[a]);
             next_idx.push_back(b);

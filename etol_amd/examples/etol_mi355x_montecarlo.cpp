@@ -239,14 +239,15 @@ int main(int argc, char** argv) {
     // diagnostics: process-wide factorisation switches (emi_set_option "kkt_*"), e.g. EMI_MC_KKT_DEBUG=1 prints retries and
     // fallbacks on stderr, EMI_MC_KKT_STICKY=0 starts every factorisation at the nominal regularisation again
     const int kkt_debug = env_int("EMI_MC_KKT_DEBUG", 0), kkt_sticky = env_int("EMI_MC_KKT_STICKY", -1), kkt_primal = env_int("EMI_MC_KKT_PRIMAL", -1);
-    const int kkt_chol = env_int("EMI_MC_KKT_CHOLESKY", -1);
-    if (kkt_debug > 0 || kkt_sticky >= 0 || kkt_primal >= 0 || kkt_chol >= 0) {
+    const int kkt_chol = env_int("EMI_MC_KKT_CHOLESKY", -1), kkt_refine = env_int("EMI_MC_KKT_REFINE_EXP", -1);
+    if (kkt_debug > 0 || kkt_sticky >= 0 || kkt_primal >= 0 || kkt_chol >= 0 || kkt_refine >= 0) {
         emi_ctx_t sw = nullptr;
         if (emi_create(device, &sw) == EMI_OK) {
             if (kkt_debug > 0) emi_set_option(sw, "kkt_debug", kkt_debug);
             if (kkt_sticky >= 0) emi_set_option(sw, "kkt_sticky_reg", kkt_sticky);
             if (kkt_primal >= 0) emi_set_option(sw, "kkt_primal_levels", kkt_primal);
             if (kkt_chol >= 0) emi_set_option(sw, "kkt_cholesky", kkt_chol);
+            if (kkt_refine >= 0) emi_set_option(sw, "kkt_refine_exp", kkt_refine);
             emi_destroy(sw);
         }
     }

@@ -468,6 +468,7 @@ def test_refined_solves_on_the_device_reach_round_off_in_the_nominal_matrix(buil
     ctxs = (C.c_void_p * n)(*[ev.ctx for ev in evs])
     for b in range(n):
         assert evs[b].kkt_factor(*probs[b], dc=max(dcs[b], 0.0)) == 0
+    evs[0].set_option("kkt_refine_exp", 14)      # (process-wide) refine to round-off here; the default stops at 1e-10 of the right-hand side
     lr = None
     if n >= 3:          # scenario 2: an active low-rank correction (K = K~ - d u u^T)
         node, vec, delta = np.array([M // 3], dtype=np.int32), rng.standard_normal((1, nv)) * 0.3, np.array([0.5])
@@ -501,6 +502,12 @@ def test_refined_solves_on_the_device_reach_round_off_in_the_nominal_matrix(buil
     r1, n1, v1, s1 = C.c_double(), C.c_int(), C.c_int(), C.c_int()
     assert lib.emi_kkt_solve_refined(evs[0].ctx, dp(w1), float(dcs[0]), 8, C.byref(r1), C.byref(n1), C.byref(v1), C.byref(s1)) == 0
     assert np.abs(w1 - work[0]).max() < 1e-12 * (np.abs(w1).max() + 1)
+    # the default depth (IPOPT's residual_ratio_max): no more solves than before, and the residual it reports is below 1e-10
+    evs[0].set_option("kkt_refine_exp", 10)
+    w2 = rhs[0].copy()
+    r2, n2 = C.c_double(), C.c_int()
+    assert lib.emi_kkt_solve_refined(evs[0].ctx, dp(w2), float(dcs[0]), 8, C.byref(r2), C.byref(n2), C.byref(v1), C.byref(s1)) == 0
+    assert n2.value <= n1.value and r2.value < 1e-10, (n2.value, n1.value, r2.value)
     # an LU factorisation is not offered: EMI_ERR_UNSUPPORTED (5)
     evs[0].set_option("kkt_method", 0)
     assert evs[0].kkt_factor(*probs[0], dc=1e-9) == 0
