@@ -308,7 +308,9 @@ PassPlan plan_pass(emi_ctx_t c, int B, bool jac) {
     // 16-deep, 448 instances 0.1112 / 0.1018, 512: 0.1226 / 0.1151, 576: 0.1351 / 0.1277, 640: 0.1492 / 0.1431, 768: 0.1675 / 0.1649,
     // 896: 0.1921 / 0.1896, 1024: 0.2164 / 0.2143; not at 256 .. 384 instances (MFMA workgroups first: 320: 0.0752 / 0.0924) nor from 2048
     // (0.4147 / 0.4205; 4096 in the grouped order 1.081 / 1.175)
-    const bool deep_large = auto_ct && !c->rtc && c->sym_bk == 0 && c->sym_nst == 3 && c->pass_order < 0 && p.tiles16 >= 208 && p.tiles16 < 768;
+    // (up to 1024 tiles -- 2048 instances -- since the end of round 4: with the pass kernel's register allocation stated, 8- / 16-deep at 1536
+    // instances 0.3204 / 0.3117, 1792: 0.3725 / 0.3611, 2048: 0.4441 / 0.4322, profiles/r04_mid_sweep_1280_2048.jsonl)
+    const bool deep_large = auto_ct && !c->rtc && c->sym_bk == 0 && c->sym_nst == 3 && c->pass_order < 0 && p.tiles16 >= 208 && p.tiles16 <= 1024;
     // ... and between 144 and 207 tiles (288 .. 415 instances) TOGETHER with the MFMA workgroups at 1.5 x the even density instead of all
     // of them first: from ~300 instances the role's 3 x tiles workgroups no longer fit beside the node role (64 places per XCD), which then
     // starts a workgroup generation late.  End of round 4, one box, ms per pass, first + 8-deep (the choice until then) / 1.5 x + 16-deep:

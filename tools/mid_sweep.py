@@ -104,6 +104,7 @@ FORMS = {
     "abl_node_off": dict(overlap_mode=3, sym_ct=6, sym_ablate=32),
     "one_sw2_nst4": dict(overlap_mode=3, sym_ct=6, sym_nst=4),
     "bk16": dict(sym_bk=16),
+    "o100": dict(pass_order=100, sym_bk=16), "o105": dict(pass_order=105, sym_bk=16), "o110": dict(pass_order=110, sym_bk=16), "o115": dict(pass_order=115, sym_bk=16), "o120": dict(pass_order=120, sym_bk=16), "o130": dict(pass_order=130, sym_bk=16),
     "nt": dict(node_store=2), "plain": dict(node_store=0), "sc1": dict(node_store=1), "ntsc1": dict(node_store=3), "cp1": dict(sym_cpart=1), "cpm1": dict(sym_cpart=-1), "cp4": dict(sym_cpart=4),
     "nt_order150": dict(node_store=2, pass_order=150), "order150_only": dict(pass_order=150, sym_bk=16), "order0_only": dict(pass_order=0, sym_bk=16),
     "sw1_ks1": dict(overlap_mode=3, sym_ct=7, sym_ksplit=1), "sw1_ks2": dict(overlap_mode=3, sym_ct=7, sym_ksplit=2), "sw2_ks1": dict(overlap_mode=3, sym_ct=6, sym_ksplit=1),
