@@ -222,6 +222,10 @@ int ready(emi_ctx_t c) {
 int store_mode_for(emi_ctx_t c, int B) {
     if (c->node_store >= 0) return c->node_store;
     if ((size_t)B * (nvals_of(c) + nres_of(c)) * c->M * (c->f32 ? 4 : 8) > ((size_t)230 << 20)) return 2;
+    // (17 .. 32 tiles -- 33 .. 64 instances at 1024 nodes, the two-slice band -- are the one place where plain stores stay ahead: 48 instances
+    // 0.0197 / 0.0203, 64: 0.0209 / 0.0215)
+    const int tiles16 = ((B + 15) / 16) * (c->M / 128);
+    if (tiles16 > 16 && tiles16 <= 32) return 0;
     return (!c->rtc && !c->f32) ? 1 : 0;
 }
 
