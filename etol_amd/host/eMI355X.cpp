@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <queue>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -888,6 +889,104 @@ void repair_guess(const Prob& P, double* xs, double* ys) {
     }
 }
 
+// A path from the start position to the end position through the free space of the STATIC keep-outs of the record table (discs and
+// ellipses, grown by `grow` of their size; tracks move and are left to repair_guess): Dijkstra over an 8-connected grid on the box of the
+// two position states, then the positions of the nodes spread along it by arc length in node time.  The last of the cold-start guesses
+// (solve_cold_with_retries): a bent straight line only reaches the homotopy classes next to the straight one -- a start that sits behind a
+// wall of overlapping keep-outs with one gap (Monte-Carlo scenario 938 of config 4, profiles/r04_notes.md section 22) needs a route.
+bool planned_path_guess(const Prob& P, double* xs, double* ys) {
+    const size_t M = P.nodes, ns = P.nstates;
+    if (P.px >= ns || P.py >= ns || M < 3 || P.event_lower.size() != 2 * ns) return false;
+    const size_t nrec = P.npath - P.npath_traced;
+    if (nrec == 0) return false;
+    const double x0 = 0.5 * (P.event_lower[P.px] + P.event_upper[P.px]), y0 = 0.5 * (P.event_lower[P.py] + P.event_upper[P.py]);
+    const double x1 = 0.5 * (P.event_lower[ns + P.px] + P.event_upper[ns + P.px]), y1 = 0.5 * (P.event_lower[ns + P.py] + P.event_upper[ns + P.py]);
+    double xl = P.state_lower[P.px], xu = P.state_upper[P.px], yl = P.state_lower[P.py], yu = P.state_upper[P.py];
+    const double span = std::max(std::fabs(x1 - x0), std::fabs(y1 - y0));
+    if (!(span > 0)) return false;
+    // unbounded positions: a box of twice the span round the end points
+    if (!(xl > -1e18) || !(xu < 1e18)) { xl = std::min(x0, x1) - span; xu = std::max(x0, x1) + span; }
+    if (!(yl > -1e18) || !(yu < 1e18)) { yl = std::min(y0, y1) - span; yu = std::max(y0, y1) + span; }
+    const int N = 161;
+    const double hx = (xu - xl) / (N - 1), hy = (yu - yl) / (N - 1);
+    if (!(hx > 0) || !(hy > 0)) return false;
+    auto cell = [&](double x, double y, int* i, int* j) {
+        *i = std::min(N - 1, std::max(0, (int)std::lround((x - xl) / hx)));
+        *j = std::min(N - 1, std::max(0, (int)std::lround((y - yl) / hy)));
+    };
+    int is, js, it, jt;
+    cell(x0, y0, &is, &js);
+    cell(x1, y1, &it, &jt);
+    for (double grow : {0.25, 0.1, 0.0}) {
+        std::vector<char> blocked((size_t)N * N, 0);
+        for (size_t j = 0; j < nrec; ++j) {
+            const double* r = &P.path_records[j * EMI_PATH_REC];
+            const int kind = (int)r[0];
+            double xc, yc, ct = 1, st = 0, asq, bsq;
+            if (kind == EMI_PATH_ELLIPSE) { xc = r[1]; yc = r[2]; ct = r[3]; st = r[4]; asq = r[5]; bsq = r[6]; }
+            else if (kind == EMI_PATH_DISC) { xc = r[1]; yc = r[2]; asq = bsq = r[3]; }
+            else continue;
+            if (!(asq > 0) || !(bsq > 0)) continue;
+            const double g = (1.0 + grow) * (1.0 + grow), reach = std::sqrt(std::max(asq, bsq) * g);
+            int ia, ja, ib, jb;
+            cell(xc - reach, yc - reach, &ia, &ja);
+            cell(xc + reach, yc + reach, &ib, &jb);
+            for (int i = ia; i <= ib; ++i)
+                for (int q = ja; q <= jb; ++q) {
+                    const double dx = xl + i * hx - xc, dy = yl + q * hy - yc;
+                    const double ex = ct * dx - st * dy, ey = st * dx + ct * dy;
+                    if (ex * ex / (asq * g) + ey * ey / (bsq * g) < 1.0) blocked[(size_t)i * N + q] = 1;
+                }
+        }
+        blocked[(size_t)is * N + js] = blocked[(size_t)it * N + jt] = 0;
+        // Dijkstra (8 neighbours, Euclidean step lengths)
+        std::vector<double> dist((size_t)N * N, 1e300);
+        std::vector<int> prev((size_t)N * N, -1);
+        typedef std::pair<double, int> QE;
+        std::priority_queue<QE, std::vector<QE>, std::greater<QE>> pq;
+        dist[(size_t)is * N + js] = 0;
+        pq.push({0.0, is * N + js});
+        const int goal = it * N + jt;
+        while (!pq.empty()) {
+            const QE e = pq.top();
+            pq.pop();
+            if (e.first > dist[e.second]) continue;
+            if (e.second == goal) break;
+            const int i = e.second / N, q = e.second % N;
+            for (int di = -1; di <= 1; ++di)
+                for (int dj = -1; dj <= 1; ++dj) {
+                    if (!di && !dj) continue;
+                    const int a = i + di, b = q + dj;
+                    if (a < 0 || b < 0 || a >= N || b >= N || blocked[(size_t)a * N + b]) continue;
+                    const double d = e.first + std::sqrt(di * di * hx * hx + dj * dj * hy * hy);
+                    if (d < dist[(size_t)a * N + b]) { dist[(size_t)a * N + b] = d; prev[(size_t)a * N + b] = e.second; pq.push({d, a * N + b}); }
+                }
+        }
+        if (!(dist[goal] < 1e299)) continue;                 // no route with the keep-outs grown this much: try them smaller
+        std::vector<double> px, py;
+        for (int c = goal; c >= 0; c = prev[c]) { px.push_back(xl + (c / N) * hx); py.push_back(yl + (c % N) * hy); }
+        std::reverse(px.begin(), px.end());
+        std::reverse(py.begin(), py.end());
+        px.front() = x0; py.front() = y0; px.back() = x1; py.back() = y1;
+        // three passes of neighbour averaging take the grid's staircase out (end points fixed)
+        for (int pass = 0; pass < 3; ++pass)
+            for (size_t c = 1; c + 1 < px.size(); ++c) { px[c] = 0.25 * px[c - 1] + 0.5 * px[c] + 0.25 * px[c + 1]; py[c] = 0.25 * py[c - 1] + 0.5 * py[c] + 0.25 * py[c + 1]; }
+        std::vector<double> arc(px.size(), 0.0);
+        for (size_t c = 1; c < px.size(); ++c) arc[c] = arc[c - 1] + std::hypot(px[c] - px[c - 1], py[c] - py[c - 1]);
+        if (!(arc.back() > 0)) return false;
+        size_t seg = 0;
+        for (size_t k = 0; k < M; ++k) {
+            const double s = 0.5 * (P.tau[k] + 1.0) * arc.back();
+            while (seg + 2 < px.size() && arc[seg + 1] < s) ++seg;
+            const double w = arc[seg + 1] > arc[seg] ? (s - arc[seg]) / (arc[seg + 1] - arc[seg]) : 0.0;
+            xs[k] = px[seg] + std::min(1.0, std::max(0.0, w)) * (px[seg + 1] - px[seg]);
+            ys[k] = py[seg] + std::min(1.0, std::max(0.0, w)) * (py[seg + 1] - py[seg]);
+        }
+        return true;
+    }
+    return false;
+}
+
 std::vector<double> initial_guess(const Prob& P) {
     const size_t ns = P.nstates, nc = P.ncontrols, M = P.nodes;
     std::vector<double> z0((ns + nc) * M, 0.0);
@@ -900,7 +999,9 @@ std::vector<double> initial_guess(const Prob& P) {
         const double b = 0.5 * (P.event_lower[ns + i] + P.event_upper[ns + i]);
         for (size_t k = 0; k < M; ++k) z0[i * M + k] = a + (b - a) * 0.5 * (P.tau[k] + 1.0);
     }
-    if (P.guess_bend != 0 && P.px < ns && P.py < ns) {
+    bool planned = false;
+    if (P.guess_planned && P.px < ns && P.py < ns) planned = planned_path_guess(P, &z0[P.px * M], &z0[P.py * M]);
+    if (!planned && P.guess_bend != 0 && P.px < ns && P.py < ns) {
         // the line bent sideways (half a sine wave along it): another homotopy class round the keep-outs
         const double dx = z0[P.px * M + M - 1] - z0[P.px * M], dy = z0[P.py * M + M - 1] - z0[P.py * M];
         const double len = std::sqrt(dx * dx + dy * dy);
@@ -1075,6 +1176,15 @@ void eMI355X::solve() {
             solve_current_mesh(o);
         }
         P.guess_bend = 0;
+        // ... and last from a route planned through the free space of the static keep-outs (planned_path_guess).  Only here: as the second
+        // start of a ladder climb (before the bends) the shortest route, which hugs the keep-outs, made the 64-scenario set slower (138.7
+        // against 129.7 iterations per scenario) and cost scenario 960 its solution (profiles/r04_notes.md section 24).
+        if (!r.ok && span > 0 && _algorithm.guess_retries > 0) {
+            P.guess_planned = true;
+            if (_algorithm.print_level >= 5) printf("cold start failed (%s): retrying from a path planned through the free space\n", r.msg.c_str());
+            solve_current_mesh(o);
+            P.guess_planned = false;
+        }
     };
     // Multipliers are NOT carried to the next mesh by default: measured over 32 Monte-Carlo scenarios at 257 nodes the
     // costate-mapped warm start needed 112 iterations on average against 103 from zero multipliers (interior-point

@@ -18,6 +18,9 @@ namespace mi355x {
 NlpProblem make_nlp(const Prob& P, NlpEvaluator* ev);
 // zeros unless Prob::guess_* were pre-filled (reference ePSOPT.cpp:47-56)
 std::vector<double> initial_guess(const Prob& P);
+// positions of the nodes along a shortest path through the free space of the static keep-outs (the last cold-start guess of solve()):
+// false if the problem has no such rows or no route exists
+bool planned_path_guess(const Prob& P, double* xs, double* ys);
 // variable scales of Alg::scaling = "automatic": max(|lower|, |upper|) per state / control (1 without a finite bound)
 std::vector<double> bound_scales(const Prob& P);
 

@@ -171,6 +171,7 @@ struct Prob {
     std::vector<double> guess_states, guess_controls;   // optional warm start, [n][nodes]
     std::vector<double> guess_lamF, guess_lamC;         // multipliers to go with it, [nstates][nodes] / [npath][nodes]
     double guess_bend = 0;                              // default guess: sideways offset of the straight line at mid-horizon
+    bool guess_planned = false;                         // default guess: positions along a shortest path through the free space of the static keep-outs
                                                         // (set by solve() when it retries a locally infeasible start)
 };
 

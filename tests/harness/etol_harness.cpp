@@ -291,6 +291,25 @@ extern "C" int harness_solve_delay_demo_oracle(const char* oracle_so, int nsteps
     return 0;
 }
 
+// ---- the planned cold-start guess (mi355x::planned_path_guess): discs (xc, yc, r) x ndisc, start / end, box, M LGL nodes -> xs, ys
+extern "C" int harness_planned_path(int ndisc, const double* discs, double x0, double y0, double x1, double y1, double lo, double hi, int M,
+                                    double* xs, double* ys) {
+    mx::Prob P;
+    P.nstates = 2; P.ncontrols = 1;
+    P.nodes = (size_t)M;
+    P.tau.resize(M); P.w.resize(M); P.D.resize((size_t)M * M);
+    emi_lgl(M, P.tau.data(), P.w.data(), P.D.data());
+    for (int i = 0; i < ndisc; ++i) {
+        const double rec[EMI_PATH_REC] = {(double)EMI_PATH_DISC, discs[3 * i], discs[3 * i + 1], discs[3 * i + 2] * discs[3 * i + 2], 0, 0, 0, 0};
+        P.path_records.insert(P.path_records.end(), rec, rec + EMI_PATH_REC);
+    }
+    P.npath = (size_t)ndisc;
+    P.px = 0; P.py = 1;
+    P.state_lower = {lo, lo}; P.state_upper = {hi, hi};
+    P.event_lower = {x0, y0, x1, y1}; P.event_upper = {x0, y0, x1, y1};
+    return mx::planned_path_guess(P, xs, ys) ? 0 : 1;
+}
+
 // ---- traced models: the quadrotor written with mi355x::Var arithmetic, as a user would -----------
 namespace {
 // x = (px, pz, theta, vx, vz, omega), u = (T, tau); same equations as EMI_MODEL_QUADROTOR2D

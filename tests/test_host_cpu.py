@@ -317,3 +317,34 @@ def test_delayed_problem_is_solved_through_coupling_rows(H, disc_r, scaling):
     for dst, src, W in P.links:
         Zn[dst * M:(dst + 1) * M] = Z[src * M:(src + 1) * M]
     assert np.abs(N.Nlp.defect(P, Zn)).max() > 1e-3
+
+
+def test_planned_cold_start_guess_finds_the_gap_in_a_wall_of_keepouts(built):
+    """mi355x::planned_path_guess (the last cold-start guess of solve(): a route through the free space of the static keep-outs, the node
+    positions spread along it).  The layout is Monte-Carlo scenario 938 of config 4 (profiles/r04_notes.md section 22): the start sits
+    under a wall of overlapping discs that the straight line to the goal enters at once; the only way out is the gap below the first
+    disc.  The planned positions start and end where they must, stay outside every disc, and leave through that gap; with the gap closed
+    and the start walled in there is no route and the function says so."""
+    import ctypes as C
+    H = C.CDLL(os.path.join(ROOT, "tests", "harness", "libetol_harness.so"))
+    D = C.POINTER(C.c_double)
+    H.harness_planned_path.argtypes = [C.c_int, D, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, D, D]
+    discs = np.array([(1.10, 2.09, 0.44), (1.27, 4.12, 0.23), (8.37, 4.69, 0.38), (1.96, 2.52, 0.58), (7.62, 6.90, 0.52), (1.23, 3.84, 0.53),
+                      (1.41, 7.11, 0.37), (7.74, 3.61, 0.50), (1.49, 7.12, 0.48), (7.21, 5.93, 0.21), (6.95, 6.54, 0.25), (1.23, 2.72, 0.33),
+                      (4.74, 5.63, 0.22), (4.04, 3.13, 0.30), (8.46, 4.16, 0.33), (1.75, 1.64, 0.41), (6.23, 3.88, 0.32), (7.08, 4.23, 0.52),
+                      (4.08, 2.70, 0.29), (6.04, 3.69, 0.44)])
+    M = 65
+    xs, ys = np.zeros(M), np.zeros(M)
+    dp = lambda a: a.ctypes.data_as(D)
+    flat = np.ascontiguousarray(discs.ravel())
+    assert H.harness_planned_path(len(discs), dp(flat), 1.0, 1.0, 8.0, 6.0, 0.0, 10.0, M, dp(xs), dp(ys)) == 0
+    assert abs(xs[0] - 1) < 1e-12 and abs(ys[0] - 1) < 1e-12 and abs(xs[-1] - 8) < 1e-12 and abs(ys[-1] - 6) < 1e-12
+    clear = np.min(np.hypot(xs[:, None] - discs[None, :, 0], ys[:, None] - discs[None, :, 1]) - discs[None, :, 2], axis=1)
+    assert clear.min() > 0.0, clear.min()                                # no node inside a disc
+    k = np.argmin(np.abs(xs - 1.75))
+    assert ys[k] < 1.64 - 0.41                                            # out through the gap BELOW the first disc
+    assert np.all(np.diff(np.hypot(np.diff(xs), np.diff(ys)) / np.diff(np.arange(M))) < 10)     # (finite steps: sanity)
+    # a ring of discs round the start: no route
+    ring = np.array([(1 + 0.9 * np.cos(a), 1 + 0.9 * np.sin(a), 0.5) for a in np.linspace(0, 2 * np.pi, 16, endpoint=False)])
+    flat = np.ascontiguousarray(ring.ravel())
+    assert H.harness_planned_path(len(ring), dp(flat), 1.0, 1.0, 8.0, 6.0, -5.0, 10.0, M, dp(xs), dp(ys)) == 1
