@@ -894,7 +894,7 @@ void repair_guess(const Prob& P, double* xs, double* ys) {
 // two position states, then the positions of the nodes spread along it by arc length in node time.  The last of the cold-start guesses
 // (solve_cold_with_retries): a bent straight line only reaches the homotopy classes next to the straight one -- a start that sits behind a
 // wall of overlapping keep-outs with one gap (Monte-Carlo scenario 938 of config 4, profiles/r04_notes.md section 22) needs a route.
-bool planned_path_guess(const Prob& P, double* xs, double* ys) {
+bool planned_path_guess(const Prob& P, double* xs, double* ys, double clearance_weight) {
     const size_t M = P.nodes, ns = P.nstates;
     if (P.px >= ns || P.py >= ns || M < 3 || P.event_lower.size() != 2 * ns) return false;
     const size_t nrec = P.npath - P.npath_traced;
@@ -917,6 +917,28 @@ bool planned_path_guess(const Prob& P, double* xs, double* ys) {
     int is, js, it, jt;
     cell(x0, y0, &is, &js);
     cell(x1, y1, &it, &jt);
+    // clearance of every cell from the nearest static keep-out (exact for discs, from the quadratic form for ellipses): steps through
+    // narrow places are charged more, so that the route prefers the middle of a gap to the edge of a keep-out -- a start for an
+    // interior-point iteration wants room, not the shortest way
+    std::vector<double> clear((size_t)N * N, 1e300);
+    for (size_t j = 0; j < nrec; ++j) {
+        const double* r = &P.path_records[j * EMI_PATH_REC];
+        const int kind = (int)r[0];
+        double xc, yc, ct = 1, st = 0, asq, bsq;
+        if (kind == EMI_PATH_ELLIPSE) { xc = r[1]; yc = r[2]; ct = r[3]; st = r[4]; asq = r[5]; bsq = r[6]; }
+        else if (kind == EMI_PATH_DISC) { xc = r[1]; yc = r[2]; asq = bsq = r[3]; }
+        else continue;
+        if (!(asq > 0) || !(bsq > 0)) continue;
+        const double rmin = std::sqrt(std::min(asq, bsq));
+        for (int i = 0; i < N; ++i)
+            for (int q = 0; q < N; ++q) {
+                const double dx = xl + i * hx - xc, dy = yl + q * hy - yc;
+                const double ex = ct * dx - st * dy, ey = st * dx + ct * dy;
+                const double c = (std::sqrt(ex * ex / asq + ey * ey / bsq) - 1.0) * rmin;
+                clear[(size_t)i * N + q] = std::min(clear[(size_t)i * N + q], c);
+            }
+    }
+    const double room = clearance_weight * span;          // a step at this clearance costs twice its length
     for (double grow : {0.25, 0.1, 0.0}) {
         std::vector<char> blocked((size_t)N * N, 0);
         for (size_t j = 0; j < nrec; ++j) {
@@ -958,7 +980,8 @@ bool planned_path_guess(const Prob& P, double* xs, double* ys) {
                     if (!di && !dj) continue;
                     const int a = i + di, b = q + dj;
                     if (a < 0 || b < 0 || a >= N || b >= N || blocked[(size_t)a * N + b]) continue;
-                    const double d = e.first + std::sqrt(di * di * hx * hx + dj * dj * hy * hy);
+                    const double cl = std::max(clear[(size_t)a * N + b], 1e-3 * span);
+                    const double d = e.first + std::sqrt(di * di * hx * hx + dj * dj * hy * hy) * (1.0 + (room > 0 ? (room / cl) * (room / cl) : 0.0));
                     if (d < dist[(size_t)a * N + b]) { dist[(size_t)a * N + b] = d; prev[(size_t)a * N + b] = e.second; pq.push({d, a * N + b}); }
                 }
         }
@@ -1163,6 +1186,8 @@ void eMI355X::solve() {
     auto solve_cold_with_retries = [&](const mi355x::NlpOptions& o) {
         solve_current_mesh(o);
         if (r.ok || P.npath == 0 || !P.guess_states.empty() || _algorithm.guess_retries <= 0) return;
+        const bool outer_planned = P.guess_planned;          // (a ladder climb that starts from the planned route: the bends follow without it)
+        P.guess_planned = false;
         double span = 0;
         if (P.event_lower.size() == 2 * ns) {
             const double dx = 0.5 * (P.event_lower[ns + P.px] + P.event_upper[ns + P.px]) - 0.5 * (P.event_lower[P.px] + P.event_upper[P.px]);
@@ -1176,15 +1201,15 @@ void eMI355X::solve() {
             solve_current_mesh(o);
         }
         P.guess_bend = 0;
-        // ... and last from a route planned through the free space of the static keep-outs (planned_path_guess).  Only here: as the second
-        // start of a ladder climb (before the bends) the shortest route, which hugs the keep-outs, made the 64-scenario set slower (138.7
-        // against 129.7 iterations per scenario) and cost scenario 960 its solution (profiles/r04_notes.md section 24).
-        if (!r.ok && span > 0 && _algorithm.guess_retries > 0) {
+        // ... and last from a route planned through the free space of the static keep-outs (planned_path_guess), unless this cold start
+        // already began from it (a ladder climb's second start, Alg::plan_second_start).
+        if (!r.ok && span > 0 && _algorithm.guess_retries > 0 && !outer_planned) {
             P.guess_planned = true;
             if (_algorithm.print_level >= 5) printf("cold start failed (%s): retrying from a path planned through the free space\n", r.msg.c_str());
             solve_current_mesh(o);
             P.guess_planned = false;
         }
+        P.guess_planned = outer_planned;
     };
     // Multipliers are NOT carried to the next mesh by default: measured over 32 Monte-Carlo scenarios at 257 nodes the
     // costate-mapped warm start needed 112 iterations on average against 103 from zero multipliers (interior-point
@@ -1236,11 +1261,16 @@ void eMI355X::solve() {
     _solution.nlp_runs.clear();
     _solution.ode_error = 0;
     bool sequenced = false;             // the requested mesh is started from the sequencing ladder's solution
-    std::function<bool(double)> climb;  // the ladder from its coarsest mesh with the straight-line guess bent by so much: true if every rung converged
+    std::function<bool(double, bool)> climb;  // the ladder from its coarsest mesh with the straight-line guess bent by so much: true if every rung converged
     double ladder_span = 0;
-    int ladder_next_bend = 0;           // index into ladder_bends of the first bend no climb has used yet
+    int ladder_next_start = 1;          // index of the first start (below) no climb has used yet
+    bool ladder_has_plan = false;       // Alg::plan_second_start, and the static keep-outs leave a route that planned_path_guess finds
     bool ladder_first_rung_failed = false;
     const double ladder_bends[4] = {0.15, -0.15, 0.35, -0.35};
+    // start k of a climb: 0 the straight line, then (Alg::plan_second_start, if there is one) the planned route, then the bends
+    auto ladder_start_planned = [&](int k) { return ladder_has_plan && k == 1; };
+    auto ladder_start_bend = [&](int k) { const int b = k - 1 - (ladder_has_plan ? 1 : 0); return (b >= 0 && b < 4) ? ladder_bends[b] : 0.0; };
+    auto ladder_starts = [&]() { return 1 + (ladder_has_plan ? 1 : 0) + 4; };
 
     // Mesh sequencing: a fine global mesh is reached through coarse ones (33, 65, 129, ... nodes), each
     // solve started from the interpolated previous solution.  An interior-point iteration from a cold
@@ -1281,9 +1311,17 @@ void eMI355X::solve() {
         // see) sends the whole ladder back to its start with the straight-line guess bent to one side: a cold start on
         // 33 nodes costs a quarter of a second, whereas the fallback below -- cold starts on the requested mesh -- spent
         // 4 x 400 iterations of a 513-node problem on one Monte-Carlo scenario (36 of its 41 s, profiles/r02_notes.md).
-        const int ladder_tries = (P.npath > 0 && span > 0) ? 1 + std::min(4, std::max(0, _algorithm.guess_retries)) : 1;
+        // Alg::plan_second_start: the route planned through the free space as the second start of a climb, before the bends.  (The SHORTEST
+        // route, which hugs the keep-outs, made things worse in that place: 138.7 against 129.7 iterations per scenario on the 64-scenario
+        // set, scenario 960 lost; charged for narrow places it takes that set to 127.0, the 256-scenario set from 135.2 to 125.5, scenario
+        // 960 from 870 to 235 iterations and scenario 17 from 685 to 313: profiles/r04_notes.md section 24.)
+        if (_algorithm.plan_second_start) {
+            std::vector<double> px(P.nodes), py(P.nodes);
+            ladder_has_plan = P.npath > 0 && span > 0 && _algorithm.guess_retries > 0 && mi355x::planned_path_guess(P, px.data(), py.data());
+        }
+        const int ladder_tries = (P.npath > 0 && span > 0) ? 1 + (ladder_has_plan ? 1 : 0) + std::min(4, std::max(0, _algorithm.guess_retries)) : 1;
         ladder_span = ladder_tries > 1 ? span : 0.0;
-        climb = [&, this, inflate_records](double bend) -> bool {
+        climb = [&, this, inflate_records](double bend, bool planned) -> bool {
             P.guess_states.clear();
             P.guess_controls.clear();
             P.guess_lamF.clear();
@@ -1299,8 +1337,10 @@ void eMI355X::solve() {
                 if (li > 0 && _algorithm.rung_patience > 0) o.max_iter = std::min(o.max_iter, _algorithm.rung_patience);
                 if (li == 0) {
                     P.guess_bend = bend;
+                    P.guess_planned = planned;
                     solve_cold_with_retries(o);
                     P.guess_bend = 0;
+                    P.guess_planned = false;
                 } else {
                     solve_warm(o);
                 }
@@ -1322,11 +1362,14 @@ void eMI355X::solve() {
         };
         bool chain_ok = false;
         for (int ca = 0; ca < ladder_tries && !chain_ok && !ladder_first_rung_failed; ++ca) {
-            if (ca > 0 && _algorithm.print_level >= 5)
-                printf("mesh sequencing: a rung failed (%s), ladder restarted from the line bent by %+.3f\n", r.msg.c_str(),
-                       ladder_bends[ca - 1] * span);
-            chain_ok = climb(ca > 0 ? ladder_bends[ca - 1] * span : 0.0);
-            ladder_next_bend = ca;                  // bends 0 .. ca - 1 have been used (the climb is deterministic: none is worth repeating)
+            const bool planned = ladder_start_planned(ca);
+            const double bend = ladder_start_bend(ca) * span;
+            if (ca > 0 && _algorithm.print_level >= 5) {
+                if (planned) printf("mesh sequencing: a rung failed (%s), ladder restarted from the route planned through the free space\n", r.msg.c_str());
+                else printf("mesh sequencing: a rung failed (%s), ladder restarted from the line bent by %+.3f\n", r.msg.c_str(), bend);
+            }
+            chain_ok = climb(bend, planned);
+            ladder_next_start = ca + 1;             // starts 0 .. ca have been used (the climb is deterministic: none is worth repeating)
         }
         P.path_records = true_records;
         if (chain_ok) {
@@ -1357,11 +1400,14 @@ void eMI355X::solve() {
             const size_t target_nodes = P.nodes;
             // (from the first bend the ladder has not been climbed with yet: a Monte-Carlo scenario whose climb from the +15 % bend ended
             // in a failed warm start used to climb from +15 % AGAIN, to the same failure, 117 iterations later)
-            for (int ca = ladder_next_bend; climb && ca < 4 && ca < _algorithm.guess_retries && ladder_span > 0 && !r.ok && !ladder_first_rung_failed; ++ca) {
-                if (_algorithm.print_level >= 5)
-                    printf("mesh sequencing: warm start on %zu nodes failed (%s), ladder restarted from the line bent by %+.3f\n",
-                           target_nodes, r.msg.c_str(), ladder_bends[ca] * ladder_span);
-                if (climb(ladder_bends[ca] * ladder_span)) {
+            for (int ca = ladder_next_start; climb && ca < ladder_starts() && ca - (ladder_has_plan ? 2 : 1) < _algorithm.guess_retries && ladder_span > 0 && !r.ok && !ladder_first_rung_failed; ++ca) {
+                const bool planned = ladder_start_planned(ca);
+                const double bend = ladder_start_bend(ca) * ladder_span;
+                if (_algorithm.print_level >= 5) {
+                    if (planned) printf("mesh sequencing: warm start on %zu nodes failed (%s), ladder restarted from the planned route\n", target_nodes, r.msg.c_str());
+                    else printf("mesh sequencing: warm start on %zu nodes failed (%s), ladder restarted from the line bent by %+.3f\n", target_nodes, r.msg.c_str(), bend);
+                }
+                if (climb(bend, planned)) {
                     solve_warm(warm);
                     ++_solution.mesh_iterations;
                 } else {

@@ -104,6 +104,9 @@ struct Alg {
     std::string linear_solver = "auto";            // Newton step: "host" (dense LDL^T), "device" (structured
                                                    // factorisation in HBM, emi_kkt_*), "auto" = device above 400 KKT rows
     int nlp_iter_max = 200;                        // per NLP solve (one mesh, one start), as ePSOPT.cpp:66
+    bool plan_second_start = true;                 // the route planned through the free space of the static keep-outs (clearance-weighted: planned_path_guess) is the
+                                                   // second start of a mesh-ladder climb, before the bent lines (false: the last cold-start attempt only).  256-scenario
+                                                   // Monte-Carlo set: 125.5 against 135.2 iterations per scenario, 3.91 against 3.65 solves/s (profiles/r04_notes.md section 24)
     int nlp_iter_budget = 0;                       // > 0: iterations ONE solve() may spend over all its meshes, rungs and restarts; when they are used
                                                    // up the problem is reported unsolved ("iteration budget exhausted") instead of being carried on
                                                    // -- a Monte-Carlo batch waits for its slowest scenario, and the slowest are the ones that wander
