@@ -579,8 +579,8 @@ def test_montecarlo_scenario_without_a_feasible_path_on_its_side_ends_early(buil
 
 def test_a_failed_rung_restarts_the_ladder_from_a_bent_guess(built):
     """Scenario 27 of the 513-node / 20 keep-out set: its 257-node rung ends locally infeasible.  The ladder must then start
-    again on 33 nodes from the straight line bent to one side -- not cold-start the 513-node mesh, which took four attempts of
-    400 iterations (41 s) before -- and solve the scenario."""
+    again on 33 nodes from another guess (the route planned through the free space of the keep-outs, then the straight line bent to one
+    side) -- not cold-start the 513-node mesh, which took four attempts of 400 iterations (41 s) before -- and solve the scenario."""
     exe = os.path.join(ROOT, "etol_amd", "lib", "etol_mi355x_montecarlo")
     env = dict(os.environ, EMI_MC_ONLY="27", EMI_MC_PRINT_LEVEL="5", EMI_MC_GATHER="0", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([exe, "32", "512", "20", "1"], capture_output=True, text=True, timeout=300, env=env)
@@ -590,7 +590,8 @@ def test_a_failed_rung_restarts_the_ladder_from_a_bent_guess(built):
     rc, iters, nodes = int(f[f.index("rc") + 1]), int(f[f.index("iterations") + 1]), int(f[f.index("nodes") + 1])
     assert rc == 0 and nodes == 513, line
     rung_failed = any(l.startswith("mesh sequencing:") and "converged" not in l and "nodes," in l for l in r.stdout.split("\n"))
-    assert not rung_failed or "ladder restarted from the line bent by" in r.stdout     # (should the rung converge one day: fine)
+    # (should the rung converge one day: fine; the restart is from the route planned through the free space first, then from the bent lines)
+    assert not rung_failed or "ladder restarted from the route planned" in r.stdout or "ladder restarted from the line bent by" in r.stdout
     assert "cold start on 513 nodes" not in r.stdout
     assert iters < 1200, line
 
