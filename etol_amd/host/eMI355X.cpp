@@ -1390,8 +1390,18 @@ void eMI355X::solve() {
     mi355x::NlpResult r_good;           // last converged solution and its mesh
     size_t M_good = 0;
     for (int mr = 0;; ++mr) {
+        // The warm start on the requested mesh, while the ladder still has a start it has not used: at most Alg::target_patience iterations
+        // (converged ones take 11 at the median, 24 at the 90th percentile, 212 at most over 256 Monte-Carlo scenarios; the one that fails used
+        // all 400 of nlp_iter_max -- 20 s of a 1024-node problem -- before the next start got its turn: scenario 558, r04_notes.md section 26)
+        auto target_warm = [&]() {
+            mi355x::NlpOptions w = warm;
+            const bool more_starts = climb && ladder_span > 0 && !ladder_first_rung_failed && ladder_next_start < ladder_starts() &&
+                                     ladder_next_start - (ladder_has_plan ? 2 : 1) < _algorithm.guess_retries;
+            if (_algorithm.target_patience > 0 && more_starts) w.max_iter = std::min(w.max_iter, _algorithm.target_patience);
+            solve_warm(w);
+        };
         if (mr == 0 && !sequenced) solve_cold_with_retries(opt);
-        else if (sequenced && mr == 0) solve_warm(warm);
+        else if (sequenced && mr == 0) target_warm();
         else solve_current_mesh(opt);
         ++_solution.mesh_iterations;
         if (!r.ok && sequenced && mr == 0) {
@@ -1407,8 +1417,9 @@ void eMI355X::solve() {
                     if (planned) printf("mesh sequencing: warm start on %zu nodes failed (%s), ladder restarted from the planned route\n", target_nodes, r.msg.c_str());
                     else printf("mesh sequencing: warm start on %zu nodes failed (%s), ladder restarted from the line bent by %+.3f\n", target_nodes, r.msg.c_str(), bend);
                 }
+                ladder_next_start = ca + 1;
                 if (climb(bend, planned)) {
-                    solve_warm(warm);
+                    target_warm();
                     ++_solution.mesh_iterations;
                 } else {
                     r.ok = false;

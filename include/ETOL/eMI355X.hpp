@@ -92,6 +92,8 @@ struct Alg {
                                                    // infeasible" (the interpolant sits on the wrong side of a keep-out) took 280 - 360 to say so, twice in
                                                    // a row in the two slowest scenarios of the 64 x 1024-node set (943 and 920 iterations): 1.93 solves/s
                                                    // without the rule, 2.50 - 2.60 with 60 - 100, 2.35 - 2.41 with 80 / 150 (paths differ) (r04_notes.md)
+    int target_patience = 200;                     // the warm start on the REQUESTED mesh gets this many iterations while the ladder still has an unused start
+                                                   // (0: nlp_iter_max); see solve()
     double mu_restart = 10.0;                      // NlpOptions::mu_restart of the warm starts: barrier parameter x this (at most 1e-3), once, when a warm
                                                    // start stagnates at a small parameter (0: off; 10 and 100 measured: profiles/r02_notes.md section 12)
     int warm_patience = 0;                         // > 0: a warm start (interpolated guess) still running after this many iterations is
