@@ -202,6 +202,8 @@ Result solve_scenario(int s, int nsteps, int ndiscs, int device, bool traced, co
     // config 4 one scenario spent 3287 iterations (91 of the run's 394 s) to end "locally infeasible" (profiles/r04_notes.md section 7)
     solver.getAlgorithm()->nlp_iter_budget = env_int("EMI_MC_BUDGET", 1000);
     if (getenv("EMI_MC_TARGET_PATIENCE")) solver.getAlgorithm()->target_patience = env_int("EMI_MC_TARGET_PATIENCE", 200);
+    if (getenv("EMI_MC_PLAN")) solver.getAlgorithm()->plan_first_start = env_int("EMI_MC_PLAN", 2) == 2;     // (A/B: 2 planned route first (default), 1 second, 0 last)
+    if (getenv("EMI_MC_PLAN_CLEARANCE")) solver.getAlgorithm()->plan_clearance = atof(getenv("EMI_MC_PLAN_CLEARANCE"));
     if (getenv("EMI_MC_PLAN")) solver.getAlgorithm()->plan_second_start = env_int("EMI_MC_PLAN", 1) != 0;     // (A/B: 0 = the planned route as the last cold-start attempt only)
     if (getenv("EMI_MC_DEFECT_SCALING")) solver.getAlgorithm()->defect_scaling = getenv("EMI_MC_DEFECT_SCALING");   // "state-based" (default) / "jacobian-based"
     if (getenv("EMI_MC_WARM_MU")) solver.getAlgorithm()->warm_mu_init = atof(getenv("EMI_MC_WARM_MU"));      // experiments

@@ -1023,7 +1023,7 @@ std::vector<double> initial_guess(const Prob& P) {
         for (size_t k = 0; k < M; ++k) z0[i * M + k] = a + (b - a) * 0.5 * (P.tau[k] + 1.0);
     }
     bool planned = false;
-    if (P.guess_planned && P.px < ns && P.py < ns) planned = planned_path_guess(P, &z0[P.px * M], &z0[P.py * M]);
+    if (P.guess_planned && P.px < ns && P.py < ns) planned = planned_path_guess(P, &z0[P.px * M], &z0[P.py * M], P.guess_clearance);
     if (!planned && P.guess_bend != 0 && P.px < ns && P.py < ns) {
         // the line bent sideways (half a sine wave along it): another homotopy class round the keep-outs
         const double dx = z0[P.px * M + M - 1] - z0[P.px * M], dy = z0[P.py * M + M - 1] - z0[P.py * M];
@@ -1083,6 +1083,7 @@ void eMI355X::evaluate(const std::vector<double>& z, std::vector<double>* res, s
 void eMI355X::solve() {
     if (!_dev || !_dev->ctx) die("solve() called before setup()");
     mi355x::Prob& P = _problem;
+    P.guess_clearance = _algorithm.plan_clearance;
     // Delayed states / controls (reference ePSOPT.cpp:231-248).  ePSOPT hands them to IPOPT through PSOPT like any other dependency of
     // the node functions.  Here the delayed values become variables of their node for the duration of the solve ("lifted"), tied to their
     // sources by linear coupling rows with the interpolation operators W(i dt) of the mesh: node functions, Jacobian entries and Hessian
@@ -1268,7 +1269,8 @@ void eMI355X::solve() {
     bool ladder_first_rung_failed = false;
     const double ladder_bends[4] = {0.15, -0.15, 0.35, -0.35};
     // start k of a climb: 0 the straight line, then (Alg::plan_second_start, if there is one) the planned route, then the bends
-    auto ladder_start_planned = [&](int k) { return ladder_has_plan && k == 1; };
+    // (Alg::plan_first_start, an experiment: the planned route FIRST and the straight line second)
+    auto ladder_start_planned = [&](int k) { return ladder_has_plan && k == (_algorithm.plan_first_start ? 0 : 1); };
     auto ladder_start_bend = [&](int k) { const int b = k - 1 - (ladder_has_plan ? 1 : 0); return (b >= 0 && b < 4) ? ladder_bends[b] : 0.0; };
     auto ladder_starts = [&]() { return 1 + (ladder_has_plan ? 1 : 0) + 4; };
 
@@ -1317,7 +1319,7 @@ void eMI355X::solve() {
         // 960 from 870 to 235 iterations and scenario 17 from 685 to 313: profiles/r04_notes.md section 24.)
         if (_algorithm.plan_second_start) {
             std::vector<double> px(P.nodes), py(P.nodes);
-            ladder_has_plan = P.npath > 0 && span > 0 && _algorithm.guess_retries > 0 && mi355x::planned_path_guess(P, px.data(), py.data());
+            ladder_has_plan = P.npath > 0 && span > 0 && _algorithm.guess_retries > 0 && mi355x::planned_path_guess(P, px.data(), py.data(), _algorithm.plan_clearance);
         }
         const int ladder_tries = (P.npath > 0 && span > 0) ? 1 + (ladder_has_plan ? 1 : 0) + std::min(4, std::max(0, _algorithm.guess_retries)) : 1;
         ladder_span = ladder_tries > 1 ? span : 0.0;

@@ -21,7 +21,7 @@ std::vector<double> initial_guess(const Prob& P);
 // positions of the nodes along a shortest path through the free space of the static keep-outs (the last cold-start guess of solve()):
 // false if the problem has no such rows or no route exists
 // clearance_weight x span: the clearance at which a step of the route costs twice its length (0: the shortest route)
-bool planned_path_guess(const Prob& P, double* xs, double* ys, double clearance_weight = 0.05);
+bool planned_path_guess(const Prob& P, double* xs, double* ys, double clearance_weight = 0.01);
 // variable scales of Alg::scaling = "automatic": max(|lower|, |upper|) per state / control (1 without a finite bound)
 std::vector<double> bound_scales(const Prob& P);
 

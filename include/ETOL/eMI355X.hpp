@@ -92,6 +92,13 @@ struct Alg {
                                                    // infeasible" (the interpolant sits on the wrong side of a keep-out) took 280 - 360 to say so, twice in
                                                    // a row in the two slowest scenarios of the 64 x 1024-node set (943 and 920 iterations): 1.93 solves/s
                                                    // without the rule, 2.50 - 2.60 with 60 - 100, 2.35 - 2.41 with 80 / 150 (paths differ) (r04_notes.md)
+    double plan_clearance = 0.01;                  // clearance (x the span) at which a step of the planned route costs twice its length.  256-scenario set, planned
+                                                   // route first: 0.1: mean cost 408.5, 105.6 iterations; 0.05: 402.3, 98.2; 0.02: 400.6, 97.3; 0.01: 400.3, 99.6
+                                                   // (the straight line first: 400.5, 125.5) -- profiles/r04_notes.md section 27
+    bool plan_first_start = true;                  // the planned route is the FIRST start of a climb of the mesh ladder, the straight line the second (needs
+                                                   // plan_second_start; false: the straight line first).  Config 4 in full: 206 s against 279 s, mean 98 against
+                                                   // 128.5 iterations, 90th percentile 126 against 270, mean cost of the solved 400.38 against 401.02; 1021 against
+                                                   // 1023 of 1024 solved within the example's budget
     int target_patience = 200;                     // the warm start on the REQUESTED mesh gets this many iterations while the ladder still has an unused start
                                                    // (0: nlp_iter_max); see solve()
     double mu_restart = 10.0;                      // NlpOptions::mu_restart of the warm starts: barrier parameter x this (at most 1e-3), once, when a warm
@@ -176,7 +183,8 @@ struct Prob {
     std::vector<double> guess_states, guess_controls;   // optional warm start, [n][nodes]
     std::vector<double> guess_lamF, guess_lamC;         // multipliers to go with it, [nstates][nodes] / [npath][nodes]
     double guess_bend = 0;                              // default guess: sideways offset of the straight line at mid-horizon
-    bool guess_planned = false;                         // default guess: positions along a shortest path through the free space of the static keep-outs
+    bool guess_planned = false;                         // default guess: positions along a route through the free space of the static keep-outs
+    double guess_clearance = 0.01;                      // ... whose steps cost twice their length at a clearance of this x the span (0: the shortest route)
                                                         // (set by solve() when it retries a locally infeasible start)
 };
 
