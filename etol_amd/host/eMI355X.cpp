@@ -938,6 +938,9 @@ bool planned_path_guess(const Prob& P, double* xs, double* ys, double clearance_
                 clear[(size_t)i * N + q] = std::min(clear[(size_t)i * N + q], c);
             }
     }
+    bool any_static = false;
+    for (double c : clear) if (c < 1e299) { any_static = true; break; }
+    if (!any_static) return false;                        // moving keep-outs only: nothing to plan round (the straight line is the route)
     const double room = clearance_weight * span;          // a step at this clearance costs twice its length
     for (double grow : {0.25, 0.1, 0.0}) {
         std::vector<char> blocked((size_t)N * N, 0);
