@@ -62,6 +62,13 @@ for nd in (0, 5):
     rc = H.harness_solve_quadrotor_oracle(orc, 24, 0.16, nd, 1e-8, 0, C.byref(cost), C.byref(M), X.ctypes.data_as(D), U.ctypes.data_as(D), 64, C.byref(it))
     print("quadrotor, jacobian-based defect scaling", nd, rc, cost.value, it.value, H.harness_last_message().decode())
 H.harness_set_defect_scaling(0)
+# the planned cold-start route (grid Dijkstra) on a layout with a wall and a gap, and on a walled-in start
+H.harness_planned_path.argtypes = [C.c_int, D, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, D, D]
+discs = np.array([1.10, 2.09, 0.44, 1.96, 2.52, 0.58, 1.75, 1.64, 0.41, 1.23, 2.72, 0.33, 4.04, 3.13, 0.30, 7.21, 5.93, 0.21])
+xs, ys = np.zeros(129), np.zeros(129)
+print("planned route", H.harness_planned_path(6, discs.ctypes.data_as(D), 1.0, 1.0, 8.0, 6.0, 0.0, 10.0, 129, xs.ctypes.data_as(D), ys.ctypes.data_as(D)), xs[:3], ys[:3])
+ring = np.array([v for a in np.linspace(0, 2 * np.pi, 16, endpoint=False) for v in (1 + 0.9 * np.cos(a), 1 + 0.9 * np.sin(a), 0.5)])
+print("walled in", H.harness_planned_path(16, ring.ctypes.data_as(D), 1.0, 1.0, 8.0, 6.0, -5.0, 10.0, 129, xs.ctypes.data_as(D), ys.ctypes.data_as(D)))
 print("asan run complete")
 PY
 cd $OUT && ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python run.py
